@@ -1,0 +1,425 @@
+// ls_api.hip — the extern "C" boundary declared in include/ls_amd.h: context
+// life-cycle, argument validation, host<->device staging.  Kernels live in
+// nq_kernels.hip / sched_kernels.hip.  No CPU fallback exists anywhere in this
+// library: without a HIP device ls_ctx_create fails.
+#include <cstdarg>
+#include <cstring>
+#include <new>
+
+#include "ls_common.hpp"
+
+namespace lsamd {
+
+static thread_local std::string g_create_err;
+
+int set_err(const ls_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+// nq_kernels.hip
+int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, const long long *cur_d,
+                      const int *cols_d, const int *n_cols_d, int max_cols, long long window,
+                      ls_nq_result *results_d, long long *scores_out_d);
+int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, long long *col_scores_d,
+                      long long *scores_d);
+// sched_kernels.hip
+int sched_score_dev(ls_ctx *ctx, int n_states, const int *states_d, long long *hard_d, long long *soft_d,
+                    long long *terms_d);
+int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const ls_sched_move *moves_d,
+                         const long long *n_moves_d, long long max_moves, long long window,
+                         ls_sched_result *results_d, long long *hard_out_d, long long *soft_out_d);
+
+static int bind(ls_ctx *ctx)
+{
+    if (!ctx) return LS_ERR_INVALID;
+    LS_HIP(ctx, hipSetDevice(ctx->device));
+    return LS_OK;
+}
+
+} // namespace lsamd
+
+using namespace lsamd;
+
+#define LS_BIND(ctx)                         \
+    do {                                     \
+        int rc__ = lsamd::bind(ctx);         \
+        if (rc__ != LS_OK) return rc__;      \
+    } while (0)
+
+#define LS_REQUIRE(ctx, cond, ...)                                           \
+    do {                                                                     \
+        if (!(cond)) return lsamd::set_err((ctx), LS_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+extern "C" {
+
+int ls_abi_version(void) { return LS_ABI_VERSION; }
+
+int ls_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ls_ctx_create(int device_id, ls_ctx **out)
+{
+    if (!out) return set_err(nullptr, LS_ERR_INVALID, "ls_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_err(nullptr, LS_ERR_NO_DEVICE,
+                       "no HIP device available (%s); this library has no CPU fallback",
+                       e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n)
+        return set_err(nullptr, LS_ERR_NO_DEVICE, "device id %d out of range [0, %d)", device_id, n);
+    ls_ctx *ctx = new (std::nothrow) ls_ctx();
+    if (!ctx) return set_err(nullptr, LS_ERR_NOMEM, "out of host memory");
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        set_err(nullptr, LS_ERR_HIP, "device %d initialisation failed: %s", device_id, hipGetErrorString(e));
+        delete ctx;
+        return LS_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    ctx->n_cus = prop.multiProcessorCount;
+    ctx->wave_size = prop.warpSize;
+    ctx->clock_khz = prop.clockRate;
+    snprintf(ctx->dev_name, sizeof ctx->dev_name, "%s (%s)", prop.name, prop.gcnArchName);
+    if (ctx->wave_size != 64) {
+        set_err(nullptr, LS_ERR_UNSUPPORTED, "device %d has wavefront size %d; the kernels are written for wave64 (gfx950)",
+                device_id, ctx->wave_size);
+        (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return LS_ERR_UNSUPPORTED;
+    }
+    *out = ctx;
+    return LS_OK;
+}
+
+int ls_ctx_destroy(ls_ctx *ctx)
+{
+    if (!ctx) return LS_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->nq_rows, &ctx->nq_cur, &ctx->nq_cols, &ctx->nq_ncols, &ctx->nq_results,
+                      &ctx->nq_scores, &ctx->nq_keys, &ctx->nq_tabs, &ctx->nq_colscores, &ctx->nq_totals,
+                      &ctx->sc_states, &ctx->sc_moves, &ctx->sc_nmoves, &ctx->sc_results, &ctx->sc_hard,
+                      &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sched.holiday_bits};
+    for (DevBuf *b : bufs) b->release();
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return LS_OK;
+}
+
+const char *ls_last_error(const ls_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int ls_ctx_set_stream(ls_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return LS_ERR_INVALID;
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return LS_OK;
+}
+
+int ls_ctx_synchronize(ls_ctx *ctx)
+{
+    LS_BIND(ctx);
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LS_OK;
+}
+
+int ls_ctx_set_nq_algo(ls_ctx *ctx, int algo)
+{
+    if (!ctx) return LS_ERR_INVALID;
+    LS_REQUIRE(ctx, algo == LS_NQ_ALGO_SCAN || algo == LS_NQ_ALGO_TABLE, "unknown N-queens algo %d", algo);
+    ctx->nq_algo = algo;
+    return LS_OK;
+}
+
+int ls_ctx_get_nq_algo(const ls_ctx *ctx, int *algo)
+{
+    if (!ctx || !algo) return LS_ERR_INVALID;
+    *algo = ctx->nq_algo;
+    return LS_OK;
+}
+
+int ls_ctx_device_info(const ls_ctx *ctx, int *n_cus, int *wave_size, int *clock_khz, char *name, int name_cap)
+{
+    if (!ctx) return LS_ERR_INVALID;
+    if (n_cus) *n_cus = ctx->n_cus;
+    if (wave_size) *wave_size = ctx->wave_size;
+    if (clock_khz) *clock_khz = ctx->clock_khz;
+    if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", ctx->dev_name);
+    return LS_OK;
+}
+
+/* ------------------------------------------------------------- N-queens */
+
+static int nq_check_dims(ls_ctx *ctx, int32_t n_restarts, int32_t n, int32_t max_cols, int64_t window)
+{
+    LS_REQUIRE(ctx, n_restarts >= 1, "n_restarts must be >= 1 (got %d)", n_restarts);
+    LS_REQUIRE(ctx, n >= 1, "n must be >= 1 (got %d)", n);
+    if (n > LS_NQ_MAX_N) return set_err(ctx, LS_ERR_UNSUPPORTED, "n = %d exceeds LS_NQ_MAX_N = %d", n, LS_NQ_MAX_N);
+    LS_REQUIRE(ctx, max_cols >= 0, "max_cols must be >= 0 (got %d)", max_cols);
+    LS_REQUIRE(ctx, window >= 0, "window must be >= 0 (got %lld)", (long long)window);
+    return LS_OK;
+}
+
+static long long nq_clamp_window(int64_t window, int32_t max_cols, int32_t n)
+{
+    const long long cap = (long long)max_cols * n + 1;
+    return window > cap ? cap : window;
+}
+
+int ls_nqueens_eval_batch_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows_d,
+                              const int64_t *cur_scores_d, const int32_t *cols_d, const int32_t *n_cols_d,
+                              int32_t max_cols, int64_t window, ls_nq_result *results_d, int64_t *scores_out_d)
+{
+    LS_BIND(ctx);
+    int rc = nq_check_dims(ctx, n_restarts, n, max_cols, window);
+    if (rc != LS_OK) return rc;
+    LS_REQUIRE(ctx, rows_d && cur_scores_d && n_cols_d && results_d && (cols_d || max_cols == 0),
+               "null device pointer");
+    return nq_eval_batch_dev(ctx, n_restarts, n, rows_d, reinterpret_cast<const long long *>(cur_scores_d), cols_d,
+                             n_cols_d, max_cols, nq_clamp_window(window, max_cols, n), results_d,
+                             reinterpret_cast<long long *>(scores_out_d));
+}
+
+int ls_nqueens_eval_batch(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows,
+                          const int64_t *cur_scores, const int32_t *cols, const int32_t *n_cols, int32_t max_cols,
+                          int64_t window, ls_nq_result *results, int64_t *scores_out)
+{
+    LS_BIND(ctx);
+    int rc = nq_check_dims(ctx, n_restarts, n, max_cols, window);
+    if (rc != LS_OK) return rc;
+    LS_REQUIRE(ctx, rows && cur_scores && n_cols && results && (cols || max_cols == 0), "null pointer");
+    for (long long i = 0; i < (long long)n_restarts * n; i++)
+        LS_REQUIRE(ctx, rows[i] >= 0 && rows[i] < n, "rows[%lld] = %d outside [0, %d)", i, rows[i], n);
+    for (int r = 0; r < n_restarts; r++) {
+        LS_REQUIRE(ctx, n_cols[r] >= 0 && n_cols[r] <= max_cols, "n_cols[%d] = %d outside [0, max_cols = %d]", r,
+                   n_cols[r], max_cols);
+        for (int s = 0; s < n_cols[r]; s++) {
+            const int c = cols[(long long)r * max_cols + s];
+            LS_REQUIRE(ctx, c >= 0 && c < n, "cols[%d][%d] = %d outside [0, %d)", r, s, c, n);
+        }
+    }
+    const size_t rows_b = (size_t)n_restarts * n * 4, cur_b = (size_t)n_restarts * 8,
+                 cols_b = (size_t)n_restarts * max_cols * 4, nc_b = (size_t)n_restarts * 4,
+                 res_b = (size_t)n_restarts * sizeof(ls_nq_result),
+                 sc_b = scores_out ? (size_t)n_restarts * max_cols * n * 8 : 0;
+    LS_RESERVE(ctx, ctx->nq_rows, rows_b);
+    LS_RESERVE(ctx, ctx->nq_cur, cur_b);
+    LS_RESERVE(ctx, ctx->nq_cols, cols_b);
+    LS_RESERVE(ctx, ctx->nq_ncols, nc_b);
+    LS_RESERVE(ctx, ctx->nq_results, res_b);
+    if (sc_b) LS_RESERVE(ctx, ctx->nq_scores, sc_b);
+    LS_HIP(ctx, hipMemcpyAsync(ctx->nq_rows.p, rows, rows_b, hipMemcpyHostToDevice, ctx->stream));
+    LS_HIP(ctx, hipMemcpyAsync(ctx->nq_cur.p, cur_scores, cur_b, hipMemcpyHostToDevice, ctx->stream));
+    if (cols_b) LS_HIP(ctx, hipMemcpyAsync(ctx->nq_cols.p, cols, cols_b, hipMemcpyHostToDevice, ctx->stream));
+    LS_HIP(ctx, hipMemcpyAsync(ctx->nq_ncols.p, n_cols, nc_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = nq_eval_batch_dev(ctx, n_restarts, n, ctx->nq_rows.as<int>(), ctx->nq_cur.as<long long>(),
+                           ctx->nq_cols.as<int>(), ctx->nq_ncols.as<int>(), max_cols,
+                           nq_clamp_window(window, max_cols, n), ctx->nq_results.as<ls_nq_result>(),
+                           sc_b ? ctx->nq_scores.as<long long>() : nullptr);
+    if (rc != LS_OK) return rc;
+    LS_HIP(ctx, hipMemcpyAsync(results, ctx->nq_results.p, res_b, hipMemcpyDeviceToHost, ctx->stream));
+    if (sc_b) LS_HIP(ctx, hipMemcpyAsync(scores_out, ctx->nq_scores.p, sc_b, hipMemcpyDeviceToHost, ctx->stream));
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LS_OK;
+}
+
+int ls_nqueens_eval(ls_ctx *ctx, int32_t n, const int32_t *rows, int64_t cur_score, const int32_t *cols,
+                    int32_t n_cols, int64_t window, ls_nq_result *out, int64_t *scores_out)
+{
+    return ls_nqueens_eval_batch(ctx, 1, n, rows, &cur_score, cols, &n_cols, n_cols, window, out, scores_out);
+}
+
+int ls_nqueens_col_scores_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows_d,
+                              int64_t *col_scores_d, int64_t *scores_d)
+{
+    LS_BIND(ctx);
+    int rc = nq_check_dims(ctx, n_restarts, n, 0, 0);
+    if (rc != LS_OK) return rc;
+    LS_REQUIRE(ctx, rows_d != nullptr, "null device pointer");
+    return nq_col_scores_dev(ctx, n_restarts, n, rows_d, reinterpret_cast<long long *>(col_scores_d),
+                             reinterpret_cast<long long *>(scores_d));
+}
+
+int ls_nqueens_col_scores(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows, int64_t *col_scores,
+                          int64_t *scores)
+{
+    LS_BIND(ctx);
+    int rc = nq_check_dims(ctx, n_restarts, n, 0, 0);
+    if (rc != LS_OK) return rc;
+    LS_REQUIRE(ctx, rows != nullptr, "null pointer");
+    for (long long i = 0; i < (long long)n_restarts * n; i++)
+        LS_REQUIRE(ctx, rows[i] >= 0 && rows[i] < n, "rows[%lld] = %d outside [0, %d)", i, rows[i], n);
+    const size_t rows_b = (size_t)n_restarts * n * 4, cs_b = (size_t)n_restarts * n * 8, t_b = (size_t)n_restarts * 8;
+    LS_RESERVE(ctx, ctx->nq_rows, rows_b);
+    LS_RESERVE(ctx, ctx->nq_colscores, cs_b);
+    LS_RESERVE(ctx, ctx->nq_totals, t_b);
+    LS_HIP(ctx, hipMemcpyAsync(ctx->nq_rows.p, rows, rows_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = nq_col_scores_dev(ctx, n_restarts, n, ctx->nq_rows.as<int>(), ctx->nq_colscores.as<long long>(),
+                           ctx->nq_totals.as<long long>());
+    if (rc != LS_OK) return rc;
+    if (col_scores)
+        LS_HIP(ctx, hipMemcpyAsync(col_scores, ctx->nq_colscores.p, cs_b, hipMemcpyDeviceToHost, ctx->stream));
+    if (scores) LS_HIP(ctx, hipMemcpyAsync(scores, ctx->nq_totals.p, t_b, hipMemcpyDeviceToHost, ctx->stream));
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LS_OK;
+}
+
+/* ------------------------------------------------------------ scheduling */
+
+int ls_sched_instance_upload(ls_ctx *ctx, int32_t n_days_scored, int32_t n_days_stored, int32_t start_weekday,
+                             int32_t n_employees, const uint64_t *holiday_bits)
+{
+    LS_BIND(ctx);
+    LS_REQUIRE(ctx, n_days_scored >= 1, "n_days_scored must be >= 1 (got %d)", n_days_scored);
+    if (n_days_stored > LS_SCHED_MAX_DAYS)
+        return set_err(ctx, LS_ERR_UNSUPPORTED, "n_days_stored = %d exceeds LS_SCHED_MAX_DAYS = %d", n_days_stored,
+                       LS_SCHED_MAX_DAYS);
+    LS_REQUIRE(ctx, n_days_stored >= n_days_scored, "n_days_stored (%d) < n_days_scored (%d)", n_days_stored,
+               n_days_scored);
+    LS_REQUIRE(ctx, start_weekday >= 0 && start_weekday <= 6, "start_weekday %d outside [0, 6]", start_weekday);
+    LS_REQUIRE(ctx, n_employees >= 1, "n_employees must be >= 1 (got %d)", n_employees);
+    LS_REQUIRE(ctx, holiday_bits != nullptr, "holiday_bits is NULL");
+    const uint64_t scored_mask = n_days_scored >= 64 ? ~0ull : ((1ull << n_days_scored) - 1);
+    for (int e = 0; e < n_employees; e++)
+        LS_REQUIRE(ctx, (holiday_bits[e] & ~scored_mask) == 0,
+                   "employee %d has a holiday outside the scored range (the reference panics here: "
+                   "examples/employee-scheduling/src/lib.rs:275)", e);
+    // the stream may still be reading the previous instance
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LS_RESERVE(ctx, ctx->sched.holiday_bits, (size_t)n_employees * 8);
+    LS_HIP(ctx, hipMemcpyAsync(ctx->sched.holiday_bits.p, holiday_bits, (size_t)n_employees * 8,
+                               hipMemcpyHostToDevice, ctx->stream));
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sched.n_days_scored = n_days_scored;
+    ctx->sched.n_days_stored = n_days_stored;
+    ctx->sched.start_weekday = start_weekday;
+    ctx->sched.n_employees = n_employees;
+    ctx->sched.valid = true;
+    return LS_OK;
+}
+
+static int sched_check_state(ls_ctx *ctx, const int32_t *states, long long count)
+{
+    for (long long i = 0; i < count; i++)
+        LS_REQUIRE(ctx, states[i] >= 0 && states[i] < ctx->sched.n_employees,
+                   "state entry %lld = %d is not an employee index in [0, %d)", i, states[i], ctx->sched.n_employees);
+    return LS_OK;
+}
+
+int ls_sched_score(ls_ctx *ctx, int32_t n_states, const int32_t *states, int64_t *hard, int64_t *soft,
+                   int64_t *terms)
+{
+    LS_BIND(ctx);
+    if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
+    LS_REQUIRE(ctx, n_states >= 1 && states && hard && soft, "bad arguments");
+    const int S = ctx->sched.n_days_stored;
+    int rc = sched_check_state(ctx, states, (long long)n_states * S);
+    if (rc != LS_OK) return rc;
+    const size_t st_b = (size_t)n_states * S * 4, sc_b = (size_t)n_states * 8, tm_b = (size_t)n_states * 64;
+    LS_RESERVE(ctx, ctx->sc_states, st_b);
+    LS_RESERVE(ctx, ctx->sc_hard, sc_b);
+    LS_RESERVE(ctx, ctx->sc_soft, sc_b);
+    LS_RESERVE(ctx, ctx->sc_terms, tm_b);
+    LS_HIP(ctx, hipMemcpyAsync(ctx->sc_states.p, states, st_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = sched_score_dev(ctx, n_states, ctx->sc_states.as<int>(), ctx->sc_hard.as<long long>(),
+                         ctx->sc_soft.as<long long>(), ctx->sc_terms.as<long long>());
+    if (rc != LS_OK) return rc;
+    LS_HIP(ctx, hipMemcpyAsync(hard, ctx->sc_hard.p, sc_b, hipMemcpyDeviceToHost, ctx->stream));
+    LS_HIP(ctx, hipMemcpyAsync(soft, ctx->sc_soft.p, sc_b, hipMemcpyDeviceToHost, ctx->stream));
+    if (terms) LS_HIP(ctx, hipMemcpyAsync(terms, ctx->sc_terms.p, tm_b, hipMemcpyDeviceToHost, ctx->stream));
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LS_OK;
+}
+
+int ls_sched_eval_batch_dev(ls_ctx *ctx, int32_t n_restarts, const int32_t *states_d, const ls_sched_move *moves_d,
+                            const int64_t *n_moves_d, int64_t max_moves, int64_t window, ls_sched_result *results_d,
+                            int64_t *hard_out_d, int64_t *soft_out_d)
+{
+    LS_BIND(ctx);
+    if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
+    LS_REQUIRE(ctx, n_restarts >= 1 && max_moves >= 0 && window >= 0, "bad sizes");
+    LS_REQUIRE(ctx, states_d && n_moves_d && results_d && (moves_d || max_moves == 0), "null device pointer");
+    return sched_eval_batch_dev(ctx, n_restarts, states_d, moves_d, reinterpret_cast<const long long *>(n_moves_d),
+                                max_moves, window, results_d, reinterpret_cast<long long *>(hard_out_d),
+                                reinterpret_cast<long long *>(soft_out_d));
+}
+
+int ls_sched_eval_batch(ls_ctx *ctx, int32_t n_restarts, const int32_t *states, const ls_sched_move *moves,
+                        const int64_t *n_moves, int64_t max_moves, int64_t window, ls_sched_result *results,
+                        int64_t *hard_out, int64_t *soft_out)
+{
+    LS_BIND(ctx);
+    if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
+    LS_REQUIRE(ctx, n_restarts >= 1 && max_moves >= 0 && window >= 0, "bad sizes");
+    LS_REQUIRE(ctx, states && n_moves && results && (moves || max_moves == 0), "null pointer");
+    const int S = ctx->sched.n_days_stored, D = ctx->sched.n_days_scored, E = ctx->sched.n_employees;
+    int rc = sched_check_state(ctx, states, (long long)n_restarts * S);
+    if (rc != LS_OK) return rc;
+    for (int r = 0; r < n_restarts; r++) {
+        LS_REQUIRE(ctx, n_moves[r] >= 0 && n_moves[r] <= max_moves, "n_moves[%d] = %lld outside [0, %lld]", r,
+                   (long long)n_moves[r], (long long)max_moves);
+        for (long long k = 0; k < n_moves[r]; k++) {
+            const ls_sched_move &m = moves[(long long)r * max_moves + k];
+            // ChangeDay may address any STORED day (the exhaustive proposer does, lib.rs:530);
+            // the random proposer only addresses scored days (lib.rs:486)
+            if (m.type == 0)
+                LS_REQUIRE(ctx, m.a >= 0 && m.a < S && m.b >= 0 && m.b < E, "move %lld of restart %d: bad ChangeDay(%d, %d)",
+                           k, r, m.a, m.b);
+            else if (m.type == 1)
+                LS_REQUIRE(ctx, m.a >= 0 && m.a < S && m.b >= 0 && m.b < S, "move %lld of restart %d: bad SwapDays(%d, %d)",
+                           k, r, m.a, m.b);
+            else
+                return set_err(ctx, LS_ERR_INVALID, "move %lld of restart %d: unknown type %d", k, r, m.type);
+        }
+    }
+    (void)D;
+    const size_t st_b = (size_t)n_restarts * S * 4, mv_b = (size_t)n_restarts * max_moves * sizeof(ls_sched_move),
+                 nm_b = (size_t)n_restarts * 8, res_b = (size_t)n_restarts * sizeof(ls_sched_result),
+                 out_b = (size_t)n_restarts * max_moves * 8;
+    LS_RESERVE(ctx, ctx->sc_states, st_b);
+    LS_RESERVE(ctx, ctx->sc_moves, mv_b);
+    LS_RESERVE(ctx, ctx->sc_nmoves, nm_b);
+    LS_RESERVE(ctx, ctx->sc_results, res_b);
+    if (hard_out) LS_RESERVE(ctx, ctx->sc_hard, out_b);
+    if (soft_out) LS_RESERVE(ctx, ctx->sc_soft, out_b);
+    LS_HIP(ctx, hipMemcpyAsync(ctx->sc_states.p, states, st_b, hipMemcpyHostToDevice, ctx->stream));
+    if (mv_b) LS_HIP(ctx, hipMemcpyAsync(ctx->sc_moves.p, moves, mv_b, hipMemcpyHostToDevice, ctx->stream));
+    LS_HIP(ctx, hipMemcpyAsync(ctx->sc_nmoves.p, n_moves, nm_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = sched_eval_batch_dev(ctx, n_restarts, ctx->sc_states.as<int>(), ctx->sc_moves.as<ls_sched_move>(),
+                              ctx->sc_nmoves.as<long long>(), max_moves, window,
+                              ctx->sc_results.as<ls_sched_result>(),
+                              hard_out ? ctx->sc_hard.as<long long>() : nullptr,
+                              soft_out ? ctx->sc_soft.as<long long>() : nullptr);
+    if (rc != LS_OK) return rc;
+    LS_HIP(ctx, hipMemcpyAsync(results, ctx->sc_results.p, res_b, hipMemcpyDeviceToHost, ctx->stream));
+    if (hard_out && out_b)
+        LS_HIP(ctx, hipMemcpyAsync(hard_out, ctx->sc_hard.p, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    if (soft_out && out_b)
+        LS_HIP(ctx, hipMemcpyAsync(soft_out, ctx->sc_soft.p, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LS_OK;
+}
+
+int ls_sched_eval(ls_ctx *ctx, const int32_t *state, const ls_sched_move *moves, int64_t n_moves, int64_t window,
+                  ls_sched_result *out, int64_t *hard_out, int64_t *soft_out)
+{
+    return ls_sched_eval_batch(ctx, 1, state, moves, &n_moves, n_moves, window, out, hard_out, soft_out);
+}
+
+} // extern "C"

@@ -1,0 +1,146 @@
+// ls_common.hpp — context object, error plumbing and wavefront helpers shared by
+// the gfx950 kernels.  Product code: never includes or links anything under
+// oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/ls_amd.h"
+
+namespace lsamd {
+
+// ---------------------------------------------------------------- device bufs
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    // grow-only; contents are not preserved across a grow
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes < 256 ? 256 : bytes;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct SchedInstance {
+    bool valid = false;
+    int n_days_scored = 0, n_days_stored = 0, start_weekday = 0, n_employees = 0;
+    DevBuf holiday_bits; // uint64[n_employees]
+};
+
+} // namespace lsamd
+
+struct ls_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int nq_algo = LS_NQ_ALGO_SCAN;
+    int n_cus = 0;
+    int wave_size = 0;
+    int clock_khz = 0;
+    char dev_name[256] = {0};
+    mutable std::string err;
+
+    // persistent workspaces (grow-only)
+    lsamd::DevBuf nq_rows, nq_cur, nq_cols, nq_ncols, nq_results, nq_scores, nq_keys, nq_tabs,
+        nq_colscores, nq_totals;
+    lsamd::DevBuf sc_states, sc_moves, sc_nmoves, sc_results, sc_hard, sc_soft, sc_keys, sc_terms;
+    lsamd::SchedInstance sched;
+};
+
+namespace lsamd {
+
+int set_err(const ls_ctx *ctx, int code, const char *fmt, ...);
+
+#define LS_HIP(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return lsamd::set_err((ctx), LS_ERR_HIP, "%s failed: %s (%s:%d)", #call,        \
+                                  hipGetErrorString(e__), __FILE__, __LINE__);              \
+    } while (0)
+
+#define LS_RESERVE(ctx, buf, bytes)                                                         \
+    do {                                                                                    \
+        hipError_t e__ = (buf).reserve(bytes);                                              \
+        if (e__ != hipSuccess)                                                              \
+            return lsamd::set_err((ctx), LS_ERR_NOMEM, "device allocation of %zu bytes failed: %s", \
+                                  (size_t)(bytes), hipGetErrorString(e__));                 \
+    } while (0)
+
+// one copy per translation unit that launches it
+static __global__ void fill_i64_kernel(long long *p, long long value, long long count)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (long long)gridDim.x * blockDim.x)
+        p[i] = value;
+}
+
+// ------------------------------------------------------------ wavefront utils
+// DPP controls (gfx9 family, wave64)
+#define LS_DPP_QUAD_1032 0xB1
+#define LS_DPP_QUAD_2301 0x4E
+#define LS_DPP_ROW_HALF_MIRROR 0x141
+#define LS_DPP_ROW_MIRROR 0x140
+#define LS_DPP_ROW_BCAST15 0x142
+#define LS_DPP_ROW_BCAST31 0x143
+
+// Sum over the 64 lanes of a wavefront; the total is returned wave-uniform
+// (read from lane 63).  6 DPP adds, no LDS.
+__device__ __forceinline__ int wave_sum_i32(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_QUAD_1032, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_QUAD_2301, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_ROW_HALF_MIRROR, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_ROW_MIRROR, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_ROW_BCAST15, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+__device__ __forceinline__ int wave_max_i32(int x)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        int o = __shfl_xor(x, m, 64);
+        x = o > x ? o : x;
+    }
+    return x;
+}
+
+__device__ __forceinline__ int wave_min_i32(int x)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        int o = __shfl_xor(x, m, 64);
+        x = o < x ? o : x;
+    }
+    return x;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        unsigned lo = __shfl_xor((unsigned)x, m, 64);
+        unsigned hi = __shfl_xor((unsigned)(x >> 32), m, 64);
+        unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        x = o < x ? o : x;
+    }
+    return x;
+}
+
+} // namespace lsamd

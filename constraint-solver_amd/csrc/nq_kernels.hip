@@ -1,0 +1,586 @@
+// nq_kernels.hip — gfx950 kernels for the N-queens neighbourhood pipeline.
+//
+// Replaces, per launch and for a batch of independent restarts, the reference's
+//   iter_local_moves -> filter(!tabu) -> map(score) -> take(window) -> sort -> first
+// (local-search/src/local_search.rs:315-325) with the N-queens plug-in
+// (examples/nqueens/src/lib.rs:74-87 pair test, :126-140 score, :214-234 order).
+//
+// Scoring identity used by every kernel here (checked against the literal
+// O(n^2) restatement in the oracle tests):
+//   score(board with rows[c] = v) = score(board) - 2*conf(c, rows[c]) + 2*conf(c, v)
+//   conf(c, r) = #{ j != c : rows[j] == r  or  |rows[j] - r| == |j - c| }
+// and the pair test splits into three mutually exclusive equalities
+//   rows[j] == r,   rows[j] - j == r - c,   rows[j] + j == r + c
+// so with R[j] = rows[j], A[j] = rows[j] - j, B[j] = rows[j] + j (independent of
+// the candidate) a candidate (c, v) is three equality scans of the same state.
+//
+// Winner selection: minimum by (score, board vector) (local_search.rs:29-37).
+// All candidates of one launch are single-position edits of one board, so the
+// vector order has a closed form: edits that lower rows[c] ("down") sort before
+// all others by (c asc, v asc); edits that raise it ("up") sort after, by
+// (c desc, v asc).  A 64-bit key (delta | up | colkey | v) makes the argmin an
+// integer min.  delta = conf(c,v) - conf(c,rows[c]) orders like the score.
+//
+// Kernel families
+//   SCAN  (default, north-star shape): one wavefront per candidate; the packed
+//         state lives in the wavefront's registers (n <= 4096) or in LDS
+//         (n <= 32768); per-lane match counts are reduced with DPP adds; each
+//         wavefront keeps a running key minimum, blocks combine through LDS and
+//         publish with one 64-bit atomicMin.
+//   TABLE occupancy histograms (rows / two diagonals) built once per board;
+//         a candidate is three table reads.  One lane per candidate.
+#include "ls_common.hpp"
+
+namespace lsamd {
+
+constexpr int NQ_DELTA_BIAS = 1 << 17; // |delta| <= n + 2 <= 32770
+constexpr unsigned long long NQ_KEY_EMPTY = ~0ull;
+constexpr int NQ_SENT = -(1 << 30); // padding value that can never satisfy an equality
+
+struct NqArgs {
+    const int *rows;             // [n_restarts][n]
+    const long long *cur_scores; // [n_restarts]
+    const int *cols;             // [n_restarts][max_cols]
+    const int *n_cols;           // [n_restarts]
+    int n;
+    int n_restarts;
+    int max_cols;
+    long long window;
+    unsigned long long *best_keys; // [n_restarts], pre-set to NQ_KEY_EMPTY
+    long long *scores_out;         // nullable [n_restarts][max_cols*n], pre-filled with INT64_MIN
+    const int *tabs;               // TABLE only: [n_restarts][tab_stride]
+    int tab_stride;
+};
+
+__device__ __forceinline__ unsigned long long nq_key_hi(int is_up, int c, int n)
+{
+    const unsigned colkey = is_up ? (unsigned)(n - 1 - c) : (unsigned)c;
+    return ((unsigned long long)(unsigned)is_up << 30) | ((unsigned long long)colkey << 15);
+}
+
+__device__ __forceinline__ unsigned long long nq_key(int delta, unsigned long long hi, int v)
+{
+    return ((unsigned long long)(unsigned)(delta + NQ_DELTA_BIAS) << 31) | hi | (unsigned)v;
+}
+
+__device__ __forceinline__ unsigned long long u64min(unsigned long long a, unsigned long long b)
+{
+    return b < a ? b : a;
+}
+
+// Sub-ranges of values v in [vs, ve) of one column that are real candidates:
+// not the no-op v == rc, and inside the window.  rank(v) = base + v - (v > rc)
+// must be < window  (tabu candidates do not consume window, local_search.rs:319-321).
+struct NqRanges {
+    int d0, d1; // "down" moves  v in [d0, d1),  v < rc
+    int u0, u1; // "up" moves    v in [u0, u1),  v > rc
+};
+
+__device__ __forceinline__ NqRanges nq_ranges(int vs, int ve, int rc, long long base, long long window)
+{
+    long long wrem = window - base; // candidates still allowed from this column on
+    NqRanges r;
+    if (wrem <= 0) { r.d0 = r.d1 = r.u0 = r.u1 = 0; return r; }
+    const long long lim_d = wrem;     // v < wrem           for v < rc
+    const long long lim_u = wrem + 1; // v - 1 < wrem       for v > rc
+    r.d0 = vs;
+    long long d1 = ve < rc ? ve : rc;
+    if (d1 > lim_d) d1 = lim_d;
+    r.d1 = (int)d1;
+    r.u0 = vs > rc + 1 ? vs : rc + 1;
+    long long u1 = ve;
+    if (u1 > lim_u) u1 = lim_u;
+    r.u1 = (int)u1;
+    if (r.d1 < r.d0) r.d1 = r.d0;
+    if (r.u1 < r.u0) r.u1 = r.u0;
+    return r;
+}
+
+// ===================================================================== SCAN
+// Register-resident state: lane l holds columns j = l + 64*i, i < NR.
+
+template <int NR>
+__device__ __forceinline__ int nq_count1(const int (&R)[NR], const int (&A)[NR], const int (&B)[NR],
+                                         int v, int va, int vb)
+{
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < NR; i++) c += (int)((R[i] == v) | (A[i] == va) | (B[i] == vb));
+    return wave_sum_i32(c);
+}
+
+template <int NR>
+__device__ __forceinline__ void nq_scan_range_regs(const int (&R)[NR], const int (&A)[NR],
+                                                   const int (&B)[NR], int vbeg, int vend, int c,
+                                                   int conf_old, unsigned long long khi,
+                                                   unsigned long long &best, long long *scores_row,
+                                                   long long cur, int lane)
+{
+    for (int v = vbeg; v < vend; v += 4) {
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        const int va = v - c, vb = v + c;
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            const int r = R[i], a = A[i], b = B[i];
+            c0 += (int)((r == v) | (a == va) | (b == vb));
+            c1 += (int)((r == v + 1) | (a == va + 1) | (b == vb + 1));
+            c2 += (int)((r == v + 2) | (a == va + 2) | (b == vb + 2));
+            c3 += (int)((r == v + 3) | (a == va + 3) | (b == vb + 3));
+        }
+        // per-lane counts <= 3*NR <= 192, wave totals <= n + 2 < 2^16: reduce two per register
+        const unsigned t01 = (unsigned)wave_sum_i32(c0 | (c1 << 16));
+        const unsigned t23 = (unsigned)wave_sum_i32(c2 | (c3 << 16));
+        const int cnt[4] = {(int)(t01 & 0xffffu), (int)(t01 >> 16), (int)(t23 & 0xffffu), (int)(t23 >> 16)};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (v + u < vend) {
+                const int delta = cnt[u] - conf_old;
+                best = u64min(best, nq_key(delta, khi, v + u));
+                if (scores_row != nullptr && lane == 0) scores_row[v + u] = cur + 2ll * delta;
+            }
+        }
+    }
+}
+
+template <int NR>
+__global__ __launch_bounds__(256, 2) void nq_scan_regs_kernel(NqArgs a)
+{
+    __shared__ unsigned long long s_best[4];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int restart = blockIdx.x % a.n_restarts;
+    const int wchunk = (blockIdx.x / a.n_restarts) * 4 + wib;
+    const int n_wchunks = (gridDim.x / a.n_restarts) * 4;
+    const int n = a.n;
+    const int *__restrict__ rows = a.rows + (long long)restart * n;
+    const int *__restrict__ cols = a.cols + (long long)restart * a.max_cols;
+    int ncols = a.n_cols[restart];
+    ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
+    const long long K = (long long)ncols * n;
+    const long long k0 = K * wchunk / n_wchunks;
+    const long long k1 = K * (wchunk + 1) / n_wchunks;
+    unsigned long long best = NQ_KEY_EMPTY;
+
+    if (k0 < k1) {
+        int R[NR], A[NR], B[NR];
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            const int j = lane + 64 * i;
+            const bool in = j < n;
+            const int r = in ? rows[j] : 0;
+            R[i] = in ? r : NQ_SENT;
+            A[i] = in ? r - j : NQ_SENT;
+            B[i] = in ? r + j : NQ_SENT;
+        }
+        const long long cur = a.cur_scores[restart];
+        int slot = (int)(k0 / n);
+        int v0 = (int)(k0 - (long long)slot * n);
+        long long k = k0;
+        while (k < k1) {
+            const long long left = k1 - k;
+            const int ve = (left < (long long)(n - v0)) ? (int)(v0 + left) : n;
+            const int c = cols[slot];
+            if ((unsigned)c < (unsigned)n) {
+                const int rc = rows[c];
+                const long long base = (long long)slot * (n - 1);
+                const NqRanges rg = nq_ranges(v0, ve, rc, base, a.window);
+                if (rg.d1 > rg.d0 || rg.u1 > rg.u0) {
+                    // the column's own queen satisfies the (OR-ed) test of its own square once
+                    const int conf_old = nq_count1<NR>(R, A, B, rc, rc - c, rc + c) - 1;
+                    long long *srow = a.scores_out
+                                          ? a.scores_out + ((long long)restart * a.max_cols + slot) * n
+                                          : nullptr;
+                    nq_scan_range_regs<NR>(R, A, B, rg.d0, rg.d1, c, conf_old, nq_key_hi(0, c, n), best,
+                                           srow, cur, lane);
+                    nq_scan_range_regs<NR>(R, A, B, rg.u0, rg.u1, c, conf_old, nq_key_hi(1, c, n), best,
+                                           srow, cur, lane);
+                }
+            }
+            k += ve - v0;
+            slot++;
+            v0 = 0;
+        }
+    }
+    if (lane == 0) s_best[wib] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = u64min(u64min(s_best[0], s_best[1]), u64min(s_best[2], s_best[3]));
+        if (b != NQ_KEY_EMPTY) atomicMin(&a.best_keys[restart], b);
+    }
+}
+
+// LDS-resident state for n > 4096 (any n <= LS_NQ_MAX_N): 4*ceil64(n) bytes.
+__device__ __forceinline__ int nq_count1_lds(const int *sR, int n_pad, int lane, int v, int va, int vb)
+{
+    int c = 0;
+    for (int j = lane; j < n_pad; j += 64) {
+        const int r = sR[j];
+        c += (int)((r == v) | (r - j == va) | (r + j == vb));
+    }
+    return wave_sum_i32(c);
+}
+
+__device__ __forceinline__ void nq_scan_range_lds(const int *sR, int n_pad, int vbeg, int vend, int c,
+                                                  int conf_old, unsigned long long khi,
+                                                  unsigned long long &best, long long *scores_row,
+                                                  long long cur, int lane)
+{
+    for (int v = vbeg; v < vend; v += 4) {
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        const int va = v - c, vb = v + c;
+        for (int j = lane; j < n_pad; j += 64) {
+            const int r = sR[j];
+            const int a = r - j, b = r + j;
+            c0 += (int)((r == v) | (a == va) | (b == vb));
+            c1 += (int)((r == v + 1) | (a == va + 1) | (b == vb + 1));
+            c2 += (int)((r == v + 2) | (a == va + 2) | (b == vb + 2));
+            c3 += (int)((r == v + 3) | (a == va + 3) | (b == vb + 3));
+        }
+        // per-lane counts <= 3*512; wave totals <= n + 2 <= 32770 < 2^16
+        const int cnt[4] = {wave_sum_i32(c0), wave_sum_i32(c1), wave_sum_i32(c2), wave_sum_i32(c3)};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (v + u < vend) {
+                const int delta = cnt[u] - conf_old;
+                best = u64min(best, nq_key(delta, khi, v + u));
+                if (scores_row != nullptr && lane == 0) scores_row[v + u] = cur + 2ll * delta;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nq_scan_lds_kernel(NqArgs a)
+{
+    extern __shared__ int s_dyn[]; // [n_pad] state, then 4 x u64 best (8-byte aligned: n_pad % 64 == 0)
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int restart = blockIdx.x % a.n_restarts;
+    const int wchunk = (blockIdx.x / a.n_restarts) * 4 + wib;
+    const int n_wchunks = (gridDim.x / a.n_restarts) * 4;
+    const int n = a.n;
+    const int n_pad = (n + 63) & ~63;
+    int *sR = s_dyn;
+    unsigned long long *s_best = reinterpret_cast<unsigned long long *>(s_dyn + n_pad);
+    const int *__restrict__ rows = a.rows + (long long)restart * n;
+    const int *__restrict__ cols = a.cols + (long long)restart * a.max_cols;
+    for (int j = threadIdx.x; j < n_pad; j += 256) sR[j] = j < n ? rows[j] : NQ_SENT;
+    __syncthreads();
+    int ncols = a.n_cols[restart];
+    ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
+    const long long K = (long long)ncols * n;
+    const long long k0 = K * wchunk / n_wchunks;
+    const long long k1 = K * (wchunk + 1) / n_wchunks;
+    unsigned long long best = NQ_KEY_EMPTY;
+    if (k0 < k1) {
+        const long long cur = a.cur_scores[restart];
+        int slot = (int)(k0 / n);
+        int v0 = (int)(k0 - (long long)slot * n);
+        long long k = k0;
+        while (k < k1) {
+            const long long left = k1 - k;
+            const int ve = (left < (long long)(n - v0)) ? (int)(v0 + left) : n;
+            const int c = cols[slot];
+            if ((unsigned)c < (unsigned)n) {
+                const int rc = sR[c];
+                const long long base = (long long)slot * (n - 1);
+                const NqRanges rg = nq_ranges(v0, ve, rc, base, a.window);
+                if (rg.d1 > rg.d0 || rg.u1 > rg.u0) {
+                    const int conf_old = nq_count1_lds(sR, n_pad, lane, rc, rc - c, rc + c) - 1;
+                    long long *srow = a.scores_out
+                                          ? a.scores_out + ((long long)restart * a.max_cols + slot) * n
+                                          : nullptr;
+                    nq_scan_range_lds(sR, n_pad, rg.d0, rg.d1, c, conf_old, nq_key_hi(0, c, n), best, srow,
+                                      cur, lane);
+                    nq_scan_range_lds(sR, n_pad, rg.u0, rg.u1, c, conf_old, nq_key_hi(1, c, n), best, srow,
+                                      cur, lane);
+                }
+            }
+            k += ve - v0;
+            slot++;
+            v0 = 0;
+        }
+    }
+    if (lane == 0) s_best[wib] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = u64min(u64min(s_best[0], s_best[1]), u64min(s_best[2], s_best[3]));
+        if (b != NQ_KEY_EMPTY) atomicMin(&a.best_keys[restart], b);
+    }
+}
+
+// ==================================================================== TABLE
+// tabs[restart] layout (int32): cntR[0..n) | cntA[0..2n) index r-j+n | cntB[0..2n) index r+j
+
+__global__ __launch_bounds__(256) void nq_tables_build_kernel(const int *rows_all, int n, int *tabs,
+                                                              int tab_stride)
+{
+    const int restart = blockIdx.y;
+    const int *rows = rows_all + (long long)restart * n;
+    int *t = tabs + (long long)restart * tab_stride;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const int r = rows[j];
+        if ((unsigned)r < (unsigned)n) {
+            atomicAdd(&t[r], 1);
+            atomicAdd(&t[n + (r - j + n)], 1);
+            atomicAdd(&t[3 * n + (r + j)], 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nq_table_eval_kernel(NqArgs a)
+{
+    __shared__ unsigned long long s_best[4];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int restart = blockIdx.x % a.n_restarts;
+    const int chunk = blockIdx.x / a.n_restarts;
+    const int n_chunks = gridDim.x / a.n_restarts;
+    const int n = a.n;
+    const int *__restrict__ rows = a.rows + (long long)restart * n;
+    const int *__restrict__ cols = a.cols + (long long)restart * a.max_cols;
+    const int *__restrict__ tR = a.tabs + (long long)restart * a.tab_stride;
+    const int *__restrict__ tA = tR + n;
+    const int *__restrict__ tB = tR + 3 * n;
+    int ncols = a.n_cols[restart];
+    ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
+    const long long K = (long long)ncols * n;
+    const long long k0 = K * chunk / n_chunks;
+    const long long k1 = K * (chunk + 1) / n_chunks;
+    unsigned long long best = NQ_KEY_EMPTY;
+    if (k0 < k1) {
+        const long long cur = a.cur_scores[restart];
+        int slot = (int)(k0 / n);
+        int v0 = (int)(k0 - (long long)slot * n);
+        long long k = k0;
+        while (k < k1) {
+            const long long left = k1 - k;
+            const int ve = (left < (long long)(n - v0)) ? (int)(v0 + left) : n;
+            const int c = cols[slot];
+            if ((unsigned)c < (unsigned)n) {
+                const int rc = rows[c];
+                const long long base = (long long)slot * (n - 1);
+                const NqRanges rg = nq_ranges(v0, ve, rc, base, a.window);
+                const int conf_old = tR[rc] + tA[rc - c + n] + tB[rc + c] - 3;
+                long long *srow =
+                    a.scores_out ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
+                const unsigned long long khd = nq_key_hi(0, c, n), khu = nq_key_hi(1, c, n);
+                for (int v = rg.d0 + (int)threadIdx.x; v < rg.d1; v += 256) {
+                    const int delta = tR[v] + tA[v - c + n] + tB[v + c] - conf_old;
+                    best = u64min(best, nq_key(delta, khd, v));
+                    if (srow) srow[v] = cur + 2ll * delta;
+                }
+                for (int v = rg.u0 + (int)threadIdx.x; v < rg.u1; v += 256) {
+                    const int delta = tR[v] + tA[v - c + n] + tB[v + c] - conf_old;
+                    best = u64min(best, nq_key(delta, khu, v));
+                    if (srow) srow[v] = cur + 2ll * delta;
+                }
+            }
+            k += ve - v0;
+            slot++;
+            v0 = 0;
+        }
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) s_best[wib] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = u64min(u64min(s_best[0], s_best[1]), u64min(s_best[2], s_best[3]));
+        if (b != NQ_KEY_EMPTY) atomicMin(&a.best_keys[restart], b);
+    }
+}
+
+// get_col_scores + sum by tables (examples/nqueens/src/lib.rs:74-87,130-139).
+__global__ __launch_bounds__(256) void nq_col_scores_kernel(const int *rows_all, int n, const int *tabs,
+                                                            int tab_stride, long long *col_scores,
+                                                            long long *totals)
+{
+    __shared__ long long s_sum[4];
+    const int restart = blockIdx.y;
+    const int *rows = rows_all + (long long)restart * n;
+    const int *tR = tabs + (long long)restart * tab_stride;
+    const int *tA = tR + n, *tB = tR + 3 * n;
+    long long local = 0;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const int r = rows[j];
+        long long s = 0;
+        if ((unsigned)r < (unsigned)n) s = (long long)tR[r] + tA[r - j + n] + tB[r + j] - 3;
+        if (col_scores) col_scores[(long long)restart * n + j] = s;
+        local += s;
+    }
+    // 64-bit wave sum via two 32-bit halves is overkill: per-thread partials are < 2^31
+    int lo = wave_sum_i32((int)local);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = lo;
+    __syncthreads();
+    if (threadIdx.x == 0 && totals) {
+        unsigned long long t = (unsigned long long)(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&totals[restart]), t);
+    }
+}
+
+// ================================================================= finalize
+__global__ void nq_finalize_kernel(NqArgs a, ls_nq_result *results)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_restarts) return;
+    const int n = a.n;
+    int ncols = a.n_cols[r];
+    ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
+    const long long total = (long long)ncols * (n - 1);
+    ls_nq_result out;
+    out.n_scored = a.window < total ? (a.window < 0 ? 0 : a.window) : total;
+    const unsigned long long key = a.best_keys[r];
+    if (key == NQ_KEY_EMPTY || out.n_scored == 0) {
+        out.n_scored = key == NQ_KEY_EMPTY ? 0 : out.n_scored;
+        out.best_index = -1;
+        out.best_score = 0;
+        out.best_col = -1;
+        out.best_value = -1;
+    } else {
+        const int v = (int)(key & 0x7fffu);
+        const int colkey = (int)((key >> 15) & 0x7fffu);
+        const int is_up = (int)((key >> 30) & 1u);
+        const int c = is_up ? n - 1 - colkey : colkey;
+        const int delta = (int)(key >> 31) - NQ_DELTA_BIAS;
+        const int *cols = a.cols + (long long)r * a.max_cols;
+        int slot = 0;
+        for (int s = 0; s < ncols; s++)
+            if (cols[s] == c) { slot = s; break; }
+        out.best_index = (long long)slot * n + v;
+        out.best_score = a.cur_scores[r] + 2ll * delta;
+        out.best_col = c;
+        out.best_value = v;
+    }
+    results[r] = out;
+}
+
+// ================================================================ launchers
+static int nq_blocks_per_cu(const void *fn, size_t dyn_lds)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, dyn_lds) != hipSuccess || nb < 1) nb = 1;
+    return nb > 8 ? 8 : nb;
+}
+
+template <int NR> static const void *scan_fn() { return reinterpret_cast<const void *>(&nq_scan_regs_kernel<NR>); }
+
+static int launch_scan(ls_ctx *ctx, const NqArgs &a, long long k_max)
+{
+    const int n = a.n;
+    // every wavefront should own >= 16 candidates; never more blocks than fit the chip at once
+    long long want_waves = (k_max + 15) / 16;
+    if (want_waves < 1) want_waves = 1;
+    long long bpr_cap = (want_waves + 3) / 4;
+    auto grid_for = [&](int blocks_per_cu) {
+        long long total = (long long)ctx->n_cus * blocks_per_cu;
+        long long bpr = total / a.n_restarts;
+        if (bpr < 1) bpr = 1;
+        if (bpr > bpr_cap) bpr = bpr_cap;
+        return (unsigned)(bpr * a.n_restarts);
+    };
+#define LS_SCAN_CASE(NRV)                                                                            \
+    {                                                                                                \
+        static int bpc = 0;                                                                          \
+        if (!bpc) bpc = nq_blocks_per_cu(scan_fn<NRV>(), 0);                                         \
+        hipLaunchKernelGGL(nq_scan_regs_kernel<NRV>, dim3(grid_for(bpc)), dim3(256), 0, ctx->stream, a); \
+    }
+    if (n <= 64) LS_SCAN_CASE(1)
+    else if (n <= 128) LS_SCAN_CASE(2)
+    else if (n <= 256) LS_SCAN_CASE(4)
+    else if (n <= 512) LS_SCAN_CASE(8)
+    else if (n <= 1024) LS_SCAN_CASE(16)
+    else if (n <= 2048) LS_SCAN_CASE(32)
+    else if (n <= 4096) LS_SCAN_CASE(64)
+    else {
+        const int n_pad = (n + 63) & ~63;
+        const size_t lds = (size_t)n_pad * 4 + 32;
+        LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_scan_lds_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        const int bpc = nq_blocks_per_cu(reinterpret_cast<const void *>(&nq_scan_lds_kernel), lds);
+        hipLaunchKernelGGL(nq_scan_lds_kernel, dim3(grid_for(bpc)), dim3(256), lds, ctx->stream, a);
+    }
+#undef LS_SCAN_CASE
+    LS_HIP(ctx, hipGetLastError());
+    return LS_OK;
+}
+
+static int build_tables(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, int **tabs_out, int *stride_out)
+{
+    const int stride = 5 * n + 8;
+    const size_t bytes = (size_t)n_restarts * stride * sizeof(int);
+    LS_RESERVE(ctx, ctx->nq_tabs, bytes);
+    LS_HIP(ctx, hipMemsetAsync(ctx->nq_tabs.p, 0, bytes, ctx->stream));
+    int gx = (n + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(nq_tables_build_kernel, dim3(gx, n_restarts), dim3(256), 0, ctx->stream, rows_d, n,
+                       ctx->nq_tabs.as<int>(), stride);
+    LS_HIP(ctx, hipGetLastError());
+    *tabs_out = ctx->nq_tabs.as<int>();
+    *stride_out = stride;
+    return LS_OK;
+}
+
+int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, const long long *cur_d,
+                      const int *cols_d, const int *n_cols_d, int max_cols, long long window,
+                      ls_nq_result *results_d, long long *scores_out_d)
+{
+    LS_RESERVE(ctx, ctx->nq_keys, (size_t)n_restarts * 8);
+    LS_HIP(ctx, hipMemsetAsync(ctx->nq_keys.p, 0xFF, (size_t)n_restarts * 8, ctx->stream));
+    NqArgs a;
+    a.rows = rows_d; a.cur_scores = cur_d; a.cols = cols_d; a.n_cols = n_cols_d;
+    a.n = n; a.n_restarts = n_restarts; a.max_cols = max_cols; a.window = window;
+    a.best_keys = ctx->nq_keys.as<unsigned long long>();
+    a.scores_out = scores_out_d;
+    a.tabs = nullptr; a.tab_stride = 0;
+    const long long k_max = (long long)max_cols * n;
+    if (scores_out_d) {
+        const long long cnt = (long long)n_restarts * k_max;
+        if (cnt > 0) {
+            long long g = (cnt + 255) / 256;
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, scores_out_d,
+                               (long long)INT64_MIN, cnt);
+            LS_HIP(ctx, hipGetLastError());
+        }
+    }
+    if (max_cols > 0) {
+        if (ctx->nq_algo == LS_NQ_ALGO_TABLE) {
+            int *tabs = nullptr; int stride = 0;
+            int rc = build_tables(ctx, n_restarts, n, rows_d, &tabs, &stride);
+            if (rc != LS_OK) return rc;
+            a.tabs = tabs; a.tab_stride = stride;
+            long long want_blocks = (k_max + 2047) / 2048; // >= 8 candidates per lane
+            long long total = (long long)ctx->n_cus * 8;
+            long long bpr = total / n_restarts;
+            if (bpr < 1) bpr = 1;
+            if (bpr > want_blocks) bpr = want_blocks;
+            if (bpr < 1) bpr = 1;
+            hipLaunchKernelGGL(nq_table_eval_kernel, dim3((unsigned)(bpr * n_restarts)), dim3(256), 0,
+                               ctx->stream, a);
+            LS_HIP(ctx, hipGetLastError());
+        } else {
+            int rc = launch_scan(ctx, a, k_max);
+            if (rc != LS_OK) return rc;
+        }
+    }
+    hipLaunchKernelGGL(nq_finalize_kernel, dim3((n_restarts + 63) / 64), dim3(64), 0, ctx->stream, a,
+                       results_d);
+    LS_HIP(ctx, hipGetLastError());
+    return LS_OK;
+}
+
+int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, long long *col_scores_d,
+                      long long *scores_d)
+{
+    int *tabs = nullptr; int stride = 0;
+    int rc = build_tables(ctx, n_restarts, n, rows_d, &tabs, &stride);
+    if (rc != LS_OK) return rc;
+    if (scores_d) LS_HIP(ctx, hipMemsetAsync(scores_d, 0, (size_t)n_restarts * 8, ctx->stream));
+    int gx = (n + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(nq_col_scores_kernel, dim3(gx, n_restarts), dim3(256), 0, ctx->stream, rows_d, n, tabs,
+                       stride, col_scores_d, scores_d);
+    LS_HIP(ctx, hipGetLastError());
+    return LS_OK;
+}
+
+} // namespace lsamd

@@ -1,0 +1,183 @@
+"""ls_amd — Python view of the MI355X local-search neighbourhood evaluator.
+
+Thin wrappers over the C ABI (include/ls_amd.h); all compute happens in the HIP
+kernels of constraint-solver_amd/csrc.  numpy arrays in / numpy arrays out for
+the host-pointer entry points, raw device addresses (e.g. torch
+`tensor.data_ptr()`) for the *_dev ones.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (INT64_MIN, LS_NQ_ALGO_SCAN, LS_NQ_ALGO_TABLE, LS_NQ_MAX_N, LS_SCHED_MAX_DAYS,  # noqa: F401
+                   LsError, NqResult, SchedMove, SchedResult)
+
+ALGOS = {"scan": LS_NQ_ALGO_SCAN, "table": LS_NQ_ALGO_TABLE}
+
+
+def device_count() -> int:
+    return int(_lib.load().ls_device_count())
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(np.asarray(a), dtype=dtype)
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU's context (ls_ctx).  Not thread-safe; one per device."""
+
+    def __init__(self, device: int = 0, algo: str = "scan"):
+        self._l = _lib.load()
+        h = C.c_void_p()
+        rc = self._l.ls_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise LsError(rc, self._l.ls_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+        self.set_algo(algo)
+
+    # -- plumbing
+    def _check(self, rc: int):
+        if rc != 0:
+            raise LsError(rc, self._l.ls_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.ls_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, hip_stream: int | None):
+        self._check(self._l.ls_ctx_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def synchronize(self):
+        self._check(self._l.ls_ctx_synchronize(self._h))
+
+    def set_algo(self, algo: str | int):
+        a = ALGOS[algo] if isinstance(algo, str) else int(algo)
+        self._check(self._l.ls_ctx_set_nq_algo(self._h, a))
+
+    def device_info(self) -> dict:
+        cus, ws, khz = C.c_int(), C.c_int(), C.c_int()
+        name = C.create_string_buffer(256)
+        self._check(self._l.ls_ctx_device_info(self._h, C.byref(cus), C.byref(ws), C.byref(khz), name, 256))
+        return dict(n_cus=cus.value, wave_size=ws.value, clock_khz=khz.value, name=name.value.decode())
+
+    # -- N-queens
+    def nqueens_eval_batch(self, rows, cur_scores, cols, n_cols, window, want_scores=False):
+        """rows [R, n] int32; cur_scores [R]; cols [R, max_cols]; n_cols [R].
+        Returns (list of dict per restart, scores [R, max_cols*n] or None)."""
+        rows = _c(rows, np.int32)
+        assert rows.ndim == 2
+        R, n = rows.shape
+        cur = _c(cur_scores, np.int64).reshape(R)
+        cols = _c(cols, np.int32).reshape(R, -1)
+        max_cols = cols.shape[1]
+        ncols = _c(n_cols, np.int32).reshape(R)
+        res = (NqResult * R)()
+        scores = np.empty((R, max_cols * n), dtype=np.int64) if want_scores else None
+        self._check(self._l.ls_nqueens_eval_batch(self._h, R, n, _vp(rows), _vp(cur), _vp(cols), _vp(ncols),
+                                                  max_cols, int(window), C.cast(res, C.c_void_p), _vp(scores)))
+        out = [dict(n_scored=r.n_scored, best_index=r.best_index, best_score=r.best_score,
+                    best_col=r.best_col, best_value=r.best_value) for r in res]
+        return out, scores
+
+    def nqueens_eval(self, rows, cur_score, cols, window, want_scores=False):
+        rows = _c(rows, np.int32).reshape(1, -1)
+        cols = _c(cols, np.int32).reshape(1, -1)
+        out, scores = self.nqueens_eval_batch(rows, [cur_score], cols, [cols.shape[1]], window, want_scores)
+        return out[0], (scores[0] if scores is not None else None)
+
+    def nqueens_eval_batch_dev(self, n_restarts, n, rows_d, cur_scores_d, cols_d, n_cols_d, max_cols, window,
+                               results_d, scores_out_d=None):
+        """All arguments are device addresses (ints); asynchronous."""
+        self._check(self._l.ls_nqueens_eval_batch_dev(
+            self._h, int(n_restarts), int(n), C.c_void_p(rows_d), C.c_void_p(cur_scores_d), C.c_void_p(cols_d),
+            C.c_void_p(n_cols_d), int(max_cols), int(window), C.c_void_p(results_d),
+            C.c_void_p(scores_out_d or 0)))
+
+    def nqueens_col_scores(self, rows):
+        """rows [R, n] -> (col_scores [R, n] int64, scores [R] int64)."""
+        rows = _c(rows, np.int32)
+        if rows.ndim == 1:
+            rows = rows.reshape(1, -1)
+        R, n = rows.shape
+        cs = np.empty((R, n), dtype=np.int64)
+        tot = np.empty(R, dtype=np.int64)
+        self._check(self._l.ls_nqueens_col_scores(self._h, R, n, _vp(rows), _vp(cs), _vp(tot)))
+        return cs, tot
+
+    def nqueens_col_scores_dev(self, n_restarts, n, rows_d, col_scores_d, scores_d):
+        self._check(self._l.ls_nqueens_col_scores_dev(self._h, int(n_restarts), int(n), C.c_void_p(rows_d),
+                                                      C.c_void_p(col_scores_d or 0), C.c_void_p(scores_d or 0)))
+
+    # -- scheduling
+    def sched_instance_upload(self, n_days_scored, n_days_stored, start_weekday, n_employees, holiday_bits=None):
+        hb = np.zeros(n_employees, dtype=np.uint64) if holiday_bits is None else _c(holiday_bits, np.uint64)
+        assert hb.shape == (n_employees,)
+        self._check(self._l.ls_sched_instance_upload(self._h, int(n_days_scored), int(n_days_stored),
+                                                     int(start_weekday), int(n_employees), _vp(hb)))
+        self._sched_dims = (int(n_days_scored), int(n_days_stored), int(n_employees))
+
+    def sched_score(self, states, want_terms=False):
+        states = _c(states, np.int32)
+        if states.ndim == 1:
+            states = states.reshape(1, -1)
+        ns = states.shape[0]
+        hard = np.empty(ns, dtype=np.int64)
+        soft = np.empty(ns, dtype=np.int64)
+        terms = np.empty((ns, 8), dtype=np.int64) if want_terms else None
+        self._check(self._l.ls_sched_score(self._h, ns, _vp(states), _vp(hard), _vp(soft), _vp(terms)))
+        return (hard, soft, terms) if want_terms else (hard, soft)
+
+    @staticmethod
+    def pack_moves(moves) -> np.ndarray:
+        """[..., 3] (type, a, b) -> contiguous int32 array laid out as ls_sched_move."""
+        return _c(moves, np.int32).reshape(-1, 3)
+
+    def sched_eval_batch(self, states, moves, n_moves, window, want_scores=False):
+        """states [R, S]; moves [R, max_moves, 3]; n_moves [R]."""
+        states = _c(states, np.int32)
+        R = states.shape[0]
+        mv = _c(moves, np.int32).reshape(R, -1, 3)
+        max_moves = mv.shape[1]
+        nm = _c(n_moves, np.int64).reshape(R)
+        res = (SchedResult * R)()
+        hard = np.empty((R, max_moves), dtype=np.int64) if want_scores else None
+        soft = np.empty((R, max_moves), dtype=np.int64) if want_scores else None
+        self._check(self._l.ls_sched_eval_batch(self._h, R, _vp(states), _vp(mv), _vp(nm), max_moves, int(window),
+                                                C.cast(res, C.c_void_p), _vp(hard), _vp(soft)))
+        out = [dict(n_scored=r.n_scored, best_index=r.best_index, best_hard=r.best_hard, best_soft=r.best_soft)
+               for r in res]
+        return out, hard, soft
+
+    def sched_eval(self, state, moves, window, want_scores=False):
+        mv = _c(moves, np.int32).reshape(1, -1, 3)
+        out, hard, soft = self.sched_eval_batch(_c(state, np.int32).reshape(1, -1), mv, [mv.shape[1]], window,
+                                                want_scores)
+        return out[0], (hard[0] if hard is not None else None), (soft[0] if soft is not None else None)
+
+    def sched_eval_batch_dev(self, n_restarts, states_d, moves_d, n_moves_d, max_moves, window, results_d,
+                             hard_out_d=None, soft_out_d=None):
+        self._check(self._l.ls_sched_eval_batch_dev(
+            self._h, int(n_restarts), C.c_void_p(states_d), C.c_void_p(moves_d), C.c_void_p(n_moves_d),
+            int(max_moves), int(window), C.c_void_p(results_d), C.c_void_p(hard_out_d or 0),
+            C.c_void_p(soft_out_d or 0)))

@@ -1,0 +1,93 @@
+"""ctypes binding of include/ls_amd.h (libls_amd.so, built in-tree by
+constraint-solver_amd/build.py with hipcc for gfx950).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is
+usable, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+SO_PATH = os.path.join(_PKG, "lib", "libls_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "ls_amd.h")
+
+LS_OK = 0
+LS_ERR_INVALID, LS_ERR_NO_DEVICE, LS_ERR_HIP, LS_ERR_UNSUPPORTED, LS_ERR_NOMEM, LS_ERR_STATE = 1, 2, 3, 4, 5, 6
+LS_NQ_ALGO_SCAN, LS_NQ_ALGO_TABLE = 0, 1
+LS_NQ_MAX_N = 32768
+LS_SCHED_MAX_DAYS = 64
+INT64_MIN = -(2 ** 63)
+
+_ERR_NAMES = {1: "LS_ERR_INVALID", 2: "LS_ERR_NO_DEVICE", 3: "LS_ERR_HIP", 4: "LS_ERR_UNSUPPORTED",
+              5: "LS_ERR_NOMEM", 6: "LS_ERR_STATE"}
+
+
+class LsError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{_ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class NqResult(C.Structure):
+    _fields_ = [("n_scored", C.c_int64), ("best_index", C.c_int64), ("best_score", C.c_int64),
+                ("best_col", C.c_int32), ("best_value", C.c_int32)]
+
+
+class SchedMove(C.Structure):
+    _fields_ = [("type", C.c_int32), ("a", C.c_int32), ("b", C.c_int32)]
+
+
+class SchedResult(C.Structure):
+    _fields_ = [("n_scored", C.c_int64), ("best_index", C.c_int64), ("best_hard", C.c_int64),
+                ("best_soft", C.c_int64)]
+
+
+_vp = C.c_void_p
+_i32, _i64 = C.c_int32, C.c_int64
+
+# name -> (restype, argtypes); one entry per function declared in include/ls_amd.h
+SIGNATURES = {
+    "ls_abi_version": (C.c_int, []),
+    "ls_device_count": (C.c_int, []),
+    "ls_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "ls_ctx_destroy": (C.c_int, [_vp]),
+    "ls_last_error": (C.c_char_p, [_vp]),
+    "ls_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "ls_ctx_synchronize": (C.c_int, [_vp]),
+    "ls_ctx_set_nq_algo": (C.c_int, [_vp, C.c_int]),
+    "ls_ctx_get_nq_algo": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "ls_ctx_device_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     C.c_char_p, C.c_int]),
+    "ls_nqueens_eval": (C.c_int, [_vp, _i32, _vp, _i64, _vp, _i32, _i64, _vp, _vp]),
+    "ls_nqueens_eval_batch": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
+    "ls_nqueens_eval_batch_dev": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
+    "ls_nqueens_col_scores": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "ls_nqueens_col_scores_dev": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "ls_sched_instance_upload": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp]),
+    "ls_sched_score": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
+    "ls_sched_eval": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "ls_sched_eval_batch": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "ls_sched_eval_batch_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libls_amd.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                f"{SO_PATH} is missing: build it with `python constraint-solver_amd/build.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

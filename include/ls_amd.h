@@ -1,0 +1,223 @@
+/*
+ * ls_amd.h — C ABI of the MI355X (gfx950) local-search neighbourhood evaluator.
+ *
+ * Drop-in boundary for ONE hot path of asimihsan/constraint-solver: the
+ * neighbourhood pipeline of LocalSearch::execute
+ * (local-search/src/local_search.rs:315-325)
+ *
+ *     move_proposer.iter_local_moves(&current, rng)      :316-317
+ *         .filter(|s| !history.is_solution_tabu(s))      :319   (tabu == {current}, :155-199)
+ *         .map(|s| calculator.get_scored_solution(s))    :320
+ *         .take(window_size).collect();  sort(); first() :321-325
+ *
+ * for the two plug-ins the reference ships: N-queens
+ * (examples/nqueens/src/lib.rs) and employee scheduling
+ * (examples/employee-scheduling/src/lib.rs).  The reference has no FFI on this
+ * path (it is monomorphised Rust); the only FFI precedent in the repository is
+ * the wasm-bindgen opaque-context pattern
+ * (web/employee-scheduling-wasm-bindgen/src/lib.rs:13-84), which this ABI
+ * mirrors: create / call / query / destroy on an opaque handle.
+ *
+ * One call evaluates one WHOLE neighbourhood (or a batch of them, one per
+ * independent restart) on the GPU and returns what `first()` would return:
+ * the minimum by (score, solution-vector) plus the number of candidates
+ * scored.  Move selection, acceptance, RNG and history stay with the caller.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; every function returns an int status
+ *    (LS_OK == 0); nothing throws or aborts across the boundary (the reference
+ *    panics via unwrap(); see ls_last_error()).
+ *  - the caller owns every host buffer for the duration of the call; no
+ *    pointer is retained after return.  Device buffers passed to the *_dev
+ *    entry points stay owned by the caller as well.
+ *  - a context is used by one host thread at a time; one context per GPU;
+ *    different contexts may be driven concurrently from different threads
+ *    (reference: Solution/Score are Send, nothing is Sync,
+ *    local-search/src/local_search.rs:16-23).
+ *  - There is NO CPU fallback: without a usable HIP device ls_ctx_create
+ *    fails with LS_ERR_NO_DEVICE.
+ */
+#ifndef LS_AMD_H
+#define LS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LS_ABI_VERSION 1
+
+/* status codes */
+#define LS_OK               0
+#define LS_ERR_INVALID      1   /* bad argument (null pointer, size, out-of-range value) */
+#define LS_ERR_NO_DEVICE    2   /* no HIP device / device id out of range */
+#define LS_ERR_HIP          3   /* a HIP runtime call failed; text via ls_last_error() */
+#define LS_ERR_UNSUPPORTED  4   /* size outside what the kernels support */
+#define LS_ERR_NOMEM        5
+#define LS_ERR_STATE        6   /* call order (e.g. schedule eval before instance upload) */
+
+/* N-queens kernel families (ls_ctx_set_nq_algo) */
+#define LS_NQ_ALGO_SCAN   0  /* one wavefront per candidate scans the packed state (default) */
+#define LS_NQ_ALGO_TABLE  1  /* occupancy count tables, O(1) per candidate */
+
+/* limits */
+#define LS_NQ_MAX_N        32768
+#define LS_SCHED_MAX_DAYS  64
+
+typedef struct ls_ctx ls_ctx;
+
+/* ------------------------------------------------------------------ context */
+
+int ls_abi_version(void);
+
+/* Number of HIP devices visible (0 when none / no driver). */
+int ls_device_count(void);
+
+/* Opaque context bound to one GPU; owns a HIP stream and persistent device
+ * workspaces.  Mirrors create_solver(..) -> SolverContext
+ * (web/employee-scheduling-wasm-bindgen/src/lib.rs:18-53). */
+int ls_ctx_create(int device_id, ls_ctx **out);
+
+/* Mirrors the JS-side solver.free() (web/employee-scheduling/src/worker.ts:9-17). */
+int ls_ctx_destroy(ls_ctx *ctx);
+
+/* Text of the last error on this context ("" if none); owned by the context.
+ * ls_last_error(NULL) returns the last error of a failed ls_ctx_create. */
+const char *ls_last_error(const ls_ctx *ctx);
+
+/* Launch on a caller-owned hipStream_t (e.g. PyTorch's current stream) instead
+ * of the context's own stream; NULL restores the own stream. */
+int ls_ctx_set_stream(ls_ctx *ctx, void *hip_stream);
+
+/* Block until everything queued on the context's stream has finished. */
+int ls_ctx_synchronize(ls_ctx *ctx);
+
+int ls_ctx_set_nq_algo(ls_ctx *ctx, int algo);
+int ls_ctx_get_nq_algo(const ls_ctx *ctx, int *algo);
+
+/* Device properties the harness reports (CU count, wavefront size, clock kHz, name). */
+int ls_ctx_device_info(const ls_ctx *ctx, int *n_cus, int *wave_size, int *clock_khz,
+                       char *name, int name_cap);
+
+/* ----------------------------------------------------------------- N-queens
+ *
+ * State: rows[col] = row, packed int32 (reference: Vec<i64>,
+ * examples/nqueens/src/lib.rs:13-21), 0 <= rows[col] < n, 1 <= n <= LS_NQ_MAX_N.
+ *
+ * Candidate order (MoveIterator, examples/nqueens/src/lib.rs:214-234): for
+ * cols[0..n_cols) in the proposer's order, values 0..n-1; candidate
+ * k = (col = cols[k / n], value = k % n) is the current board with
+ * rows[col] = value.  Candidates equal to the current board are tabu and
+ * neither scored nor counted (local_search.rs:319); only the first `window`
+ * remaining candidates are scored (:321).  Score = sum of per-column conflict
+ * counts (lib.rs:126-140).  Winner = minimum by (score, board vector), the
+ * derived Ord of ScoredSolution (local_search.rs:29-37).
+ */
+typedef struct ls_nq_result {
+    int64_t n_scored;    /* candidates scored (after tabu filter and window)            */
+    int64_t best_index;  /* winner's position k in the UNFILTERED order; -1 if none    */
+    int64_t best_score;  /* its score (NQueensScore)                                    */
+    int32_t best_col;    /* cols[best_index / n]                                        */
+    int32_t best_value;  /* best_index % n                                              */
+} ls_nq_result;
+
+/* Replaces local_search.rs:315-325 for ONE neighbourhood.  cur_score must be
+ * the score of `rows` (the caller always has it: local_search.rs:306/:335).
+ * scores_out (nullable, n_cols*n entries, parity/debug mode): per-candidate
+ * scores indexed by k; INT64_MIN where the candidate was tabu or beyond the
+ * window. */
+int ls_nqueens_eval(ls_ctx *ctx, int32_t n, const int32_t *rows, int64_t cur_score,
+                    const int32_t *cols, int32_t n_cols, int64_t window,
+                    ls_nq_result *out, int64_t *scores_out);
+
+/* Batched over independent restarts (one neighbourhood each, one launch):
+ * rows[n_restarts][n], cur_scores[n_restarts], cols[n_restarts][max_cols]
+ * (only the first n_cols[r] of each row are read), results[n_restarts],
+ * scores_out (nullable) [n_restarts][max_cols*n]. */
+int ls_nqueens_eval_batch(ls_ctx *ctx, int32_t n_restarts, int32_t n,
+                          const int32_t *rows, const int64_t *cur_scores,
+                          const int32_t *cols, const int32_t *n_cols, int32_t max_cols,
+                          int64_t window, ls_nq_result *results, int64_t *scores_out);
+
+/* Same, every pointer in DEVICE memory; asynchronous on the context's stream
+ * (no host synchronisation, graph-capturable).  cols are NOT validated: a
+ * column outside [0, n) contributes no candidates. */
+int ls_nqueens_eval_batch_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n,
+                              const int32_t *rows_d, const int64_t *cur_scores_d,
+                              const int32_t *cols_d, const int32_t *n_cols_d, int32_t max_cols,
+                              int64_t window, ls_nq_result *results_d, int64_t *scores_out_d);
+
+/* get_col_scores + its sum (examples/nqueens/src/lib.rs:74-87,130-139) for a
+ * batch of boards, by occupancy count tables: col_scores[n_restarts][n]
+ * (nullable), scores[n_restarts] (nullable).  This is the vector the move
+ * proposer needs per LS iteration (lib.rs:182-187). */
+int ls_nqueens_col_scores(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows,
+                          int64_t *col_scores, int64_t *scores);
+int ls_nqueens_col_scores_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows_d,
+                              int64_t *col_scores_d, int64_t *scores_d);
+
+/* ------------------------------------------------------ employee scheduling
+ *
+ * State: date_to_employee as int32 employee INDICES into the instance's
+ * ascending `employees` vector (reference: Vec<Employee{id:i64}>,
+ * examples/employee-scheduling/src/lib.rs:119-146; ascending ids <-> ascending
+ * indices, so the derived vector order is preserved).  n_days_stored entries
+ * (the reference stores one more than it scores, lib.rs:407-411);
+ * the first n_days_scored are scored (lib.rs:181-192).
+ */
+typedef struct ls_sched_move {
+    int32_t type; /* 0 = ChangeDay: day a <- employee index b   (lib.rs:466-470)
+                     1 = SwapDays : days a and b swap employees (lib.rs:471-478) */
+    int32_t a;
+    int32_t b;
+} ls_sched_move;
+
+typedef struct ls_sched_result {
+    int64_t n_scored;
+    int64_t best_index;  /* position in the move list; -1 if none */
+    int64_t best_hard;   /* ScheduleScore.hard_score (integer-valued f64 in the reference) */
+    int64_t best_soft;   /* ScheduleScore.soft_score */
+} ls_sched_result;
+
+/* Instance = what ScheduleSolutionScoreCalculator::new + the solution's date
+ * range hold (lib.rs:251-259,129-146): holiday_bits[e] bit d set <=> employee
+ * index e has a holiday on day index d (d < n_days_scored).
+ * start_weekday: Monday = 0 .. Sunday = 6 (chrono::Weekday). */
+int ls_sched_instance_upload(ls_ctx *ctx, int32_t n_days_scored, int32_t n_days_stored,
+                             int32_t start_weekday, int32_t n_employees,
+                             const uint64_t *holiday_bits);
+
+/* get_scored_solution (lib.rs:261-375) for n_states stored vectors:
+ * states[n_states][n_days_stored] -> hard[n_states], soft[n_states];
+ * terms (nullable) [n_states][8] = H1..H4, S1..S4. */
+int ls_sched_score(ls_ctx *ctx, int32_t n_states, const int32_t *states,
+                   int64_t *hard, int64_t *soft, int64_t *terms);
+
+/* Replaces local_search.rs:315-325 for one neighbourhood given the proposer's
+ * move stream (ScheduleRandomMoveProposer lib.rs:444-490 or ScheduleMoveProposer
+ * :515-558, both expressible as ls_sched_move lists).  Candidates equal to the
+ * current state are tabu; the first `window` others are scored; winner =
+ * minimum by (hard, soft, date_to_employee vector).  hard_out/soft_out
+ * (nullable, n_moves entries): per-candidate scores, INT64_MIN where skipped. */
+int ls_sched_eval(ls_ctx *ctx, const int32_t *state, const ls_sched_move *moves,
+                  int64_t n_moves, int64_t window, ls_sched_result *out,
+                  int64_t *hard_out, int64_t *soft_out);
+
+/* Batched over restarts: states[n_restarts][n_days_stored],
+ * moves[n_restarts][max_moves] (first n_moves[r] used), results[n_restarts]. */
+int ls_sched_eval_batch(ls_ctx *ctx, int32_t n_restarts, const int32_t *states,
+                        const ls_sched_move *moves, const int64_t *n_moves, int64_t max_moves,
+                        int64_t window, ls_sched_result *results,
+                        int64_t *hard_out, int64_t *soft_out);
+
+/* Device-pointer flavour, asynchronous on the context's stream. */
+int ls_sched_eval_batch_dev(ls_ctx *ctx, int32_t n_restarts, const int32_t *states_d,
+                            const ls_sched_move *moves_d, const int64_t *n_moves_d,
+                            int64_t max_moves, int64_t window, ls_sched_result *results_d,
+                            int64_t *hard_out_d, int64_t *soft_out_d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LS_AMD_H */

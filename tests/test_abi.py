@@ -1,0 +1,60 @@
+"""CPU-only: the C-ABI library builds, loads and exports every symbol that
+include/ls_amd.h declares; no compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import ls_amd
+from ls_amd import _lib
+
+
+def _declared_functions():
+    with open(_lib.HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ls_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_is_built():
+    assert os.path.exists(_lib.SO_PATH), "run `python constraint-solver_amd/build.py`"
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _lib.load()
+    names = _declared_functions()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in ls_amd.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_abi_version():
+    assert _lib.load().ls_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.NqResult) == 32
+    assert C.sizeof(_lib.SchedMove) == 12
+    assert C.sizeof(_lib.SchedResult) == 32
+
+
+def test_no_cpu_fallback_without_device():
+    if ls_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(ls_amd.LsError) as ei:
+        ls_amd.Context(0)
+    assert ei.value.code == _lib.LS_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_product_never_references_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(_lib.__file__)))
+    for dirpath, _, files in os.walk(root):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                with open(os.path.join(dirpath, fn)) as f:
+                    src = f.read()
+                assert "import oracle" not in src and "liboracle" not in src and "orc_" not in src, fn

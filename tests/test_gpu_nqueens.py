@@ -1,0 +1,240 @@
+"""GPU parity tests (through the C ABI) for the N-queens neighbourhood
+pipeline: HIP path vs the CPU oracle on the same seeded inputs — bit-exact on
+every per-candidate score, on n_scored and on the selected candidate."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = ["scan", "table"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import ls_amd
+    c = ls_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _board(rng, n, kind):
+    return rng.permutation(n) if kind == "perm" else rng.integers(0, n, size=n)
+
+
+def _check(ctx, algo, rows, cols, window, formulation):
+    ctx.set_algo(algo)
+    exp = orc.nq_neighbourhood(rows, cols, window, formulation)
+    cur = orc.nq_score(rows)
+    got, scores = ctx.nqueens_eval(rows, cur, cols, window, want_scores=True)
+    assert got["n_scored"] == exp["n_scored"]
+    assert got["best_index"] == exp["best_index"]
+    if exp["best_index"] >= 0:
+        assert got["best_score"] == exp["best_score"]
+        n = len(rows)
+        assert got["best_col"] == cols[exp["best_index"] // n]
+        assert got["best_value"] == exp["best_index"] % n
+    assert np.array_equal(scores, exp["scores"])
+    return got
+
+
+def test_reference_kats_col_scores(ctx, golden_dir):
+    with open(os.path.join(golden_dir, "nqueens_kats.json")) as f:
+        g = json.load(f)
+    for group in ("reference", "derived"):
+        for kat in g[group]:
+            cs, tot = ctx.nqueens_col_scores(kat["rows"])
+            assert cs[0].tolist() == kat["col_scores"]
+            assert tot[0] == kat["score"]
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 8, 33, 63, 64, 65, 100])
+def test_small_vs_literal(ctx, algo, n):
+    rng = np.random.default_rng(n)
+    for kind in ("perm", "uniform"):
+        rows = _board(rng, n, kind)
+        for n_cols in sorted({1, min(n, 3), n}):
+            cols = rng.permutation(n)[:n_cols]
+            for window in (1, n - 1, 5 * n, 10 ** 12):
+                if window < 1:
+                    continue
+                _check(ctx, algo, rows, cols, window, "literal")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("n", [127, 128, 129, 255, 256, 257, 500, 512, 513, 1000, 1024, 1025, 2047, 2048, 2049])
+def test_register_tiers_vs_delta(ctx, algo, n):
+    # every register tier of the scan kernel (n <= 64*NR) incl. its edges
+    rng = np.random.default_rng(n)
+    rows = _board(rng, n, "uniform" if n % 2 else "perm")
+    cols = rng.permutation(n)[:7]
+    _check(ctx, algo, rows, cols, 5 * n, "delta")
+    _check(ctx, algo, rows, cols[:2], 10 ** 9, "table")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_nq8_example_shape(ctx, algo):
+    # config 1 shape: n = 8, window = 40, one column (amount = clamp(8/20, 1, L) = 1)
+    rng = np.random.default_rng(42)
+    for _ in range(20):
+        rows = _board(rng, 8, "perm")
+        _check(ctx, algo, rows, [int(rng.integers(0, 8))], 40, "literal")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_nq1024_reference_shaped_launch(ctx, algo):
+    # config 2 shape: n = 1024, window = 5n = 5120, up to 51 proposed columns
+    rng = np.random.default_rng(1024)
+    rows = _board(rng, 1024, "perm")
+    cols = rng.permutation(1024)[:51]
+    got = _check(ctx, algo, rows, cols, 5120, "delta")
+    assert got["n_scored"] == 5120
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_nq4096_reference_shaped_launch(ctx, algo):
+    # config 4 per-iteration shape: n = 4096, window = 20480, up to 204 columns
+    rng = np.random.default_rng(4096)
+    rows = _board(rng, 4096, "uniform")
+    cols = rng.permutation(4096)[:204]
+    got = _check(ctx, algo, rows, cols, 20480, "table")
+    assert got["n_scored"] == 20480
+    # independent check of the winner with the literal O(n^2) scorer
+    b = rows.copy()
+    b[got["best_col"]] = got["best_value"]
+    assert orc.nq_score(b) == got["best_score"]
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_nq4096_full_neighbourhood(ctx, algo):
+    # BASELINE.json full size, kernel-throughput shape: all n columns, window = n(n-1)
+    n = 4096
+    rng = np.random.default_rng(7)
+    rows = _board(rng, n, "uniform")
+    cols = np.arange(n)
+    ctx.set_algo(algo)
+    exp = orc.nq_neighbourhood(rows, cols, n * (n - 1), "table")
+    got, scores = ctx.nqueens_eval(rows, orc.nq_score(rows), cols, n * (n - 1), want_scores=True)
+    assert got["n_scored"] == n * (n - 1) == exp["n_scored"]
+    assert got["best_index"] == exp["best_index"] and got["best_score"] == exp["best_score"]
+    assert np.array_equal(scores, exp["scores"])
+    # size-independent properties
+    valid = scores != orc.SKIPPED
+    assert valid.sum() == n * (n - 1)
+    assert scores[valid].min() == got["best_score"]
+    assert (scores[valid] % 2 == 0).all()          # every attacking pair counts twice
+    b = rows.copy()
+    b[got["best_col"]] = got["best_value"]
+    assert orc.nq_score(b) == got["best_score"]
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("n", [4097, 5000, 8192, 20000, 32768])
+def test_large_n_lds_path(ctx, algo, n):
+    rng = np.random.default_rng(n)
+    rows = _board(rng, n, "uniform")
+    cols = rng.permutation(n)[:3]
+    _check(ctx, algo, rows, cols, 2 * n + 17, "table")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_batched_restarts_ragged(ctx, algo):
+    ctx.set_algo(algo)
+    rng = np.random.default_rng(99)
+    n, R, max_cols = 200, 11, 9
+    rows = np.stack([_board(rng, n, "uniform" if r % 2 else "perm") for r in range(R)])
+    n_cols = rng.integers(0, max_cols + 1, size=R)
+    n_cols[0], n_cols[1] = 0, max_cols                      # an empty and a full one
+    cols = np.stack([rng.permutation(n)[:max_cols] for _ in range(R)])
+    cur = [orc.nq_score(rows[r]) for r in range(R)]
+    window = 3 * (n - 1) + 50                               # truncates inside the 4th column
+    out, scores = ctx.nqueens_eval_batch(rows, cur, cols, n_cols, window, want_scores=True)
+    for r in range(R):
+        exp = orc.nq_neighbourhood(rows[r], cols[r, :n_cols[r]], window, "delta")
+        assert out[r]["n_scored"] == exp["n_scored"]
+        assert out[r]["best_index"] == exp["best_index"]
+        if exp["best_index"] >= 0:
+            assert out[r]["best_score"] == exp["best_score"]
+        k = n_cols[r] * n
+        assert np.array_equal(scores[r, :k], exp["scores"])
+        assert (scores[r, k:] == orc.SKIPPED).all()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_ties_and_duplicates(ctx, algo):
+    # all queens on one row: massive score ties -> the lexicographic tie-break decides
+    n = 96
+    rows = np.full(n, 5)
+    _check(ctx, algo, rows, [90, 3, 47], 10 ** 9, "literal")
+    # duplicated proposal column: identical candidates, first position wins
+    _check(ctx, algo, np.arange(n)[::-1].copy(), [10, 10, 4], 10 ** 9, "literal")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_empty_neighbourhoods(ctx, algo):
+    ctx.set_algo(algo)
+    got, _ = ctx.nqueens_eval([0, 2, 1], 2, [], 10)
+    assert got["n_scored"] == 0 and got["best_index"] == -1
+    got, _ = ctx.nqueens_eval([0], 0, [0], 10)              # the only candidate is the no-op
+    assert got["n_scored"] == 0 and got["best_index"] == -1
+    got, _ = ctx.nqueens_eval([0, 2, 1], 2, [1], 0)         # window 0
+    assert got["n_scored"] == 0 and got["best_index"] == -1
+
+
+def test_col_scores_match_reference_loop(ctx):
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 64, 1000, 4096):
+        rows = np.stack([_board(rng, n, "perm"), _board(rng, n, "uniform")])
+        cs, tot = ctx.nqueens_col_scores(rows)
+        for r in range(2):
+            exp = orc.nq_col_scores(rows[r])                 # literal lib.rs:74-87
+            assert np.array_equal(cs[r], exp)
+            assert tot[r] == exp.sum()
+
+
+def test_argument_errors(ctx):
+    import ls_amd
+    with pytest.raises(ls_amd.LsError) as ei:
+        ctx.nqueens_eval([0, 5], 0, [0], 10)                 # row value outside [0, n)
+    assert ei.value.code == ls_amd._lib.LS_ERR_INVALID
+    with pytest.raises(ls_amd.LsError):
+        ctx.nqueens_eval([0, 1], 0, [2], 10)                 # column outside [0, n)
+    with pytest.raises(ls_amd.LsError):
+        ctx.nqueens_eval([0, 1], 0, [0], -1)                 # negative window
+    with pytest.raises(ls_amd.LsError) as ei:
+        ctx.nqueens_eval(np.zeros(40000, dtype=np.int32), 0, [0], 1)
+    assert ei.value.code == ls_amd._lib.LS_ERR_UNSUPPORTED
+
+
+def test_device_pointer_entry_matches_host_entry(ctx):
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    import ls_amd
+    rng = np.random.default_rng(11)
+    n, R, mc = 300, 4, 5
+    rows = np.stack([_board(rng, n, "uniform") for _ in range(R)]).astype(np.int32)
+    cols = np.stack([rng.permutation(n)[:mc] for _ in range(R)]).astype(np.int32)
+    ncols = np.full(R, mc, dtype=np.int32)
+    cur = np.array([orc.nq_score(rows[r]) for r in range(R)], dtype=np.int64)
+    ctx.set_algo("scan")
+    host, _ = ctx.nqueens_eval_batch(rows, cur, cols, ncols, 777)
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(x).to(dev) for x in (rows, cur, cols, ncols)]
+    res = torch.zeros(R * 4, dtype=torch.int64, device=dev)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.nqueens_eval_batch_dev(R, n, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), mc,
+                                   777, res.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_stream(None)
+    raw = res.cpu().numpy().reshape(R, 4)
+    for r in range(R):
+        assert raw[r, 0] == host[r]["n_scored"]
+        assert raw[r, 1] == host[r]["best_index"]
+        assert raw[r, 2] == host[r]["best_score"]

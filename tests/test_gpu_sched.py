@@ -1,0 +1,170 @@
+"""GPU parity tests (through the C ABI) for the employee-scheduling path: HIP
+kernels vs the CPU oracle, bit-exact on (hard, soft) per candidate, on the eight
+constraint terms, on n_scored and on the selected candidate.  The reference
+holds no fixture for these scores (parity unpinned by the reference); the oracle
+is cross-checked separately in test_oracle_sched.py."""
+import datetime as dt
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import ls_amd
+    c = ls_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _upload(ctx, start, end, n_emp, hol=None, n_stored=None):
+    inst = orc.Sched(start, end, hol or {})
+    D = inst.n_scored_days
+    S = D + 1 if n_stored is None else n_stored
+    bits = np.zeros(n_emp, dtype=np.uint64)
+    for e, days in (hol or {}).items():
+        for d in days:
+            bits[e] |= np.uint64(1) << np.uint64(d)
+    ctx.sched_instance_upload(D, S, inst.start_weekday, n_emp, bits)
+    return inst, D, S
+
+
+def _random_moves(rng, n, D, n_emp, state):
+    mv = np.zeros((n, 3), dtype=np.int64)
+    for i in range(n):
+        if rng.integers(0, 5) == 0 or D < 2:              # ChangeDay : SwapDays = 1 : 4 (lib.rs:435)
+            mv[i] = (0, rng.integers(0, D), rng.integers(0, n_emp))
+        else:
+            a, b = rng.choice(D, size=2, replace=False)
+            mv[i] = (1, a, b)
+    return mv
+
+
+def test_survey_kats(ctx, golden_dir):
+    with open(os.path.join(golden_dir, "sched_kats.json")) as f:
+        g = json.load(f)
+    for case in g["cases"]:
+        hol = {int(k): v for k, v in case["holidays"].items()}
+        _upload(ctx, g["start"], g["end"], 7, hol, g["n_stored"])
+        d = np.arange(g["n_stored"])
+        e = {"const0": d * 0, "mod7": d % 7, "mod2": d % 2, "mod3": d % 3}[case["pattern"]]
+        hard, soft, terms = ctx.sched_score(e, want_terms=True)
+        assert (hard[0], soft[0]) == (case["hard"], case["soft"]), case
+        assert terms[0].tolist() == case["terms"], case
+
+
+@pytest.mark.parametrize("start,end,n_emp", [
+    ((2022, 5, 9), (2022, 6, 8), 7),       # config 3: the reference example (main.rs:11-21)
+    ((2022, 5, 9), (2022, 6, 8), 2),
+    ((2022, 5, 9), (2022, 6, 8), 10000),   # config 5 employee count
+    ((2023, 12, 30), (2024, 2, 29), 5),    # 62 scored / 63 stored days, Saturday start
+    ((2024, 1, 6), (2024, 3, 9), 4),       # 64 scored days (the maximum), stored == scored
+    ((2024, 1, 3), (2024, 1, 10), 3),      # 8 days: no 9-/14-window
+    ((2024, 1, 3), (2024, 1, 3), 3),       # one day
+])
+def test_score_vs_oracle(ctx, start, end, n_emp):
+    rng = np.random.default_rng(abs(hash((start, end, n_emp))) % 2 ** 32)
+    d = (dt.date(*end) - dt.date(*start)).days + 1
+    hol = {}
+    for emp in range(min(n_emp, 50)):
+        k = int(rng.integers(0, 4))
+        if k:
+            hol[emp] = rng.choice(d, size=min(k, d), replace=False).tolist()
+    inst, D, S = _upload(ctx, start, end, n_emp, hol, n_stored=min(d + 1, 64))
+    pool = min(n_emp, 50) if n_emp > 100 else n_emp      # force repeats even with 10k employees
+    states = rng.integers(0, pool, size=(300, S))
+    states[:50] = rng.integers(0, min(3, n_emp), size=(50, S))
+    hard, soft, terms = ctx.sched_score(states, want_terms=True)
+    for i in range(len(states)):
+        h, s, t = inst.score(states[i], terms=True)
+        assert terms[i].tolist() == t.tolist(), (i, states[i])
+        assert (hard[i], soft[i]) == (h, s)
+
+
+@pytest.mark.parametrize("n_emp,window", [(7, 100), (7, 10 ** 9), (2, 37), (10000, 4096)])
+def test_neighbourhood_random_stream(ctx, n_emp, window):
+    start, end = (2022, 5, 9), (2022, 6, 8)
+    rng = np.random.default_rng(n_emp + window % 1000)
+    hol = {e: rng.choice(31, size=2, replace=False).tolist() for e in range(0, min(n_emp, 40), 3)}
+    inst, D, S = _upload(ctx, start, end, n_emp, hol)
+    for trial in range(3):
+        state = rng.integers(0, min(n_emp, 12), size=S)
+        moves = _random_moves(rng, 700, D, min(n_emp, 12), state)
+        exp = inst.neighbourhood(state, moves, window)
+        got, hard, soft = ctx.sched_eval(state, moves, window, want_scores=True)
+        assert got["n_scored"] == exp["n_scored"]
+        assert got["best_index"] == exp["best_index"]
+        assert (got["best_hard"], got["best_soft"]) == (exp["best_hard"], exp["best_soft"])
+        assert np.array_equal(hard, exp["hard"]) and np.array_equal(soft, exp["soft"])
+
+
+def test_neighbourhood_exhaustive_proposer(ctx):
+    # ScheduleMoveProposer order (lib.rs:526-550): 32 stored days x E employees, one no-op per day
+    start, end, n_emp = (2022, 5, 9), (2022, 6, 8), 40
+    rng = np.random.default_rng(3)
+    inst, D, S = _upload(ctx, start, end, n_emp, {1: [4], 7: [0, 30]})
+    state = rng.integers(0, n_emp, size=S)
+    moves = orc.Sched.exhaustive_moves(state, range(n_emp))
+    assert len(moves) == S * n_emp
+    exp = inst.neighbourhood(state, moves, 10 ** 9)
+    got, hard, soft = ctx.sched_eval(state, moves, 10 ** 9, want_scores=True)
+    assert got["n_scored"] == exp["n_scored"] == S * (n_emp - 1)
+    assert got["best_index"] == exp["best_index"]
+    assert np.array_equal(hard, exp["hard"]) and np.array_equal(soft, exp["soft"])
+
+
+def test_batched_restarts_ragged(ctx):
+    start, end, n_emp = (2022, 5, 9), (2022, 6, 8), 7
+    rng = np.random.default_rng(17)
+    inst, D, S = _upload(ctx, start, end, n_emp)
+    R, max_moves = 6, 250
+    states = rng.integers(0, n_emp, size=(R, S))
+    moves = np.stack([_random_moves(rng, max_moves, D, n_emp, states[r]) for r in range(R)])
+    n_moves = np.array([0, 1, 100, 250, 17, 249])
+    out, hard, soft = ctx.sched_eval_batch(states, moves, n_moves, 100, want_scores=True)
+    for r in range(R):
+        exp = inst.neighbourhood(states[r], moves[r, :n_moves[r]], 100)
+        assert out[r]["n_scored"] == exp["n_scored"]
+        assert out[r]["best_index"] == exp["best_index"]
+        if exp["best_index"] >= 0:
+            assert (out[r]["best_hard"], out[r]["best_soft"]) == (exp["best_hard"], exp["best_soft"])
+        assert np.array_equal(hard[r, :n_moves[r]], exp["hard"])
+        assert (hard[r, n_moves[r]:] == orc.SKIPPED).all()
+
+
+def test_tie_break_and_first_of_equals(ctx):
+    # identical moves proposed twice: first position wins; swap(a,b) == swap(b,a)
+    inst, D, S = _upload(ctx, (2022, 5, 9), (2022, 6, 8), 7)
+    state = (np.arange(S) % 7).astype(np.int64)
+    moves = [(1, 3, 9), (1, 9, 3), (0, 5, 0), (0, 5, 0), (1, 3, 9), (0, 31, 2), (0, 31, 2)]
+    exp = inst.neighbourhood(state, moves, 100)
+    got, hard, soft = ctx.sched_eval(state, moves, 100, want_scores=True)
+    assert got["best_index"] == exp["best_index"]
+    assert np.array_equal(hard, exp["hard"]) and np.array_equal(soft, exp["soft"])
+    # stored-but-unscored tail entry (index 31) changes the vector order, not the score
+    assert hard[5] == hard[6] and exp["hard"][5] != orc.SKIPPED
+
+
+def test_errors(ctx):
+    import ls_amd
+    c2 = ls_amd.Context(0)
+    with pytest.raises(ls_amd.LsError) as ei:
+        c2.sched_score(np.zeros(32, dtype=np.int32))
+    assert ei.value.code == ls_amd._lib.LS_ERR_STATE
+    with pytest.raises(ls_amd.LsError) as ei:
+        c2.sched_instance_upload(70, 71, 0, 3)
+    assert ei.value.code == ls_amd._lib.LS_ERR_UNSUPPORTED
+    c2.sched_instance_upload(31, 32, 0, 3)
+    with pytest.raises(ls_amd.LsError):
+        c2.sched_score(np.full(32, 3, dtype=np.int32))       # employee index out of range
+    with pytest.raises(ls_amd.LsError):
+        c2.sched_eval(np.zeros(32, dtype=np.int32), [(2, 0, 0)], 10)   # unknown move type
+    with pytest.raises(ls_amd.LsError):
+        c2.sched_instance_upload(31, 32, 0, 1, np.array([1 << 40], dtype=np.uint64))  # holiday outside range
+    c2.close()
