@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py — neighbour evaluations / second of the N-queens neighbourhood
+evaluator on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (kernel-throughput mode): per GPU 8
+independent restarts, each a fixed pseudo-random n = 4096 board (uniform rows,
+seed = global restart id); one STEP = one launch that scores the FULL n x n
+neighbourhood of every restart (all columns in order, window = n(n-1) non-tabu
+candidates) and selects each restart's (score, board)-minimum.  Inputs are
+resident in HBM before the timed region.  Weak scaling: restarts per GPU fixed.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "constraint-solver_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_neighbour(n: int) -> int:
+    """one scan of the packed int32 state (4n) + 8 B move descriptor + 8 B result."""
+    return 4 * n + 16
+
+
+def make_boards(n: int, restart_ids) -> np.ndarray:
+    return np.stack([np.random.default_rng(int(r)).integers(0, n, size=n) for r in restart_ids]).astype(np.int32)
+
+
+def cpu_baseline(n: int, board: np.ndarray, target_seconds: float):
+    """The oracle's literal restatement of the reference CPU path (clone + tabu test + full
+    O(n^2) rescoring + running (score, board) minimum per candidate), single thread, on a
+    bounded sample of the same workload: the first `sample` candidates of restart 0."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+
+    orc.build()
+    cols = np.arange(n)
+    t0 = time.perf_counter()
+    ns, _ = orc.nq_baseline_run(board, cols, 32)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    sample = int(max(64, min(n * (n - 1), target_seconds * ns / dt)))
+    t0 = time.perf_counter()
+    ns, best = orc.nq_baseline_run(board, cols, sample)
+    dt = time.perf_counter() - t0
+    return dict(value=ns / dt, unit="neighbour evals/s", cores=1, kind="port",
+                sample=f"first {ns} non-tabu candidates of restart 0 (n={n}, full O(n^2) rescoring each), "
+                       f"{dt:.1f} s on one host core; reference is single-threaded Rust, unbuildable here",
+                ), ns, best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--restarts-per-gpu", type=int, default=8)
+    ap.add_argument("--algo", choices=["scan", "table"], default="scan")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import ls_amd
+    from ls_amd import sharding
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the evaluator has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, R = args.n, args.restarts_per_gpu
+    # restart r -> rank r mod world; R restarts per GPU
+    my_ids = sharding.shard_restarts(R * world, world, rank)
+    boards = make_boards(n, my_ids)
+    ctx = ls_amd.Context(local_rank, algo=args.algo)
+    info = ctx.device_info()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # current scores from the GPU col-score kernel (bit-identical to get_col_scores; tested)
+    _, cur_np = ctx.nqueens_col_scores(boards)
+    rows_d = torch.from_numpy(boards).to(dev)
+    cur_d = torch.from_numpy(cur_np).to(dev)
+    cols_d = torch.arange(n, dtype=torch.int32, device=dev).repeat(R, 1).contiguous()
+    ncols_d = torch.full((R,), n, dtype=torch.int32, device=dev)
+    res_d = torch.zeros((R, 4), dtype=torch.int64, device=dev)
+    window = n * (n - 1)
+    neighbours_per_step = R * n * (n - 1)
+
+    def step():
+        ctx.nqueens_eval_batch_dev(R, n, rows_d.data_ptr(), cur_d.data_ptr(), cols_d.data_ptr(), ncols_d.data_ptr(),
+                                   n, window, res_d.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    launch_ms = [a.elapsed_time(b) for a, b in ev]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # results: host-side gather of one (score, board) record per restart, global minimum
+    res = res_d.cpu().numpy()
+    recs = []
+    for i, rid in enumerate(my_ids):
+        b = boards[i].copy()
+        col, val = int(res[i, 3] & 0xFFFFFFFF), int(res[i, 3] >> 32)
+        b[col] = val
+        recs.append(sharding.record(rid, int(res[i, 2]), b))
+        assert res[i, 0] == n * (n - 1), "every non-tabu candidate of the full neighbourhood must be scored"
+    best, all_recs = sharding.gather_best(recs)
+
+    if rank == 0:
+        value = neighbours_per_step * world * args.steps / elapsed
+        avg_launch_s = float(np.mean(launch_ms)) / 1e3
+        bpn = algorithmic_bytes_per_neighbour(n)
+        achieved = neighbours_per_step * bpn / avg_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(f"nq_{args.algo}_n{n}_r{R}", {}).get("bytes_per_launch")
+        out = {
+            "metric": "neighbor evals/sec (N=4096 nqueens)" if n == 4096 else f"neighbor evals/sec (N={n} nqueens)",
+            "value": value,
+            "unit": "neighbour evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"nqueens n={n}, {R} independent restarts per GPU ({R * world} total, restart r on rank r mod {world}), "
+                            f"full n x n neighbourhood per restart per launch (window = n(n-1) = {window}), "
+                            f"uniform-random boards seeded by restart id, algo={args.algo}",
+                "n": n, "restarts_per_gpu": R, "neighbours_per_step_per_gpu": neighbours_per_step,
+                "algo": args.algo, "device": info["name"], "n_cus": info["n_cus"],
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic,
+                "kernel": "nq_scan_regs_kernel<64>" if (args.algo == "scan" and 2048 < n <= 4096) else f"nq_{args.algo}",
+                "avg_launch_ms": avg_launch_s * 1e3,
+                "algorithmic_bytes_per_neighbour": bpn,
+                "note": "algorithmic bytes per SURVEY 8(d) (4n+16 per neighbour); the 16 KiB state is shared by all "
+                        "candidates of a restart and is held in registers/LDS, so the effective rate can exceed the HBM peak",
+            },
+            "global_best": {"score": best[0][0], "restart": best[2]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cb, ns, cb_best = cpu_baseline(n, boards[0], args.cpu_seconds)
+            out["cpu_baseline"] = cb
+            out["cpu_baseline"]["gpu_over_cpu"] = value / cb["value"]
+        if not args.no_extra and world == 1:
+            out["extra"] = extra_measurements(ctx, torch, dev, n, R, boards, cur_np)
+        print(json.dumps(out), flush=True)
+    barrier()
+    ctx.set_stream(None)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extra_measurements(ctx, torch, dev, n, R, boards, cur_np):
+    """Secondary lines (not `value`): the other kernel family on the same workload and the
+    reference-shaped small launch (<= 204 proposed columns, window 5n), SURVEY 8(d) config 4."""
+    out = {}
+    rows_d = torch.from_numpy(boards).to(dev)
+    cur_d = torch.from_numpy(cur_np).to(dev)
+    res_d = torch.zeros((R, 4), dtype=torch.int64, device=dev)
+
+    def timed(fn, iters):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters / 1e3
+
+    cols_full = torch.arange(n, dtype=torch.int32, device=dev).repeat(R, 1).contiguous()
+    ncols_full = torch.full((R,), n, dtype=torch.int32, device=dev)
+    rng = np.random.default_rng(12345)
+    mc = max(1, min(n // 20, n))
+    cols_ref = torch.from_numpy(np.stack([rng.permutation(n)[:mc] for _ in range(R)]).astype(np.int32)).to(dev)
+    ncols_ref = torch.full((R,), mc, dtype=torch.int32, device=dev)
+    for algo in ("scan", "table"):
+        ctx.set_algo(algo)
+        s = timed(lambda: ctx.nqueens_eval_batch_dev(R, n, rows_d.data_ptr(), cur_d.data_ptr(), cols_full.data_ptr(),
+                                                     ncols_full.data_ptr(), n, n * (n - 1), res_d.data_ptr()),
+                  5 if algo == "scan" else 50)
+        out[f"{algo}_full_neighbourhood"] = {"neighbours_per_s": R * n * (n - 1) / s, "ms_per_launch": s * 1e3}
+        w = 5 * n
+        s = timed(lambda: ctx.nqueens_eval_batch_dev(R, n, rows_d.data_ptr(), cur_d.data_ptr(), cols_ref.data_ptr(),
+                                                     ncols_ref.data_ptr(), mc, w, res_d.data_ptr()), 200)
+        out[f"{algo}_reference_shaped_window_5n"] = {"neighbours_per_s": R * min(w, mc * (n - 1)) / s,
+                                                     "us_per_launch": s * 1e6, "candidates_per_launch": R * min(w, mc * (n - 1))}
+    return out
+
+
+if __name__ == "__main__":
+    main()

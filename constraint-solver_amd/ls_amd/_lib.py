@@ -76,6 +76,38 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, the
+    same as /opt/rocm's).  Two HIP runtimes in one process cannot both own the GPU, so
+    when torch is installed its copy is loaded first and libls_amd.so binds to it by
+    SONAME; a later `import torch` then finds its runtime already mapped.  torch itself
+    is NOT imported here.  LS_AMD_SYSTEM_HIP=1 keeps the system runtime instead."""
+    if os.environ.get("LS_AMD_SYSTEM_HIP") == "1":
+        return None
+    import importlib.util
+    import sys
+
+    origin = None
+    if "torch" in sys.modules:
+        origin = getattr(sys.modules["torch"], "__file__", None)
+    else:
+        try:
+            spec = importlib.util.find_spec("torch")
+            origin = spec.origin if spec else None
+        except (ImportError, ValueError):
+            origin = None
+    if not origin:
+        return None
+    cand = os.path.join(os.path.dirname(origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        return cand
+    return None
+
+
+HIP_RUNTIME = None
+
+
 def load() -> C.CDLL:
     """Load libls_amd.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -84,6 +116,8 @@ def load() -> C.CDLL:
             raise ImportError(
                 f"{SO_PATH} is missing: build it with `python constraint-solver_amd/build.py` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        global HIP_RUNTIME
+        HIP_RUNTIME = _share_hip_runtime_with_torch() or "system"
         lib = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
