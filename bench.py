@@ -100,7 +100,12 @@ def main():
     boards = make_boards(n, my_ids)
     ctx = ls_amd.Context(local_rank, algo=args.algo)
     info = ctx.device_info()
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # a dedicated (non-default) torch stream: HIP events recorded on it bracket the kernels
+    # (ls_ctx_set_stream(NULL) would select the context's own stream, and 0 is torch's default stream)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    ctx.set_stream(stream.cuda_stream)
 
     # current scores from the GPU col-score kernel (bit-identical to get_col_scores; tested)
     _, cur_np = ctx.nqueens_col_scores(boards)

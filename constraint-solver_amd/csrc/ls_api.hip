@@ -3,6 +3,7 @@
 // nq_kernels.hip / sched_kernels.hip.  No CPU fallback exists anywhere in this
 // library: without a HIP device ls_ctx_create fails.
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -93,6 +94,7 @@ int ls_ctx_create(int device_id, ls_ctx **out)
         return LS_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (const char *v = getenv("LS_NQ_SCAN_VARIANT")) ctx->nq_scan_variant = atoi(v);
     ctx->n_cus = prop.multiProcessorCount;
     ctx->wave_size = prop.warpSize;
     ctx->clock_khz = prop.clockRate;
@@ -172,6 +174,9 @@ static int nq_check_dims(ls_ctx *ctx, int32_t n_restarts, int32_t n, int32_t max
     LS_REQUIRE(ctx, n >= 1, "n must be >= 1 (got %d)", n);
     if (n > LS_NQ_MAX_N) return set_err(ctx, LS_ERR_UNSUPPORTED, "n = %d exceeds LS_NQ_MAX_N = %d", n, LS_NQ_MAX_N);
     LS_REQUIRE(ctx, max_cols >= 0, "max_cols must be >= 0 (got %d)", max_cols);
+    if (max_cols > LS_NQ_MAX_N)
+        return set_err(ctx, LS_ERR_UNSUPPORTED, "max_cols = %d exceeds %d (15-bit slot field of the argmin key)", max_cols,
+                       LS_NQ_MAX_N);
     LS_REQUIRE(ctx, window >= 0, "window must be >= 0 (got %lld)", (long long)window);
     return LS_OK;
 }

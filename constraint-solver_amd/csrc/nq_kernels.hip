@@ -52,15 +52,28 @@ struct NqArgs {
     int tab_stride;
 };
 
-__device__ __forceinline__ unsigned long long nq_key_hi(int is_up, int c, int n)
+// key = delta+bias (18 bits) | up (1) | colkey (15) | v (15) | slot (15).  The slot (position of
+// the column in the proposer's list) is last: it only separates identical candidates of a
+// duplicated column, where the earlier one must win (stable sort + first()).
+__device__ __forceinline__ unsigned long long nq_key_hi(int is_up, int c, int n, int slot)
 {
     const unsigned colkey = is_up ? (unsigned)(n - 1 - c) : (unsigned)c;
-    return ((unsigned long long)(unsigned)is_up << 30) | ((unsigned long long)colkey << 15);
+    return ((unsigned long long)(unsigned)is_up << 45) | ((unsigned long long)colkey << 30) | (unsigned)slot;
 }
 
 __device__ __forceinline__ unsigned long long nq_key(int delta, unsigned long long hi, int v)
 {
-    return ((unsigned long long)(unsigned)(delta + NQ_DELTA_BIAS) << 31) | hi | (unsigned)v;
+    return ((unsigned long long)(unsigned)(delta + NQ_DELTA_BIAS) << 46) | hi | ((unsigned long long)(unsigned)v << 15);
+}
+
+// Unfiltered positions [0, nq_k_limit) are the only ones take(window) can reach: each column
+// holds n - 1 real candidates and one no-op.
+__device__ __forceinline__ long long nq_k_limit(long long K, int n, long long window)
+{
+    if (n <= 1 || window <= 0) return 0;
+    const long long full = window / (n - 1), rem = window % (n - 1);
+    const long long lim = full * n + (rem > 0 ? rem + 1 : 0);
+    return lim < K ? lim : K;
 }
 
 __device__ __forceinline__ unsigned long long u64min(unsigned long long a, unsigned long long b)
@@ -97,28 +110,67 @@ __device__ __forceinline__ NqRanges nq_ranges(int vs, int ve, int rc, long long 
 }
 
 // ===================================================================== SCAN
-// Register-resident state: lane l holds columns j = l + 64*i, i < NR.
+// Register-resident state.  A "board" policy holds the three equality arrays of
+// one restart in the wavefront's registers and counts, for four consecutive
+// values v..v+3 of one column c, the matches of (v, v-c, v+c) over all columns.
+// Variants differ only in how a match is turned into a count (measured on
+// MI355X); all produce identical counts.
+//   SELF = what the column's own queen adds when its own square is counted.
 
-template <int NR>
-__device__ __forceinline__ int nq_count1(const int (&R)[NR], const int (&A)[NR], const int (&B)[NR],
-                                         int v, int va, int vb)
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+// waves per SIMD a kernel needing `vgprs` registers per lane can hold (512-entry file)
+constexpr int nq_waves_for(int vgprs) { return 512 / vgprs < 1 ? 1 : (512 / vgprs > 8 ? 8 : 512 / vgprs); }
+
+__device__ __forceinline__ us2 as_us2(unsigned x) { return __builtin_bit_cast(us2, x); }
+__device__ __forceinline__ unsigned as_u32(us2 x) { return __builtin_bit_cast(unsigned, x); }
+
+// min(x, y) per 16-bit half as ONE instruction.  Written as asm because hipcc
+// rewrites min(x, 1) into two scalar-half compares + selects + a permute.
+__device__ __forceinline__ us2 pk_min_u16_raw(us2 x, us2 y)
 {
-    int c = 0;
-#pragma unroll
-    for (int i = 0; i < NR; i++) c += (int)((R[i] == v) | (A[i] == va) | (B[i] == vb));
-    return wave_sum_i32(c);
+    us2 r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
 }
 
-template <int NR>
-__device__ __forceinline__ void nq_scan_range_regs(const int (&R)[NR], const int (&A)[NR],
-                                                   const int (&B)[NR], int vbeg, int vend, int c,
-                                                   int conf_old, unsigned long long khi,
-                                                   unsigned long long &best, long long *scores_row,
-                                                   long long cur, int lane)
+// per-lane counts < 2^15, wave totals <= n + 2 < 2^16: reduce two candidates per register
+__device__ __forceinline__ void nq_reduce4(int c0, int c1, int c2, int c3, int (&cnt)[4])
 {
-    for (int v = vbeg; v < vend; v += 4) {
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    const unsigned t01 = (unsigned)wave_sum_i32(c0 | (c1 << 16));
+    const unsigned t23 = (unsigned)wave_sum_i32(c2 | (c3 << 16));
+    cnt[0] = (int)(t01 & 0xffffu); cnt[1] = (int)(t01 >> 16);
+    cnt[2] = (int)(t23 & 0xffffu); cnt[3] = (int)(t23 >> 16);
+}
+
+// 32-bit integer lanes: lane l holds columns j = l + 64*i, i < NR  (n <= 64*NR).  The
+// three equality masks are OR-ed on the scalar unit and added with one carry-add
+// (3 v_cmp + 2 s_or + 1 v_addc per column).  Kept as the plain formulation the other
+// two are measured against (LS_NQ_SCAN_VARIANT=2); v_cmp with a scalar destination is
+// a half-rate instruction on gfx950 and the s_or chain serialises behind it.
+template <int NR>
+struct BoardI32 {
+    static constexpr int CAP = 64 * NR;
+    static constexpr int SELF = 1;
+    static constexpr int WAVES = nq_waves_for(3 * NR + 32);
+    int R[NR], A[NR], B[NR];
+    __device__ __forceinline__ void load(const int *__restrict__ rows, int n, int lane)
+    {
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            const int j = lane + 64 * i;
+            const bool in = j < n;
+            const int r = in ? rows[j] : 0;
+            R[i] = in ? r : NQ_SENT;
+            A[i] = in ? r - j : NQ_SENT;
+            B[i] = in ? r + j : NQ_SENT;
+        }
+    }
+    __device__ __forceinline__ void prepare(int, int) {}
+    __device__ __forceinline__ void count4(int v, int c, int (&cnt)[4]) const
+    {
         const int va = v - c, vb = v + c;
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
         for (int i = 0; i < NR; i++) {
             const int r = R[i], a = A[i], b = B[i];
@@ -127,10 +179,150 @@ __device__ __forceinline__ void nq_scan_range_regs(const int (&R)[NR], const int
             c2 += (int)((r == v + 2) | (a == va + 2) | (b == vb + 2));
             c3 += (int)((r == v + 3) | (a == va + 3) | (b == vb + 3));
         }
-        // per-lane counts <= 3*NR <= 192, wave totals <= n + 2 < 2^16: reduce two per register
-        const unsigned t01 = (unsigned)wave_sum_i32(c0 | (c1 << 16));
-        const unsigned t23 = (unsigned)wave_sum_i32(c2 | (c3 << 16));
-        const int cnt[4] = {(int)(t01 & 0xffffu), (int)(t01 >> 16), (int)(t23 & 0xffffu), (int)(t23 >> 16)};
+        nq_reduce4(c0, c1, c2, c3, cnt);
+    }
+};
+
+// Packed 16-bit lanes: register i of lane l holds columns l + 64*(2i) (low half)
+// and l + 64*(2i+1) (high half)  (n <= 128*NRP <= 8192).  A is stored biased by
+// +n so every entry is a u16.  A match zeroes the XOR with the replicated
+// comparand; min over the three XORs is zero iff the column attacks; pure VALU,
+// 3.5 instructions per column pair and candidate, no scalar mask traffic.
+template <int NRP>
+struct BoardPk16 {
+    static constexpr int CAP = 128 * NRP;
+    static constexpr int SELF = 1;
+    static constexpr int WAVES = nq_waves_for(3 * NRP + 32);
+    us2 R[NRP], A[NRP], B[NRP];
+    int n;
+    __device__ __forceinline__ void load(const int *__restrict__ rows, int n_, int lane)
+    {
+        n = n_;
+#pragma unroll
+        for (int i = 0; i < NRP; i++) {
+            unsigned pr = 0, pa = 0, pb = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int j = lane + 64 * (2 * i + h);
+                const bool in = j < n_;
+                const int r = in ? rows[j] : 0;
+                const unsigned vr = in ? (unsigned)r : 0xffffu;
+                const unsigned va = in ? (unsigned)(r - j + n_) : 0xffffu;
+                const unsigned vb = in ? (unsigned)(r + j) : 0xffffu;
+                pr |= vr << (16 * h); pa |= va << (16 * h); pb |= vb << (16 * h);
+            }
+            R[i] = as_us2(pr); A[i] = as_us2(pa); B[i] = as_us2(pb);
+        }
+    }
+    __device__ __forceinline__ void prepare(int, int) {}
+    __device__ __forceinline__ void count4(int v, int c, int (&cnt)[4]) const
+    {
+        const unsigned rep = 0x00010001u;
+        const unsigned Vr = (unsigned)v * rep, Va = (unsigned)(v - c + n) * rep, Vb = (unsigned)(v + c) * rep;
+        const us2 one = as_us2(rep);
+        us2 m0 = as_us2(0u), m1 = m0, m2 = m0, m3 = m0; // mismatching halves per candidate
+#pragma unroll
+        for (int i = 0; i < NRP; i++) {
+            const unsigned r = as_u32(R[i]), a = as_u32(A[i]), b = as_u32(B[i]);
+#define LS_PK_STEP(acc, u)                                                                          \
+    {                                                                                               \
+        const us2 x = __builtin_elementwise_min(                                                    \
+            __builtin_elementwise_min(as_us2(r ^ (Vr + (u) * rep)), as_us2(a ^ (Va + (u) * rep))),  \
+            as_us2(b ^ (Vb + (u) * rep)));                                                          \
+        acc += pk_min_u16_raw(x, one);                                                              \
+    }
+            LS_PK_STEP(m0, 0u)
+            LS_PK_STEP(m1, 1u)
+            LS_PK_STEP(m2, 2u)
+            LS_PK_STEP(m3, 3u)
+#undef LS_PK_STEP
+        }
+        // matches per lane = halves - mismatches
+        const int c0 = 2 * NRP - (int)(m0.x + m0.y), c1 = 2 * NRP - (int)(m1.x + m1.y);
+        const int c2 = 2 * NRP - (int)(m2.x + m2.y), c3 = 2 * NRP - (int)(m3.x + m3.y);
+        nq_reduce4(c0, c1, c2, c3, cnt);
+    }
+};
+
+// clamp(|x| * |y|, 0, 1) as ONE instruction (source abs + output clamp modifiers).  hipcc
+// emits v_mul + v_max(clamp) for the equivalent C expression, so it is spelled out.
+__device__ __forceinline__ float mul_abs_clamp(float x, float y)
+{
+    float r;
+    asm("v_mul_f32_e64 %0, |%1|, |%2| clamp" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
+// FP32 lanes: lane l holds rows[j] as a float for j = l + 64*i, plus, for the column c
+// being scanned, E[i] = |j - c| (recomputed when the column changes).  With d = |rows[j] - v|
+// column j attacks square (c, v) iff d == 0 or d == |j - c|, i.e. iff d * (d - E) == 0
+// (also true for the own column j == c where E == 0).  Both factors are integers of
+// magnitude < 2^15, so the product is zero exactly when a factor is and otherwise >= 1 in
+// magnitude; the clamp output modifier turns it into a 0/1 mismatch flag.  4 FP32
+// instructions per column and candidate (sub, sub, mul+abs+clamp, add), which issue at
+// twice the rate of the integer VALU ops on gfx950.
+template <int NR>
+struct BoardF32 {
+    static constexpr int CAP = 64 * NR;
+    static constexpr int SELF = 1;
+    static constexpr int WAVES = nq_waves_for(2 * NR + 40);
+    float R[NR], E[NR];
+    __device__ __forceinline__ void load(const int *__restrict__ rows, int n, int lane)
+    {
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            const int j = lane + 64 * i;
+            R[i] = j < n ? (float)rows[j] : 1.0e9f; // padding never matches
+            E[i] = 0.0f;
+        }
+    }
+    __device__ __forceinline__ void prepare(int c, int lane)
+    {
+#pragma unroll
+        for (int i = 0; i < NR; i++) E[i] = __builtin_fabsf((float)(lane + 64 * i - c));
+    }
+    __device__ __forceinline__ void count4(int v, int c, int (&cnt)[4]) const
+    {
+        (void)c;
+        const float f0 = (float)v, f1 = (float)(v + 1), f2 = (float)(v + 2), f3 = (float)(v + 3);
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f; // mismatching columns per candidate
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            // four candidates interleaved so that neighbouring instructions are independent
+            // (a dependent FP32 op issues every ~4 cycles, an independent one every 2)
+            float d0, d1, d2, d3, u0, u1, u2, u3;
+            asm("v_sub_f32_e32 %4, %12, %14\n\t"
+                "v_sub_f32_e32 %5, %12, %15\n\t"
+                "v_sub_f32_e32 %6, %12, %16\n\t"
+                "v_sub_f32_e32 %7, %12, %17\n\t"
+                "v_sub_f32_e64 %8, |%4|, %13\n\t"
+                "v_sub_f32_e64 %9, |%5|, %13\n\t"
+                "v_sub_f32_e64 %10, |%6|, %13\n\t"
+                "v_sub_f32_e64 %11, |%7|, %13\n\t"
+                "v_mul_f32_e64 %4, |%4|, |%8| clamp\n\t"
+                "v_mul_f32_e64 %5, |%5|, |%9| clamp\n\t"
+                "v_mul_f32_e64 %6, |%6|, |%10| clamp\n\t"
+                "v_mul_f32_e64 %7, |%7|, |%11| clamp\n\t"
+                "v_add_f32_e32 %0, %0, %4\n\t"
+                "v_add_f32_e32 %1, %1, %5\n\t"
+                "v_add_f32_e32 %2, %2, %6\n\t"
+                "v_add_f32_e32 %3, %3, %7"
+                : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3),
+                  "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
+                : "v"(R[i]), "v"(E[i]), "v"(f0), "v"(f1), "v"(f2), "v"(f3));
+        }
+        nq_reduce4(NR - (int)m0, NR - (int)m1, NR - (int)m2, NR - (int)m3, cnt);
+    }
+};
+
+template <class Board>
+__device__ __forceinline__ void nq_scan_range_regs(const Board &bd, int vbeg, int vend, int c, int conf_old,
+                                                   unsigned long long khi, unsigned long long &best,
+                                                   long long *scores_row, long long cur, int lane)
+{
+    for (int v = vbeg; v < vend; v += 4) {
+        int cnt[4];
+        bd.count4(v, c, cnt);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (v + u < vend) {
@@ -142,8 +334,8 @@ __device__ __forceinline__ void nq_scan_range_regs(const int (&R)[NR], const int
     }
 }
 
-template <int NR>
-__global__ __launch_bounds__(256, 2) void nq_scan_regs_kernel(NqArgs a)
+template <class Board>
+__global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs a)
 {
     __shared__ unsigned long long s_best[4];
     const int lane = threadIdx.x & 63;
@@ -156,22 +348,14 @@ __global__ __launch_bounds__(256, 2) void nq_scan_regs_kernel(NqArgs a)
     const int *__restrict__ cols = a.cols + (long long)restart * a.max_cols;
     int ncols = a.n_cols[restart];
     ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
-    const long long K = (long long)ncols * n;
+    const long long K = nq_k_limit((long long)ncols * n, n, a.window);
     const long long k0 = K * wchunk / n_wchunks;
     const long long k1 = K * (wchunk + 1) / n_wchunks;
     unsigned long long best = NQ_KEY_EMPTY;
 
     if (k0 < k1) {
-        int R[NR], A[NR], B[NR];
-#pragma unroll
-        for (int i = 0; i < NR; i++) {
-            const int j = lane + 64 * i;
-            const bool in = j < n;
-            const int r = in ? rows[j] : 0;
-            R[i] = in ? r : NQ_SENT;
-            A[i] = in ? r - j : NQ_SENT;
-            B[i] = in ? r + j : NQ_SENT;
-        }
+        Board bd;
+        bd.load(rows, n, lane);
         const long long cur = a.cur_scores[restart];
         int slot = (int)(k0 / n);
         int v0 = (int)(k0 - (long long)slot * n);
@@ -185,15 +369,16 @@ __global__ __launch_bounds__(256, 2) void nq_scan_regs_kernel(NqArgs a)
                 const long long base = (long long)slot * (n - 1);
                 const NqRanges rg = nq_ranges(v0, ve, rc, base, a.window);
                 if (rg.d1 > rg.d0 || rg.u1 > rg.u0) {
-                    // the column's own queen satisfies the (OR-ed) test of its own square once
-                    const int conf_old = nq_count1<NR>(R, A, B, rc, rc - c, rc + c) - 1;
+                    bd.prepare(c, lane);
+                    // conf(c, rows[c]): scan the own square, drop the own queen's matches
+                    int cnt[4];
+                    bd.count4(rc, c, cnt);
+                    const int conf_old = cnt[0] - Board::SELF;
                     long long *srow = a.scores_out
                                           ? a.scores_out + ((long long)restart * a.max_cols + slot) * n
                                           : nullptr;
-                    nq_scan_range_regs<NR>(R, A, B, rg.d0, rg.d1, c, conf_old, nq_key_hi(0, c, n), best,
-                                           srow, cur, lane);
-                    nq_scan_range_regs<NR>(R, A, B, rg.u0, rg.u1, c, conf_old, nq_key_hi(1, c, n), best,
-                                           srow, cur, lane);
+                    nq_scan_range_regs(bd, rg.d0, rg.d1, c, conf_old, nq_key_hi(0, c, n, slot), best, srow, cur, lane);
+                    nq_scan_range_regs(bd, rg.u0, rg.u1, c, conf_old, nq_key_hi(1, c, n, slot), best, srow, cur, lane);
                 }
             }
             k += ve - v0;
@@ -267,7 +452,7 @@ __global__ __launch_bounds__(256) void nq_scan_lds_kernel(NqArgs a)
     __syncthreads();
     int ncols = a.n_cols[restart];
     ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
-    const long long K = (long long)ncols * n;
+    const long long K = nq_k_limit((long long)ncols * n, n, a.window);
     const long long k0 = K * wchunk / n_wchunks;
     const long long k1 = K * (wchunk + 1) / n_wchunks;
     unsigned long long best = NQ_KEY_EMPTY;
@@ -289,9 +474,9 @@ __global__ __launch_bounds__(256) void nq_scan_lds_kernel(NqArgs a)
                     long long *srow = a.scores_out
                                           ? a.scores_out + ((long long)restart * a.max_cols + slot) * n
                                           : nullptr;
-                    nq_scan_range_lds(sR, n_pad, rg.d0, rg.d1, c, conf_old, nq_key_hi(0, c, n), best, srow,
+                    nq_scan_range_lds(sR, n_pad, rg.d0, rg.d1, c, conf_old, nq_key_hi(0, c, n, slot), best, srow,
                                       cur, lane);
-                    nq_scan_range_lds(sR, n_pad, rg.u0, rg.u1, c, conf_old, nq_key_hi(1, c, n), best, srow,
+                    nq_scan_range_lds(sR, n_pad, rg.u0, rg.u1, c, conf_old, nq_key_hi(1, c, n, slot), best, srow,
                                       cur, lane);
                 }
             }
@@ -343,7 +528,7 @@ __global__ __launch_bounds__(256) void nq_table_eval_kernel(NqArgs a)
     const int *__restrict__ tB = tR + 3 * n;
     int ncols = a.n_cols[restart];
     ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
-    const long long K = (long long)ncols * n;
+    const long long K = nq_k_limit((long long)ncols * n, n, a.window);
     const long long k0 = K * chunk / n_chunks;
     const long long k1 = K * (chunk + 1) / n_chunks;
     unsigned long long best = NQ_KEY_EMPTY;
@@ -363,7 +548,7 @@ __global__ __launch_bounds__(256) void nq_table_eval_kernel(NqArgs a)
                 const int conf_old = tR[rc] + tA[rc - c + n] + tB[rc + c] - 3;
                 long long *srow =
                     a.scores_out ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
-                const unsigned long long khd = nq_key_hi(0, c, n), khu = nq_key_hi(1, c, n);
+                const unsigned long long khd = nq_key_hi(0, c, n, slot), khu = nq_key_hi(1, c, n, slot);
                 for (int v = rg.d0 + (int)threadIdx.x; v < rg.d1; v += 256) {
                     const int delta = tR[v] + tA[v - c + n] + tB[v + c] - conf_old;
                     best = u64min(best, nq_key(delta, khd, v));
@@ -436,15 +621,12 @@ __global__ void nq_finalize_kernel(NqArgs a, ls_nq_result *results)
         out.best_col = -1;
         out.best_value = -1;
     } else {
-        const int v = (int)(key & 0x7fffu);
-        const int colkey = (int)((key >> 15) & 0x7fffu);
-        const int is_up = (int)((key >> 30) & 1u);
+        const int slot = (int)(key & 0x7fffu);
+        const int v = (int)((key >> 15) & 0x7fffu);
+        const int colkey = (int)((key >> 30) & 0x7fffu);
+        const int is_up = (int)((key >> 45) & 1u);
         const int c = is_up ? n - 1 - colkey : colkey;
-        const int delta = (int)(key >> 31) - NQ_DELTA_BIAS;
-        const int *cols = a.cols + (long long)r * a.max_cols;
-        int slot = 0;
-        for (int s = 0; s < ncols; s++)
-            if (cols[s] == c) { slot = s; break; }
+        const int delta = (int)(key >> 46) - NQ_DELTA_BIAS;
         out.best_index = (long long)slot * n + v;
         out.best_score = a.cur_scores[r] + 2ll * delta;
         out.best_col = c;
@@ -461,7 +643,55 @@ static int nq_blocks_per_cu(const void *fn, size_t dyn_lds)
     return nb > 8 ? 8 : nb;
 }
 
-template <int NR> static const void *scan_fn() { return reinterpret_cast<const void *>(&nq_scan_regs_kernel<NR>); }
+template <class Board>
+static int launch_scan_board(ls_ctx *ctx, const NqArgs &a, long long bpr_cap)
+{
+    static int bpc = 0;
+    if (!bpc) bpc = nq_blocks_per_cu(reinterpret_cast<const void *>(&nq_scan_regs_kernel<Board>), 0);
+    long long total = (long long)ctx->n_cus * bpc;
+    long long bpr = total / a.n_restarts;
+    if (bpr < 1) bpr = 1;
+    if (bpr > bpr_cap) bpr = bpr_cap;
+    hipLaunchKernelGGL(nq_scan_regs_kernel<Board>, dim3((unsigned)(bpr * a.n_restarts)), dim3(256), 0, ctx->stream, a);
+    LS_HIP(ctx, hipGetLastError());
+    return LS_OK;
+}
+
+static int launch_scan_i32(ls_ctx *ctx, const NqArgs &a, long long cap)
+{
+    const int n = a.n;
+    if (n <= 64) return launch_scan_board<BoardI32<1>>(ctx, a, cap);
+    if (n <= 128) return launch_scan_board<BoardI32<2>>(ctx, a, cap);
+    if (n <= 256) return launch_scan_board<BoardI32<4>>(ctx, a, cap);
+    if (n <= 512) return launch_scan_board<BoardI32<8>>(ctx, a, cap);
+    if (n <= 1024) return launch_scan_board<BoardI32<16>>(ctx, a, cap);
+    if (n <= 2048) return launch_scan_board<BoardI32<32>>(ctx, a, cap);
+    return launch_scan_board<BoardI32<64>>(ctx, a, cap);
+}
+
+static int launch_scan_pk16(ls_ctx *ctx, const NqArgs &a, long long cap)
+{
+    const int n = a.n;
+    if (n <= 128) return launch_scan_board<BoardPk16<1>>(ctx, a, cap);
+    if (n <= 256) return launch_scan_board<BoardPk16<2>>(ctx, a, cap);
+    if (n <= 512) return launch_scan_board<BoardPk16<4>>(ctx, a, cap);
+    if (n <= 1024) return launch_scan_board<BoardPk16<8>>(ctx, a, cap);
+    if (n <= 2048) return launch_scan_board<BoardPk16<16>>(ctx, a, cap);
+    if (n <= 4096) return launch_scan_board<BoardPk16<32>>(ctx, a, cap);
+    return launch_scan_board<BoardPk16<64>>(ctx, a, cap);
+}
+
+static int launch_scan_f32(ls_ctx *ctx, const NqArgs &a, long long cap)
+{
+    const int n = a.n;
+    if (n <= 64) return launch_scan_board<BoardF32<1>>(ctx, a, cap);
+    if (n <= 128) return launch_scan_board<BoardF32<2>>(ctx, a, cap);
+    if (n <= 256) return launch_scan_board<BoardF32<4>>(ctx, a, cap);
+    if (n <= 512) return launch_scan_board<BoardF32<8>>(ctx, a, cap);
+    if (n <= 1024) return launch_scan_board<BoardF32<16>>(ctx, a, cap);
+    if (n <= 2048) return launch_scan_board<BoardF32<32>>(ctx, a, cap);
+    return launch_scan_board<BoardF32<64>>(ctx, a, cap);
+}
 
 static int launch_scan(ls_ctx *ctx, const NqArgs &a, long long k_max)
 {
@@ -469,36 +699,23 @@ static int launch_scan(ls_ctx *ctx, const NqArgs &a, long long k_max)
     // every wavefront should own >= 16 candidates; never more blocks than fit the chip at once
     long long want_waves = (k_max + 15) / 16;
     if (want_waves < 1) want_waves = 1;
-    long long bpr_cap = (want_waves + 3) / 4;
-    auto grid_for = [&](int blocks_per_cu) {
-        long long total = (long long)ctx->n_cus * blocks_per_cu;
-        long long bpr = total / a.n_restarts;
-        if (bpr < 1) bpr = 1;
-        if (bpr > bpr_cap) bpr = bpr_cap;
-        return (unsigned)(bpr * a.n_restarts);
-    };
-#define LS_SCAN_CASE(NRV)                                                                            \
-    {                                                                                                \
-        static int bpc = 0;                                                                          \
-        if (!bpc) bpc = nq_blocks_per_cu(scan_fn<NRV>(), 0);                                         \
-        hipLaunchKernelGGL(nq_scan_regs_kernel<NRV>, dim3(grid_for(bpc)), dim3(256), 0, ctx->stream, a); \
-    }
-    if (n <= 64) LS_SCAN_CASE(1)
-    else if (n <= 128) LS_SCAN_CASE(2)
-    else if (n <= 256) LS_SCAN_CASE(4)
-    else if (n <= 512) LS_SCAN_CASE(8)
-    else if (n <= 1024) LS_SCAN_CASE(16)
-    else if (n <= 2048) LS_SCAN_CASE(32)
-    else if (n <= 4096) LS_SCAN_CASE(64)
-    else {
-        const int n_pad = (n + 63) & ~63;
-        const size_t lds = (size_t)n_pad * 4 + 32;
-        LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_scan_lds_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        const int bpc = nq_blocks_per_cu(reinterpret_cast<const void *>(&nq_scan_lds_kernel), lds);
-        hipLaunchKernelGGL(nq_scan_lds_kernel, dim3(grid_for(bpc)), dim3(256), lds, ctx->stream, a);
-    }
-#undef LS_SCAN_CASE
+    const long long bpr_cap = (want_waves + 3) / 4;
+    // 0 = default: FP32 registers (n <= 4096), packed u16 registers (n <= 8192), LDS beyond;
+    // 1 = packed u16, 2 = int32 masks (tuning/measurement knobs, LS_NQ_SCAN_VARIANT)
+    const int variant = ctx->nq_scan_variant;
+    if (n <= 4096 && variant == 2) return launch_scan_i32(ctx, a, bpr_cap);
+    if (n <= 4096 && variant != 1) return launch_scan_f32(ctx, a, bpr_cap);
+    if (n <= 8192) return launch_scan_pk16(ctx, a, bpr_cap);
+    const int n_pad = (n + 63) & ~63;
+    const size_t lds = (size_t)n_pad * 4 + 32;
+    LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_scan_lds_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    const int bpc = nq_blocks_per_cu(reinterpret_cast<const void *>(&nq_scan_lds_kernel), lds);
+    long long total = (long long)ctx->n_cus * bpc;
+    long long bpr = total / a.n_restarts;
+    if (bpr < 1) bpr = 1;
+    if (bpr > bpr_cap) bpr = bpr_cap;
+    hipLaunchKernelGGL(nq_scan_lds_kernel, dim3((unsigned)(bpr * a.n_restarts)), dim3(256), lds, ctx->stream, a);
     LS_HIP(ctx, hipGetLastError());
     return LS_OK;
 }
@@ -531,9 +748,11 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
     a.best_keys = ctx->nq_keys.as<unsigned long long>();
     a.scores_out = scores_out_d;
     a.tabs = nullptr; a.tab_stride = 0;
-    const long long k_max = (long long)max_cols * n;
+    const long long k_all = (long long)max_cols * n;
+    long long k_max = k_all;
+    if (n > 1 && window / (n - 1) < max_cols) k_max = (window / (n - 1) + 1) * n; // reachable by take(window)
     if (scores_out_d) {
-        const long long cnt = (long long)n_restarts * k_max;
+        const long long cnt = (long long)n_restarts * k_all;
         if (cnt > 0) {
             long long g = (cnt + 255) / 256;
             if (g > 4096) g = 4096;

@@ -238,3 +238,17 @@ def test_device_pointer_entry_matches_host_entry(ctx):
         assert raw[r, 0] == host[r]["n_scored"]
         assert raw[r, 1] == host[r]["best_index"]
         assert raw[r, 2] == host[r]["best_score"]
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_scan_formulations_agree(monkeypatch, variant):
+    # the register-scan kernel has three inner-loop formulations (fp32 product test = default,
+    # packed-u16 min3, int32 compare masks); all must be bit-identical to the oracle
+    import ls_amd
+    monkeypatch.setenv("LS_NQ_SCAN_VARIANT", variant)
+    with ls_amd.Context(0, algo="scan") as c:
+        rng = np.random.default_rng(int(variant))
+        for n, n_cols in ((9, 9), (200, 7), (1000, 5), (4096, 6), (6000, 2)):
+            rows = _board(rng, n, "uniform")
+            cols = rng.permutation(n)[:n_cols]
+            _check(c, "scan", rows, cols, 5 * n, "table")

@@ -1,0 +1,195 @@
+// tools/valu_rates.hip — issue-rate probe for the VALU instructions the scan kernels use.
+// Diagnostic only (not part of the library): measures, on the GPU it runs on,
+// cycles per wave-instruction per SIMD for independent instruction streams at
+// 1..N waves per SIMD, and the shader clock actually held under that load
+// (s_memtime ticks / wall time).  Build: hipcc --offload-arch=gfx950 -O2 tools/valu_rates.hip -o tools/_build/valu_rates
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                          \
+    do {                                                                                  \
+        hipError_t e = (x);                                                               \
+        if (e != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e)); exit(1); } \
+    } while (0)
+
+// 16 independent instructions per block; operands: %0..%15 = 16 VGPR accumulators, %16 %17 = VGPR sources
+#define REP16(OP)                                                                         \
+    OP("%0") OP("%1") OP("%2") OP("%3") OP("%4") OP("%5") OP("%6") OP("%7")               \
+    OP("%8") OP("%9") OP("%10") OP("%11") OP("%12") OP("%13") OP("%14") OP("%15")
+
+#define OP_FMA(d) "v_fma_f32 " d ", %16, %17, " d "\n\t"
+#define OP_SUB32(d) "v_sub_f32_e32 " d ", %16, " d "\n\t"
+#define OP_SUB64ABS(d) "v_sub_f32_e64 " d ", |" d "|, %17\n\t"
+#define OP_MULCLAMP(d) "v_mul_f32_e64 " d ", |" d "|, |%16| clamp\n\t"
+#define OP_ADDF(d) "v_add_f32_e32 " d ", %16, " d "\n\t"
+#define OP_XOR(d) "v_xor_b32_e32 " d ", %16, " d "\n\t"
+#define OP_PKMINU16(d) "v_pk_min_u16 " d ", " d ", %16\n\t"
+#define OP_PKADDU16(d) "v_pk_add_u16 " d ", " d ", %16\n\t"
+#define OP_ADDU32(d) "v_add_u32_e32 " d ", %16, " d "\n\t"
+#define OP_CMPEQ(d) "v_cmp_eq_u32_e64 s[20:21], " d ", %16\n\t"
+#define OP_PKADDF32(d) "v_pk_add_f32 %[p0], %[p0], %[p1]\n\t"
+#define OP_MIN3F(d) "v_min3_f32 " d ", " d ", %16, %17\n\t"
+#define OP_SADU32(d) "v_sad_u32 " d ", " d ", %16, %17\n\t"
+#define OP_MADU24(d) "v_mad_u32_u24 " d ", " d ", %16, %17\n\t"
+#define OP_PKFMAF16(d) "v_pk_fma_f16 " d ", " d ", %16, %17\n\t"
+#define OP_PKMULF16(d) "v_pk_mul_f16 " d ", " d ", %16\n\t"
+#define OP_MED3F(d) "v_med3_f32 " d ", " d ", %16, %17\n\t"
+#define OP_PKMAXI16(d) "v_pk_max_i16 " d ", " d ", %16\n\t"
+#define OP_SUBU32(d) "v_sub_u32_e32 " d ", %16, " d "\n\t"
+#define OP_MINU32(d) "v_min_u32_e32 " d ", %16, " d "\n\t"
+#define OP_FMAMIX(d) "v_fma_mix_f32 " d ", " d ", %16, %17\n\t"
+#define OP_DOT2F16(d) "v_dot2c_f32_f16 " d ", %16, %17\n\t"
+#define OP_MIN3U32(d) "v_min3_u32 " d ", " d ", %16, %17\n\t"
+#define OP_ANDOR(d) "v_and_or_b32 " d ", " d ", %16, %17\n\t"
+#define OP_XAD(d) "v_xad_u32 " d ", " d ", %16, %17\n\t"
+
+#define KERNEL(NAME, OPM, ...)                                                           \
+    __global__ __launch_bounds__(256) void NAME(unsigned long long *out, float *sink, int iters)  \
+    {                                                                                     \
+        float a[16];                                                                      \
+        for (int i = 0; i < 16; i++) a[i] = (float)(threadIdx.x + i);                     \
+        float s0 = 3.0f, s1 = 5.0f;                                                       \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                             \
+        for (int it = 0; it < iters; it++) {                                              \
+            asm volatile(REP16(OPM) REP16(OPM) REP16(OPM) REP16(OPM)                      \
+                         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]),   \
+                           "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]),           \
+                           "+v"(a[13]), "+v"(a[14]), "+v"(a[15])                          \
+                         : "v"(s0), "v"(s1)                                               \
+                         : __VA_ARGS__);                                                       \
+        }                                                                                 \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                             \
+        float acc = 0;                                                                    \
+        for (int i = 0; i < 16; i++) acc += a[i];                                         \
+        if (acc == 12345.678f) sink[0] = acc;                                             \
+        if ((threadIdx.x & 63) == 0) out[(blockIdx.x * 256 + threadIdx.x) >> 6] = t1 - t0; \
+    }
+
+KERNEL(k_fma, OP_FMA, "memory")
+KERNEL(k_sub32, OP_SUB32, "memory")
+KERNEL(k_sub64abs, OP_SUB64ABS, "memory")
+KERNEL(k_mulclamp, OP_MULCLAMP, "memory")
+KERNEL(k_addf, OP_ADDF, "memory")
+KERNEL(k_xor, OP_XOR, "memory")
+KERNEL(k_pkminu16, OP_PKMINU16, "memory")
+KERNEL(k_pkaddu16, OP_PKADDU16, "memory")
+KERNEL(k_addu32, OP_ADDU32, "memory")
+KERNEL(k_cmpeq, OP_CMPEQ, "s20", "s21", "memory")
+KERNEL(k_min3f, OP_MIN3F, "memory")
+KERNEL(k_sadu32, OP_SADU32, "memory")
+KERNEL(k_madu24, OP_MADU24, "memory")
+KERNEL(k_pkfmaf16, OP_PKFMAF16, "memory")
+KERNEL(k_pkmulf16, OP_PKMULF16, "memory")
+KERNEL(k_med3f, OP_MED3F, "memory")
+KERNEL(k_pkmaxi16, OP_PKMAXI16, "memory")
+KERNEL(k_subu32, OP_SUBU32, "memory")
+KERNEL(k_minu32, OP_MINU32, "memory")
+KERNEL(k_fmamix, OP_FMAMIX, "memory")
+KERNEL(k_dot2f16, OP_DOT2F16, "memory")
+KERNEL(k_min3u32, OP_MIN3U32, "memory")
+KERNEL(k_andor, OP_ANDOR, "memory")
+KERNEL(k_xad, OP_XAD, "memory")
+
+// packed f32 needs 64-bit register pairs
+__global__ __launch_bounds__(256) void k_pkaddf32(unsigned long long *out, float *sink, int iters)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a[8];
+    for (int i = 0; i < 8; i++) a[i] = f2{(float)threadIdx.x, (float)i};
+    f2 s = f2{3.0f, 5.0f};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+#define P(i) "v_pk_add_f32 %" #i ", %" #i ", %8\n\t"
+#define P8 P(0) P(1) P(2) P(3) P(4) P(5) P(6) P(7)
+        asm volatile(P8 P8 P8 P8 P8 P8 P8 P8
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(s)
+                     : "memory");
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float acc = 0;
+    for (int i = 0; i < 8; i++) acc += a[i].x + a[i].y;
+    if (acc == 12345.678f) sink[0] = acc;
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * 256 + threadIdx.x) >> 6] = t1 - t0;
+}
+
+__global__ __launch_bounds__(256) void k_pkfmaf32(unsigned long long *out, float *sink, int iters)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a[8];
+    for (int i = 0; i < 8; i++) a[i] = f2{(float)threadIdx.x, (float)i};
+    f2 s = f2{1.0f, 1.0f};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+#define Q(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %8\n\t"
+#define Q8 Q(0) Q(1) Q(2) Q(3) Q(4) Q(5) Q(6) Q(7)
+        asm volatile(Q8 Q8 Q8 Q8 Q8 Q8 Q8 Q8
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(s)
+                     : "memory");
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float acc = 0;
+    for (int i = 0; i < 8; i++) acc += a[i].x + a[i].y;
+    if (acc == 12345.678f) sink[0] = acc;
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * 256 + threadIdx.x) >> 6] = t1 - t0;
+}
+
+typedef void (*kern_t)(unsigned long long *, float *, int);
+
+struct Entry { const char *name; kern_t fn; };
+
+int main(int argc, char **argv)
+{
+    const int iters = argc > 1 ? atoi(argv[1]) : 20000;
+    Entry tab[] = {
+        {"v_fma_f32", k_fma}, {"v_sub_f32_e32", k_sub32}, {"v_sub_f32_e64|abs|", k_sub64abs},
+        {"v_mul_f32_e64|abs|clamp", k_mulclamp}, {"v_add_f32_e32", k_addf}, {"v_min3_f32", k_min3f},
+        {"v_med3_f32", k_med3f}, {"v_pk_add_f32", k_pkaddf32}, {"v_pk_fma_f32", k_pkfmaf32},
+        {"v_pk_fma_f16", k_pkfmaf16}, {"v_pk_mul_f16", k_pkmulf16}, {"v_fma_mix_f32", k_fmamix},
+        {"v_dot2c_f32_f16", k_dot2f16},
+        {"v_xor_b32", k_xor}, {"v_add_u32", k_addu32}, {"v_sub_u32", k_subu32}, {"v_min_u32", k_minu32},
+        {"v_min3_u32", k_min3u32}, {"v_and_or_b32", k_andor}, {"v_xad_u32", k_xad},
+        {"v_pk_min_u16", k_pkminu16}, {"v_pk_add_u16", k_pkaddu16}, {"v_pk_max_i16", k_pkmaxi16},
+        {"v_sad_u32", k_sadu32}, {"v_mad_u32_u24", k_madu24}, {"v_cmp_eq_u32_e64(sdst)", k_cmpeq},
+    };
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("device %s, %d CUs, iters %d (x64 instructions per wave per iteration; pk_f32 kernels also 64)\n",
+           prop.gcnArchName, cus, iters);
+    unsigned long long *out;
+    float *sink;
+    CHECK(hipMalloc(&out, sizeof(unsigned long long) * cus * 8 * 4));
+    CHECK(hipMalloc(&sink, 64));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    printf("%-28s %5s %12s %12s %10s\n", "instruction", "w/SIMD", "cyc/instr/SIMD", "ns/instr/SIMD", "clock GHz");
+    for (const Entry &en : tab) {
+        for (int wps : {1, 2, 4}) {
+            const int blocks = cus * wps; // 256-thread blocks: one wave per SIMD each
+            hipLaunchKernelGGL(en.fn, dim3(blocks), dim3(256), 0, 0, out, sink, iters / 10); // warm-up
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(en.fn, dim3(blocks), dim3(256), 0, 0, out, sink, iters);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipDeviceSynchronize());
+            float ms = 0;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            std::vector<unsigned long long> h(blocks * 4);
+            CHECK(hipMemcpy(h.data(), out, sizeof(unsigned long long) * blocks * 4, hipMemcpyDeviceToHost));
+            double avg = 0;
+            for (auto v : h) avg += (double)v;
+            avg /= h.size();
+            const double n_instr = (double)iters * 64.0;
+            const double cyc = avg / (n_instr * wps);          // per instruction per SIMD (wps waves share a SIMD)
+            const double ns = ms * 1e6 / (n_instr * wps);
+            printf("%-28s %5d %12.2f %12.3f %10.2f\n", en.name, wps, cyc, ns, cyc / ns);
+        }
+    }
+    return 0;
+}
