@@ -13,12 +13,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libls_amd.so")
-SOURCES = ["ls_api.hip", "nq_kernels.hip", "sched_kernels.hip"]
+SOURCES = ["ls_api.hip", "nq_kernels.hip", "sched_kernels.hip", "ls_solver.hip"]
 ARCH = "gfx950"
 
 
 def _deps():
-    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    out = []
+    for d, _, files in os.walk(CSRC):
+        out += [os.path.join(d, f) for f in files]
     out.append(os.path.join(os.path.dirname(HERE), "include", "ls_amd.h"))
     out.append(os.path.abspath(__file__))
     return out

@@ -1,0 +1,233 @@
+// host/plugins.hpp — the two problem plug-ins of the reference as policies for
+// host/local_search.hpp.  Move proposal, perturbation and initial solutions are host code
+// (restated from examples/nqueens/src/lib.rs and examples/employee-scheduling/src/lib.rs);
+// every score and every neighbourhood goes through the C ABI to the HIP kernels.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../../include/ls_amd.h"
+#include "local_search.hpp"
+
+namespace lshost {
+
+inline void check_rc(ls_ctx *ctx, int rc, const char *what)
+{
+    if (rc != LS_OK) throw std::runtime_error(std::string(what) + ": " + ls_last_error(ctx));
+}
+
+// =================================================================== N-queens
+struct NQueensProblem {
+    using Solution = std::vector<int64_t>; // rows[col] = row, Integer = i64 (lib.rs:13-21)
+    using Score = int64_t;                 // NQueensScore (lib.rs:63-71)
+    using SS = ScoredSolution<NQueensProblem>;
+    static bool is_best(Score s) { return s == 0; }
+
+    ls_ctx *ctx;
+    size_t board_size;
+    // statistics
+    uint64_t neighbours_scored = 0, gpu_evals = 0;
+
+    NQueensProblem(ls_ctx *c, size_t n) : ctx(c), board_size(n) {}
+
+    std::vector<int32_t> pack(const Solution &s) const
+    {
+        std::vector<int32_t> r(s.size());
+        for (size_t i = 0; i < s.size(); i++) r[i] = (int32_t)s[i];
+        return r;
+    }
+
+    // NQueensInitialSolutionGenerator (lib.rs:152-161): identity permutation, shuffled
+    template <class R> Solution generate_initial_solution(R &rng) const
+    {
+        Solution rows(board_size);
+        for (size_t i = 0; i < board_size; i++) rows[i] = (int64_t)i;
+        shuffle(rng, rows);
+        return rows;
+    }
+
+    // get_col_scores (lib.rs:74-87) on the GPU; also returns the sum (lib.rs:130-139)
+    std::vector<int64_t> col_scores(const Solution &s, int64_t *total) const
+    {
+        const std::vector<int32_t> rows = pack(s);
+        std::vector<int64_t> cs(s.size());
+        int64_t tot = 0;
+        check_rc(ctx, ls_nqueens_col_scores(ctx, 1, (int32_t)s.size(), rows.data(), cs.data(), &tot), "ls_nqueens_col_scores");
+        if (total) *total = tot;
+        return cs;
+    }
+    Score score(const Solution &s) const
+    {
+        int64_t tot = 0;
+        (void)col_scores(s, &tot);
+        return tot;
+    }
+
+    // NQueensMoveProposer::iter_local_moves, the part before the iterator (lib.rs:182-205):
+    // columns with conflicts, Efraimidis-Spirakis weighted sample of `amount`, then a random
+    // number of them in choose_multiple order.  Empty result <=> `random_cols == None`.
+    template <class R> std::vector<int32_t> propose_columns(const Solution &start, R &rng) const
+    {
+        const std::vector<int64_t> cs = col_scores(start, nullptr);
+        std::vector<uint32_t> conflict_cols;
+        std::vector<double> weights;
+        for (size_t c = 0; c < cs.size(); c++)
+            if (cs[c] != 0) {
+                conflict_cols.push_back((uint32_t)c);
+                weights.push_back((double)cs[c] + 1e-4);
+            }
+        if (conflict_cols.empty()) return {};
+        size_t amount = start.size() / 20;
+        if (amount < 1) amount = 1;
+        if (amount > conflict_cols.size()) amount = conflict_cols.size();
+        const std::vector<uint32_t> picked = index_sample_weighted(rng, weights, (uint32_t)amount);
+        std::vector<uint32_t> cols;
+        for (uint32_t i : picked) cols.push_back(conflict_cols[i]);
+        const uint64_t num_cols = gen_range_u64_incl(rng, 1, cols.size());
+        const std::vector<uint32_t> order = index_sample(rng, (uint32_t)cols.size(), (uint32_t)num_cols);
+        std::vector<int32_t> out;
+        for (uint32_t i : order) out.push_back((int32_t)cols[i]);
+        return out;
+    }
+
+    // local_search.rs:315-325 for this plug-in: one GPU launch
+    template <class R> bool best_of_neighbourhood(const SS &current, R &rng, size_t window, SS &out)
+    {
+        const std::vector<int32_t> cols = propose_columns(current.solution, rng);
+        if (cols.empty()) return false;
+        const std::vector<int32_t> rows = pack(current.solution);
+        ls_nq_result res;
+        check_rc(ctx, ls_nqueens_eval(ctx, (int32_t)rows.size(), rows.data(), current.score, cols.data(),
+                                      (int32_t)cols.size(), (int64_t)window, &res, nullptr), "ls_nqueens_eval");
+        gpu_evals++;
+        neighbours_scored += (uint64_t)res.n_scored;
+        if (res.best_index < 0) return false;
+        out.solution = current.solution;
+        out.solution[(size_t)res.best_col] = res.best_value; // MoveIterator, lib.rs:226-228
+        out.score = res.best_score;
+        return true;
+    }
+
+    // NQueensPerturbation (lib.rs:285-320), default strategy table (:274-283)
+    template <class R> Solution propose_new_starting_solution(const SS &current, bool current_is_in_best_set, R &rng) const
+    {
+        const size_t strategy = choose_weighted_index(rng, {100, 10}, /*wide=*/true); // 0 ChangeSubset, 1 DoNothing
+        Solution next = current.solution;
+        if (strategy == 1) return next;
+        const uint64_t n = current.solution.size();
+        std::vector<uint64_t> rows(n);
+        for (uint64_t i = 0; i < n; i++) rows[i] = i;
+        shuffle(rng, rows);
+        auto clamp1 = [&](uint64_t x) { return x < 1 ? (uint64_t)1 : (x > n ? n : x); };
+        const uint64_t k = current_is_in_best_set ? gen_range_u64_incl(rng, 1, clamp1(n / 20))
+                                                  : gen_range_u64_incl(rng, 1, clamp1(n / 2));
+        for (uint64_t i = 0; i < k; i++) next[(size_t)rows[i]] = (int64_t)gen_range_u64(rng, 0, n);
+        return next;
+    }
+};
+
+// ========================================================= employee scheduling
+struct SchedProblem {
+    using Solution = std::vector<int32_t>;          // date_to_employee as employee indices (lib.rs:140)
+    using Score = std::pair<int64_t, int64_t>;      // ScheduleScore {hard, soft} (lib.rs:239-243)
+    using SS = ScoredSolution<SchedProblem>;
+    static bool is_best(const Score &s) { return s.first == 0 && s.second == 0; }
+
+    ls_ctx *ctx;
+    int32_t n_days_scored, n_days_stored, n_employees;
+    uint64_t neighbours_scored = 0, gpu_evals = 0;
+    // ScheduleRandomMoveProposer's stream (lib.rs:444-490).  The iterator owns rng.clone()
+    // (:488) and nothing else ever advances LocalSearch's rng, so every LS iteration replays
+    // the SAME draw stream; it is generated once, lazily, from a clone.
+    std::vector<ls_sched_move> stream;
+    ChaCha20Rng stream_rng;
+    bool stream_started = false;
+
+    SchedProblem(ls_ctx *c, int32_t d, int32_t s, int32_t e) : ctx(c), n_days_scored(d), n_days_stored(s), n_employees(e) {}
+
+    // ScheduleInitialSolutionGenerator (lib.rs:400-420): pushes D + 1 entries
+    template <class R> Solution generate_initial_solution(R &rng) const
+    {
+        Solution s;
+        for (int32_t i = 0; i < n_days_stored; i++) s.push_back((int32_t)choose_index(rng, (size_t)n_employees));
+        return s;
+    }
+
+    Score score(const Solution &s) const
+    {
+        int64_t h = 0, so = 0;
+        check_rc(ctx, ls_sched_score(ctx, 1, s.data(), &h, &so, nullptr), "ls_sched_score");
+        return Score(h, so);
+    }
+
+    void extend_stream(const ChaCha20Rng &ls_rng, size_t want)
+    {
+        if (!stream_started) { stream_rng = ls_rng; stream_started = true; }
+        while (stream.size() < want) {
+            const size_t t = choose_weighted_index(stream_rng, {1, 4}, /*wide=*/true); // ChangeDay:1, SwapDays:4 (:435)
+            ls_sched_move m;
+            if (t == 0) {
+                m.type = 0;
+                m.a = (int32_t)choose_index(stream_rng, (size_t)n_days_scored); // days_to_employees.choose (:467)
+                m.b = (int32_t)choose_index(stream_rng, (size_t)n_employees);   // employees.choose (:468)
+            } else {
+                const std::vector<uint32_t> xs = index_sample(stream_rng, (uint32_t)n_days_scored, 2); // :473
+                m.type = 1;
+                m.a = (int32_t)xs[0];
+                m.b = (int32_t)xs[1];
+            }
+            stream.push_back(m);
+        }
+    }
+
+    bool best_of_neighbourhood(const SS &current, ChaCha20Rng &rng, size_t window, SS &out)
+    {
+        if (window == 0) return false;
+        size_t want = window + window / 4 + 16;
+        for (;;) {
+            extend_stream(rng, want);
+            ls_sched_result res;
+            check_rc(ctx, ls_sched_eval(ctx, current.solution.data(), stream.data(), (int64_t)want, (int64_t)window, &res,
+                                        nullptr, nullptr), "ls_sched_eval");
+            gpu_evals++;
+            if ((size_t)res.n_scored == window) {
+                neighbours_scored += (uint64_t)res.n_scored;
+                const ls_sched_move m = stream[(size_t)res.best_index];
+                out.solution = current.solution;
+                if (m.type == 0) out.solution[(size_t)m.a] = m.b;
+                else {
+                    out.solution[(size_t)m.a] = current.solution[(size_t)m.b];
+                    out.solution[(size_t)m.b] = current.solution[(size_t)m.a];
+                }
+                out.score = Score(res.best_hard, res.best_soft);
+                return true;
+            }
+            if (want > 64 * window + (1u << 16))
+                throw std::runtime_error("the random move stream cannot fill the window (the reference would not terminate)");
+            want *= 2;
+        }
+    }
+
+    // SchedulePerturbation (lib.rs:582-612), default table (:572-579): DoNothing 10, ChangeDaysSubsetRandomly 100
+    template <class R> Solution propose_new_starting_solution(const SS &current, bool current_is_in_best_set, R &rng) const
+    {
+        const size_t strategy = choose_weighted_index(rng, {10, 100}, /*wide=*/true);
+        Solution next = current.solution;
+        if (strategy == 0) return next;
+        const uint64_t total_days = next.size();
+        auto clamp1 = [&](uint64_t x) { return x < 1 ? (uint64_t)1 : (x > total_days ? total_days : x); };
+        const uint64_t k = current_is_in_best_set ? gen_range_u64_incl(rng, 1, clamp1(total_days / 20))
+                                                  : gen_range_u64_incl(rng, 1, clamp1(total_days / 2));
+        std::vector<uint64_t> idx(total_days);
+        for (uint64_t i = 0; i < total_days; i++) idx[i] = i;
+        shuffle(rng, idx);
+        for (uint64_t i = 0; i < k; i++) next[(size_t)idx[i]] = (int32_t)choose_index(rng, (size_t)n_employees);
+        return next;
+    }
+};
+
+} // namespace lshost

@@ -1,0 +1,336 @@
+// host/rng.hpp — the random-number stack the reference's drivers sit on, restated for the
+// host side of the boundary (move proposal, perturbation, acceptance stay on the host by
+// design).  None of these crates is in /root/reference (Cargo.lock pins rand 0.8.5,
+// rand_chacha 0.3.1, rand_core 0.6.3, blake2 0.10.4); the algorithms below follow their
+// published sources as recorded in SURVEY.md Appendix A.  Stream equality with the Rust
+// binaries is UNVERIFIED here (no Rust toolchain); Blake2b and the ChaCha20 block function
+// are checked against RFC 7693 / RFC 7539 vectors in the tests.
+//
+// Call sites in the reference: examples/nqueens/src/main.rs:28-39,66 (seed hashing, two
+// identically seeded ChaCha20Rng), nqueens lib.rs:158,198,202-203,297,303-311,
+// employee-scheduling lib.rs:408,461,467-468,473,594,601-607,
+// iterated_local_search.rs:61,70, local_search.rs:226.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+namespace lshost {
+
+// ------------------------------------------------------------------ Blake2b-256
+// hash_str (nqueens main.rs:28-33): Blake2b with a 32-byte digest, no key.  RFC 7693.
+inline void blake2b_256(const void *data, size_t len, uint8_t out[32])
+{
+    static const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
+                                   0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL,
+                                   0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+    static const uint8_t SIGMA[12][16] = {
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+        {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+        {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+        {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+        {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+    auto rotr = [](uint64_t x, int n) { return (x >> n) | (x << (64 - n)); };
+    uint64_t h[8];
+    for (int i = 0; i < 8; i++) h[i] = IV[i];
+    h[0] ^= 0x01010000ULL ^ 32ULL; // digest length 32, no key, fanout = depth = 1
+    const uint8_t *p = static_cast<const uint8_t *>(data);
+    uint64_t t = 0;
+    auto compress = [&](const uint8_t block[128], bool last) {
+        uint64_t m[16], v[16];
+        for (int i = 0; i < 16; i++) {
+            uint64_t w = 0;
+            for (int b = 7; b >= 0; b--) w = (w << 8) | block[8 * i + b];
+            m[i] = w;
+        }
+        for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = IV[i]; }
+        v[12] ^= t; // low word of the 128-bit counter (inputs here are far below 2^64 bytes)
+        if (last) v[14] = ~v[14];
+        auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+            v[a] = v[a] + v[b] + x; v[d] = rotr(v[d] ^ v[a], 32);
+            v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 24);
+            v[a] = v[a] + v[b] + y; v[d] = rotr(v[d] ^ v[a], 16);
+            v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 63);
+        };
+        for (int r = 0; r < 12; r++) {
+            const uint8_t *s = SIGMA[r];
+            G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+            G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+            G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+            G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+        }
+        for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+    };
+    uint8_t block[128];
+    size_t rem = len;
+    while (rem > 128) {
+        t += 128;
+        compress(p, false);
+        p += 128; rem -= 128;
+    }
+    std::memset(block, 0, sizeof block);
+    std::memcpy(block, p, rem);
+    t += rem;
+    compress(block, true);
+    for (int i = 0; i < 4; i++)
+        for (int b = 0; b < 8; b++) out[8 * i + b] = (uint8_t)(h[i] >> (8 * b));
+}
+
+// -------------------------------------------------------------------- ChaCha20
+// One 64-byte block of the original (djb) layout rand_chacha uses: 64-bit block counter in
+// words 12-13, 64-bit stream id in words 14-15.
+inline void chacha20_block(const uint32_t key[8], uint32_t w12, uint32_t w13, uint32_t w14, uint32_t w15,
+                           uint32_t out[16])
+{
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                      key[4], key[5], key[6], key[7], w12, w13, w14, w15};
+    uint32_t x[16];
+    std::memcpy(x, s, sizeof x);
+    auto rotl = [](uint32_t v, int n) { return (v << n) | (v >> (32 - n)); };
+    auto QR = [&](int a, int b, int c, int d) {
+        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);
+        x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
+        x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+    };
+    for (int r = 0; r < 10; r++) {
+        QR(0, 4, 8, 12); QR(1, 5, 9, 13); QR(2, 6, 10, 14); QR(3, 7, 11, 15);
+        QR(0, 5, 10, 15); QR(1, 6, 11, 12); QR(2, 7, 8, 13); QR(3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+
+// rand_chacha::ChaCha20Rng over rand_core::block::BlockRng: 4 blocks (64 words) per refill.
+class ChaCha20Rng {
+public:
+    ChaCha20Rng() { std::memset(key_, 0, sizeof key_); }
+    // SeedableRng::from_seed([u8; 32]): key words little-endian, counter = stream = 0
+    explicit ChaCha20Rng(const uint8_t seed[32])
+    {
+        for (int i = 0; i < 8; i++)
+            key_[i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) | ((uint32_t)seed[4 * i + 2] << 16) |
+                      ((uint32_t)seed[4 * i + 3] << 24);
+    }
+    static ChaCha20Rng from_seed_string(const std::string &s)
+    {
+        uint8_t d[32];
+        blake2b_256(s.data(), s.size(), d);
+        return ChaCha20Rng(d);
+    }
+    uint32_t next_u32()
+    {
+        if (index_ >= 64) generate_and_set(0);
+        return buf_[index_++];
+    }
+    // BlockRng::next_u64: two consecutive words, low first; straddles a refill when one word is left
+    uint64_t next_u64()
+    {
+        const size_t len = 64;
+        if (index_ < len - 1) {
+            const uint64_t lo = buf_[index_], hi = buf_[index_ + 1];
+            index_ += 2;
+            return (hi << 32) | lo;
+        } else if (index_ >= len) {
+            generate_and_set(2);
+            return ((uint64_t)buf_[1] << 32) | buf_[0];
+        } else {
+            const uint64_t x = buf_[len - 1];
+            generate_and_set(1);
+            const uint64_t y = buf_[0];
+            return (y << 32) | x;
+        }
+    }
+    // Standard f64: 53 random bits scaled into [0, 1)
+    double gen_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+    uint64_t words_drawn() const { return counter_ * 16 - (64 - (index_ > 64 ? 64 : index_)); }
+
+private:
+    void generate_and_set(size_t idx)
+    {
+        for (int b = 0; b < 4; b++) {
+            chacha20_block(key_, (uint32_t)counter_, (uint32_t)(counter_ >> 32), 0, 0, buf_ + 16 * b);
+            counter_++;
+        }
+        index_ = idx;
+    }
+    uint32_t key_[8];
+    uint64_t counter_ = 0;
+    uint32_t buf_[64];
+    size_t index_ = 64;
+};
+
+// ----------------------------------------------------------- rand 0.8.5 sampling
+// UniformInt::sample_single_inclusive, 32-bit and 64-bit draws (widening multiply + zone).
+template <class R> inline uint32_t gen_range_u32_incl(R &rng, uint32_t low, uint32_t high)
+{
+    const uint32_t range = high - low + 1;
+    if (range == 0) return rng.next_u32();
+    const uint32_t zone = (range << __builtin_clz(range)) - 1;
+    for (;;) {
+        const uint64_t m = (uint64_t)rng.next_u32() * range;
+        if ((uint32_t)m <= zone) return low + (uint32_t)(m >> 32);
+    }
+}
+template <class R> inline uint64_t gen_range_u64_incl(R &rng, uint64_t low, uint64_t high)
+{
+    const uint64_t range = high - low + 1;
+    if (range == 0) return rng.next_u64();
+    const uint64_t zone = (range << __builtin_clzll(range)) - 1;
+    for (;;) {
+        const unsigned __int128 m = (unsigned __int128)rng.next_u64() * range;
+        if ((uint64_t)m <= zone) return low + (uint64_t)(m >> 64);
+    }
+}
+// rng.gen_range(low..high) on u64 / usize / i64 (64-bit targets)
+template <class R> inline uint64_t gen_range_u64(R &rng, uint64_t low, uint64_t high) { return gen_range_u64_incl(rng, low, high - 1); }
+
+// Uniform::new(0, high).sample for the WeightedIndex draw: a DIFFERENT zone than sample_single
+template <class R> inline uint64_t uniform_u64_below(R &rng, uint64_t high)
+{
+    const uint64_t range = high; // new_inclusive(0, high - 1)
+    const uint64_t ints_to_reject = (UINT64_MAX - range + 1) % range;
+    const uint64_t zone = UINT64_MAX - ints_to_reject;
+    for (;;) {
+        const unsigned __int128 m = (unsigned __int128)rng.next_u64() * range;
+        if ((uint64_t)m <= zone) return (uint64_t)(m >> 64);
+    }
+}
+template <class R> inline uint32_t uniform_u32_below(R &rng, uint32_t high)
+{
+    const uint32_t range = high;
+    const uint32_t ints_to_reject = (UINT32_MAX - range + 1) % range;
+    const uint32_t zone = UINT32_MAX - ints_to_reject;
+    for (;;) {
+        const uint64_t m = (uint64_t)rng.next_u32() * range;
+        if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
+    }
+}
+
+// seq::gen_index: u32 draws whenever the bound fits
+template <class R> inline size_t gen_index(R &rng, size_t ubound)
+{
+    if (ubound <= (size_t)UINT32_MAX) return gen_range_u32_incl(rng, 0, (uint32_t)ubound - 1);
+    return (size_t)gen_range_u64_incl(rng, 0, (uint64_t)ubound - 1);
+}
+
+// SliceRandom::shuffle
+template <class R, class T> inline void shuffle(R &rng, std::vector<T> &v)
+{
+    for (size_t i = v.size(); i-- > 1;) std::swap(v[i], v[gen_index(rng, i + 1)]);
+}
+
+// SliceRandom::choose -> index
+template <class R> inline size_t choose_index(R &rng, size_t len)
+{
+    if (len == 0) throw std::runtime_error("choose on an empty slice (the reference unwraps None)");
+    return gen_index(rng, len);
+}
+
+// SliceRandom::choose_weighted with integer weights: WeightedIndex::new + sample.
+// `wide` selects the weight type: u64 (strategy tables) or i32 (acceptance tuple literals).
+template <class R> inline size_t choose_weighted_index(R &rng, const std::vector<uint64_t> &weights, bool wide)
+{
+    if (weights.empty()) throw std::runtime_error("choose_weighted: no items");
+    uint64_t total = 0;
+    std::vector<uint64_t> cumulative;
+    for (size_t i = 0; i < weights.size(); i++) {
+        if (i + 1 < weights.size()) cumulative.push_back(total + weights[i]);
+        total += weights[i];
+    }
+    if (total == 0) throw std::runtime_error("choose_weighted: all weights zero");
+    const uint64_t chosen = wide ? uniform_u64_below(rng, total) : uniform_u32_below(rng, (uint32_t)total);
+    // partition_point(|w| w <= chosen)
+    size_t idx = 0;
+    while (idx < cumulative.size() && cumulative[idx] <= chosen) idx++;
+    return idx;
+}
+
+// seq::index::sample(rng, length, amount) — indices in the order the reference yields them
+template <class R> inline std::vector<uint32_t> index_sample(R &rng, uint32_t length, uint32_t amount)
+{
+    if (amount > length) throw std::runtime_error("`amount` of samples must be less than or equal to `length`");
+    auto floyd = [&]() {
+        const bool floyd_shuffle = amount < 50;
+        std::vector<uint32_t> idx;
+        idx.reserve(amount);
+        for (uint32_t j = length - amount; j < length; j++) {
+            const uint32_t t = gen_range_u32_incl(rng, 0, j);
+            if (floyd_shuffle) {
+                auto pos = std::find(idx.begin(), idx.end(), t);
+                if (pos != idx.end()) { idx.insert(pos, j); continue; }
+            } else if (std::find(idx.begin(), idx.end(), t) != idx.end()) {
+                idx.push_back(j);
+                continue;
+            }
+            idx.push_back(t);
+        }
+        if (!floyd_shuffle)
+            for (uint32_t i = amount; i-- > 1;) std::swap(idx[i], idx[gen_range_u32_incl(rng, 0, i)]);
+        return idx;
+    };
+    auto inplace = [&]() {
+        std::vector<uint32_t> idx(length);
+        for (uint32_t i = 0; i < length; i++) idx[i] = i;
+        for (uint32_t i = 0; i < amount; i++) std::swap(idx[i], idx[gen_range_u32_incl(rng, i, length - 1)]);
+        idx.resize(amount);
+        return idx;
+    };
+    auto rejection = [&]() {
+        std::unordered_set<uint32_t> cache;
+        std::vector<uint32_t> idx;
+        idx.reserve(amount);
+        for (uint32_t i = 0; i < amount; i++) {
+            uint32_t pos = uniform_u32_below(rng, length);
+            while (!cache.insert(pos).second) pos = uniform_u32_below(rng, length);
+            idx.push_back(pos);
+        }
+        return idx;
+    };
+    const int j = length < 500000 ? 0 : 1;
+    if (amount < 163) {
+        static const float C[2][2] = {{1.6f, 8.0f / 45.0f}, {10.0f, 70.0f / 9.0f}};
+        const float amount_fp = (float)amount;
+        const float m4 = C[0][j] * amount_fp;
+        if (amount > 11 && (float)length < (C[1][j] + m4) * amount_fp) return inplace();
+        return floyd();
+    }
+    static const float C2[2] = {270.0f, 330.0f / 9.0f};
+    if ((float)length < C2[j] * (float)amount) return inplace();
+    return rejection();
+}
+
+// seq::index::sample_weighted -> Efraimidis-Spirakis with a binary max-heap (non-nightly path):
+// key_i = u_i^(1/w_i), the `amount` largest keys in descending order.
+template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, const std::vector<double> &weights, uint32_t amount)
+{
+    const uint32_t length = (uint32_t)weights.size();
+    if (amount == 0) return {};
+    if (amount > length) throw std::runtime_error("`amount` of samples must be less than or equal to `length`");
+    struct El { double key; uint32_t index; };
+    std::vector<El> heap;
+    heap.reserve(length);
+    auto less = [](const El &a, const El &b) { return a.key < b.key; }; // max-heap on key
+    for (uint32_t i = 0; i < length; i++) {
+        if (!(weights[i] >= 0.0)) throw std::runtime_error("invalid weight");
+        const double key = std::pow(rng.gen_f64(), 1.0 / weights[i]);
+        heap.push_back(El{key, i});
+        std::push_heap(heap.begin(), heap.end(), less);
+    }
+    std::vector<uint32_t> out;
+    out.reserve(amount);
+    while (out.size() < amount) {
+        std::pop_heap(heap.begin(), heap.end(), less);
+        out.push_back(heap.back().index);
+        heap.pop_back();
+    }
+    return out;
+}
+
+} // namespace lshost

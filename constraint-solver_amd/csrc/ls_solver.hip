@@ -1,0 +1,269 @@
+// ls_solver.hip — C entry points for the whole-solver view (include/ls_amd.h, "whole solver"):
+// the host driver of csrc/host/ wired to the GPU path of this library.  Plain host C++; it is a
+// .hip file only so that the one hipcc invocation style builds everything.
+#include <memory>
+#include <new>
+
+#include "host/plugins.hpp"
+#include "ls_common.hpp"
+
+using namespace lshost;
+
+struct ls_solver {
+    ls_ctx *ctx = nullptr;
+    int kind = 0; // 0 N-queens, 1 scheduling
+    std::unique_ptr<NQueensProblem> nq;
+    std::unique_ptr<IteratedLocalSearch<NQueensProblem>> nq_ils;
+    std::unique_ptr<SchedProblem> sc;
+    std::unique_ptr<IteratedLocalSearch<SchedProblem>> sc_ils;
+};
+
+namespace {
+
+int check_params(ls_ctx *ctx, const ls_solver_params *p)
+{
+    if (!p) return lsamd::set_err(ctx, LS_ERR_INVALID, "params is NULL");
+    if (p->all_solution_iteration_expiry == 0)
+        return lsamd::set_err(ctx, LS_ERR_UNSUPPORTED,
+                              "all_solution_iteration_expiry == 0 makes the reference's tabu set grow without bound; "
+                              "the GPU path implements tabu == {current} (every configuration the reference ships)");
+    if (p->best_solutions_capacity == 0)
+        return lsamd::set_err(ctx, LS_ERR_INVALID, "best_solutions_capacity must be >= 1 (the reference would panic)");
+    return LS_OK;
+}
+
+template <class F> int guarded(ls_ctx *ctx, F &&f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return lsamd::set_err(ctx, LS_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return lsamd::set_err(ctx, LS_ERR_STATE, "%s", e.what());
+    }
+}
+
+template <class V> int copy_solution(const V &v, int64_t *solution, int32_t cap, int32_t *len)
+{
+    if (len) *len = (int32_t)v.size();
+    if (solution) {
+        if ((size_t)cap < v.size()) return LS_ERR_INVALID;
+        for (size_t i = 0; i < v.size(); i++) solution[i] = (int64_t)v[i];
+    }
+    return LS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ls_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, const char *seed, const ls_solver_params *params,
+                             ls_solver **out)
+{
+    if (!ctx || !out || !seed) return LS_ERR_INVALID;
+    *out = nullptr;
+    int rc = check_params(ctx, params);
+    if (rc != LS_OK) return rc;
+    if (board_size < 1 || board_size > LS_NQ_MAX_N)
+        return lsamd::set_err(ctx, LS_ERR_UNSUPPORTED, "board_size %llu outside [1, %d]", (unsigned long long)board_size,
+                              LS_NQ_MAX_N);
+    return guarded(ctx, [&]() {
+        std::unique_ptr<ls_solver> s(new ls_solver());
+        s->ctx = ctx;
+        s->kind = 0;
+        s->nq.reset(new NQueensProblem(ctx, (size_t)board_size));
+        // examples/nqueens/src/main.rs:36-87: one seed, two identically seeded generators
+        const ChaCha20Rng solver_rng = ChaCha20Rng::from_seed_string(seed);
+        const ChaCha20Rng ils_rng = ChaCha20Rng::from_seed_string(seed);
+        LocalSearch<NQueensProblem> ls(s->nq.get(), params->local_search_max_iterations, (size_t)params->window_size,
+                                       (size_t)params->best_solutions_capacity, (size_t)params->all_solutions_capacity,
+                                       params->all_solution_iteration_expiry, solver_rng);
+        History<NQueensProblem> history((size_t)params->best_solutions_capacity, (size_t)params->all_solutions_capacity,
+                                        params->all_solution_iteration_expiry);
+        s->nq_ils.reset(new IteratedLocalSearch<NQueensProblem>(s->nq.get(), std::move(ls), std::move(history),
+                                                                params->iterated_local_search_max_iterations,
+                                                                params->max_allow_no_improvement_for, ils_rng));
+        *out = s.release();
+        return LS_OK;
+    });
+}
+
+int ls_solver_create_sched(ls_ctx *ctx, int32_t n_days_scored, int32_t start_weekday, int32_t n_employees,
+                           const uint64_t *holiday_bits, const char *seed, const ls_solver_params *params,
+                           ls_solver **out)
+{
+    if (!ctx || !out || !seed) return LS_ERR_INVALID;
+    *out = nullptr;
+    int rc = check_params(ctx, params);
+    if (rc != LS_OK) return rc;
+    rc = ls_sched_instance_upload(ctx, n_days_scored, n_days_scored + 1, start_weekday, n_employees, holiday_bits);
+    if (rc != LS_OK) return rc;
+    return guarded(ctx, [&]() {
+        std::unique_ptr<ls_solver> s(new ls_solver());
+        s->ctx = ctx;
+        s->kind = 1;
+        s->sc.reset(new SchedProblem(ctx, n_days_scored, n_days_scored + 1, n_employees));
+        const ChaCha20Rng solver_rng = ChaCha20Rng::from_seed_string(seed); // lib.rs:58-62
+        const ChaCha20Rng ils_rng = ChaCha20Rng::from_seed_string(seed);    // lib.rs:94
+        LocalSearch<SchedProblem> ls(s->sc.get(), params->local_search_max_iterations, (size_t)params->window_size,
+                                     (size_t)params->best_solutions_capacity, (size_t)params->all_solutions_capacity,
+                                     params->all_solution_iteration_expiry, solver_rng);
+        History<SchedProblem> history((size_t)params->best_solutions_capacity, (size_t)params->all_solutions_capacity,
+                                      params->all_solution_iteration_expiry);
+        s->sc_ils.reset(new IteratedLocalSearch<SchedProblem>(s->sc.get(), std::move(ls), std::move(history),
+                                                              params->iterated_local_search_max_iterations,
+                                                              params->max_allow_no_improvement_for, ils_rng));
+        *out = s.release();
+        return LS_OK;
+    });
+}
+
+int ls_solver_execute_round(ls_solver *s)
+{
+    if (!s) return LS_ERR_INVALID;
+    return guarded(s->ctx, [&]() {
+        if (s->kind == 0) s->nq_ils->execute_round();
+        else s->sc_ils->execute_round();
+        return LS_OK;
+    });
+}
+
+int ls_solver_is_finished(const ls_solver *s, int *finished)
+{
+    if (!s || !finished) return LS_ERR_INVALID;
+    *finished = (s->kind == 0 ? s->nq_ils->is_finished() : s->sc_ils->is_finished()) ? 1 : 0;
+    return LS_OK;
+}
+
+int ls_solver_get_iteration_info(const ls_solver *s, uint64_t *current, uint64_t *total)
+{
+    if (!s) return LS_ERR_INVALID;
+    const IterationInfo i = s->kind == 0 ? s->nq_ils->get_iteration_info() : s->sc_ils->get_iteration_info();
+    if (current) *current = i.current;
+    if (total) *total = i.total;
+    return LS_OK;
+}
+
+int ls_solver_get_best_solution(const ls_solver *s, int64_t score[2], int64_t *solution, int32_t cap, int32_t *len,
+                                int *have)
+{
+    if (!s || !score) return LS_ERR_INVALID;
+    if (s->kind == 0) {
+        ScoredSolution<NQueensProblem> b;
+        const bool ok = s->nq_ils->get_best_solution(b);
+        if (have) *have = ok ? 1 : 0;
+        if (!ok) { if (len) *len = 0; return LS_OK; }
+        score[0] = b.score; score[1] = 0;
+        return copy_solution(b.solution, solution, cap, len);
+    }
+    ScoredSolution<SchedProblem> b;
+    const bool ok = s->sc_ils->get_best_solution(b);
+    if (have) *have = ok ? 1 : 0;
+    if (!ok) { if (len) *len = 0; return LS_OK; }
+    score[0] = b.score.first; score[1] = b.score.second;
+    return copy_solution(b.solution, solution, cap, len);
+}
+
+int ls_solver_get_current_solution(const ls_solver *s, int64_t score[2], int64_t *solution, int32_t cap, int32_t *len)
+{
+    if (!s || !score) return LS_ERR_INVALID;
+    if (s->kind == 0) {
+        const auto &c = s->nq_ils->current();
+        score[0] = c.score; score[1] = 0;
+        return copy_solution(c.solution, solution, cap, len);
+    }
+    const auto &c = s->sc_ils->current();
+    score[0] = c.score.first; score[1] = c.score.second;
+    return copy_solution(c.solution, solution, cap, len);
+}
+
+int ls_solver_get_stats(const ls_solver *s, uint64_t *ls_iterations, uint64_t *neighbours_scored, uint64_t *gpu_evals)
+{
+    if (!s) return LS_ERR_INVALID;
+    if (s->kind == 0) {
+        if (ls_iterations) *ls_iterations = s->nq_ils->ls_iterations();
+        if (neighbours_scored) *neighbours_scored = s->nq->neighbours_scored;
+        if (gpu_evals) *gpu_evals = s->nq->gpu_evals;
+    } else {
+        if (ls_iterations) *ls_iterations = s->sc_ils->ls_iterations();
+        if (neighbours_scored) *neighbours_scored = s->sc->neighbours_scored;
+        if (gpu_evals) *gpu_evals = s->sc->gpu_evals;
+    }
+    return LS_OK;
+}
+
+int ls_solver_free(ls_solver *s)
+{
+    delete s;
+    return LS_OK;
+}
+
+int ls_host_hash_seed(const char *seed, uint8_t out32[32])
+{
+    if (!seed || !out32) return LS_ERR_INVALID;
+    blake2b_256(seed, strlen(seed), out32);
+    return LS_OK;
+}
+
+int ls_host_chacha20_block(const uint32_t key[8], uint32_t w12, uint32_t w13, uint32_t w14, uint32_t w15,
+                           uint32_t out16[16])
+{
+    if (!key || !out16) return LS_ERR_INVALID;
+    chacha20_block(key, w12, w13, w14, w15, out16);
+    return LS_OK;
+}
+
+int ls_host_rng_script(const uint8_t seed32[32], const int64_t *ops, int64_t n_ops, const double *weights,
+                       uint64_t *out, int64_t cap, int64_t *n_out)
+{
+    if (!seed32 || !ops || !out || !n_out) return LS_ERR_INVALID;
+    try {
+        ChaCha20Rng rng(seed32);
+        int64_t k = 0;
+        auto push = [&](uint64_t v) {
+            if (k >= cap) throw std::runtime_error("output buffer too small");
+            out[k++] = v;
+        };
+        for (int64_t i = 0; i < n_ops; i++) {
+            const int64_t op = ops[3 * i], a = ops[3 * i + 1], b = ops[3 * i + 2];
+            switch (op) {
+            case 0: push(rng.next_u32()); break;
+            case 1: push(rng.next_u64()); break;
+            case 2: push(gen_range_u64_incl(rng, (uint64_t)a, (uint64_t)b)); break;
+            case 3: push(gen_range_u32_incl(rng, (uint32_t)a, (uint32_t)b)); break;
+            case 4: push(uniform_u64_below(rng, (uint64_t)a)); break;
+            case 5: push(uniform_u32_below(rng, (uint32_t)a)); break;
+            case 6: {
+                std::vector<uint64_t> v((size_t)a);
+                for (size_t j = 0; j < v.size(); j++) v[j] = j;
+                shuffle(rng, v);
+                for (uint64_t x : v) push(x);
+                break;
+            }
+            case 7:
+                for (uint32_t x : index_sample(rng, (uint32_t)a, (uint32_t)b)) push(x);
+                break;
+            case 8: {
+                const double d = rng.gen_f64();
+                uint64_t bits;
+                memcpy(&bits, &d, 8);
+                push(bits);
+                break;
+            }
+            case 9: {
+                if (!weights) return LS_ERR_INVALID;
+                std::vector<double> w(weights, weights + a);
+                for (uint32_t x : index_sample_weighted(rng, w, (uint32_t)b)) push(x);
+                break;
+            }
+            default: return LS_ERR_INVALID;
+            }
+        }
+        *n_out = k;
+        return LS_OK;
+    } catch (const std::exception &) {
+        return LS_ERR_INVALID;
+    }
+}
+
+} // extern "C"

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (INT64_MIN, LS_NQ_ALGO_SCAN, LS_NQ_ALGO_TABLE, LS_NQ_MAX_N, LS_SCHED_MAX_DAYS,  # noqa: F401
-                   LsError, NqResult, SchedMove, SchedResult)
+                   LsError, NqResult, SchedMove, SchedResult, SolverParams)
 
 ALGOS = {"scan": LS_NQ_ALGO_SCAN, "table": LS_NQ_ALGO_TABLE}
 
@@ -181,3 +181,116 @@ class Context:
             self._h, int(n_restarts), C.c_void_p(states_d), C.c_void_p(moves_d), C.c_void_p(n_moves_d),
             int(max_moves), int(window), C.c_void_p(results_d), C.c_void_p(hard_out_d or 0),
             C.c_void_p(soft_out_d or 0)))
+
+
+# ------------------------------------------------------------------ whole solver
+_PARAM_FIELDS = [f[0] for f in SolverParams._fields_]
+
+
+def _params(d: dict) -> SolverParams:
+    return SolverParams(*[int(d[k]) for k in _PARAM_FIELDS])
+
+
+class Solver:
+    """ls_solver: the reference's IteratedLocalSearch driver on the host, every score and
+    neighbourhood on the GPU of `ctx` (mirrors the wasm SolverContext API)."""
+
+    def __init__(self, ctx: Context, handle, kind: str, sol_len: int):
+        self._ctx, self._h, self.kind, self._len = ctx, handle, kind, sol_len
+        self._l = ctx._l
+
+    @classmethod
+    def nqueens(cls, ctx: Context, board_size: int, seed: str, params: dict) -> "Solver":
+        h = C.c_void_p()
+        p = _params(params)
+        ctx._check(ctx._l.ls_solver_create_nqueens(ctx._h, int(board_size), seed.encode(), C.byref(p), C.byref(h)))
+        return cls(ctx, h, "nqueens", int(board_size))
+
+    @classmethod
+    def scheduling(cls, ctx: Context, n_days_scored: int, start_weekday: int, n_employees: int, seed: str,
+                   params: dict, holiday_bits=None) -> "Solver":
+        hb = np.zeros(n_employees, dtype=np.uint64) if holiday_bits is None else _c(holiday_bits, np.uint64)
+        h = C.c_void_p()
+        p = _params(params)
+        ctx._check(ctx._l.ls_solver_create_sched(ctx._h, int(n_days_scored), int(start_weekday), int(n_employees),
+                                                 _vp(hb), seed.encode(), C.byref(p), C.byref(h)))
+        return cls(ctx, h, "sched", int(n_days_scored) + 1)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.ls_solver_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def execute_round(self):
+        self._ctx._check(self._l.ls_solver_execute_round(self._h))
+
+    def is_finished(self) -> bool:
+        f = C.c_int()
+        self._ctx._check(self._l.ls_solver_is_finished(self._h, C.byref(f)))
+        return bool(f.value)
+
+    def iteration_info(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ctx._check(self._l.ls_solver_get_iteration_info(self._h, C.byref(a), C.byref(b)))
+        return dict(current=a.value, total=b.value)
+
+    def _score(self, sc):
+        return int(sc[0]) if self.kind == "nqueens" else (int(sc[0]), int(sc[1]))
+
+    def best(self):
+        sc = np.zeros(2, dtype=np.int64)
+        sol = np.zeros(self._len, dtype=np.int64)
+        n, have = C.c_int32(), C.c_int()
+        self._ctx._check(self._l.ls_solver_get_best_solution(self._h, _vp(sc), _vp(sol), self._len, C.byref(n),
+                                                             C.byref(have)))
+        if not have.value:
+            return None
+        return self._score(sc), tuple(int(x) for x in sol[:n.value])
+
+    def current(self):
+        sc = np.zeros(2, dtype=np.int64)
+        sol = np.zeros(self._len, dtype=np.int64)
+        n = C.c_int32()
+        self._ctx._check(self._l.ls_solver_get_current_solution(self._h, _vp(sc), _vp(sol), self._len, C.byref(n)))
+        return self._score(sc), tuple(int(x) for x in sol[:n.value])
+
+    def stats(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._ctx._check(self._l.ls_solver_get_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(ls_iterations=a.value, neighbours_scored=b.value, gpu_evals=c.value)
+
+
+# host RNG primitives (no GPU needed)
+def host_hash_seed(seed: str) -> bytes:
+    out = (C.c_uint8 * 32)()
+    rc = _lib.load().ls_host_hash_seed(seed.encode(), C.cast(out, C.c_void_p))
+    if rc != 0:
+        raise LsError(rc, "ls_host_hash_seed")
+    return bytes(out)
+
+
+def host_chacha20_block(key_words, w12, w13, w14, w15):
+    key = (C.c_uint32 * 8)(*[int(k) for k in key_words])
+    out = (C.c_uint32 * 16)()
+    rc = _lib.load().ls_host_chacha20_block(C.cast(key, C.c_void_p), w12, w13, w14, w15, C.cast(out, C.c_void_p))
+    if rc != 0:
+        raise LsError(rc, "ls_host_chacha20_block")
+    return [int(x) for x in out]
+
+
+def host_rng_script(seed32: bytes, ops, weights=None, cap=1 << 16):
+    seed = (C.c_uint8 * 32)(*seed32)
+    o = _c(ops, np.int64).reshape(-1, 3)
+    w = None if weights is None else _c(weights, np.float64)
+    out = np.zeros(cap, dtype=np.uint64)
+    n = C.c_int64()
+    rc = _lib.load().ls_host_rng_script(C.cast(seed, C.c_void_p), _vp(o), len(o), _vp(w), _vp(out), cap, C.byref(n))
+    if rc != 0:
+        raise LsError(rc, "ls_host_rng_script")
+    return [int(x) for x in out[:n.value]]

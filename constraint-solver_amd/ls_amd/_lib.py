@@ -40,6 +40,13 @@ class SchedMove(C.Structure):
     _fields_ = [("type", C.c_int32), ("a", C.c_int32), ("b", C.c_int32)]
 
 
+class SolverParams(C.Structure):
+    _fields_ = [("local_search_max_iterations", C.c_uint64), ("window_size", C.c_uint64),
+                ("best_solutions_capacity", C.c_uint64), ("all_solutions_capacity", C.c_uint64),
+                ("all_solution_iteration_expiry", C.c_uint64), ("iterated_local_search_max_iterations", C.c_uint64),
+                ("max_allow_no_improvement_for", C.c_uint64)]
+
+
 class SchedResult(C.Structure):
     _fields_ = [("n_scored", C.c_int64), ("best_index", C.c_int64), ("best_hard", C.c_int64),
                 ("best_soft", C.c_int64)]
@@ -71,6 +78,18 @@ SIGNATURES = {
     "ls_sched_eval": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "ls_sched_eval_batch": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "ls_sched_eval_batch_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "ls_solver_create_nqueens": (C.c_int, [_vp, C.c_uint64, C.c_char_p, _vp, C.POINTER(_vp)]),
+    "ls_solver_create_sched": (C.c_int, [_vp, _i32, _i32, _i32, _vp, C.c_char_p, _vp, C.POINTER(_vp)]),
+    "ls_solver_execute_round": (C.c_int, [_vp]),
+    "ls_solver_is_finished": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "ls_solver_get_iteration_info": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ls_solver_get_best_solution": (C.c_int, [_vp, _vp, _vp, _i32, C.POINTER(_i32), C.POINTER(C.c_int)]),
+    "ls_solver_get_current_solution": (C.c_int, [_vp, _vp, _vp, _i32, C.POINTER(_i32)]),
+    "ls_solver_get_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ls_solver_free": (C.c_int, [_vp]),
+    "ls_host_hash_seed": (C.c_int, [C.c_char_p, _vp]),
+    "ls_host_chacha20_block": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
+    "ls_host_rng_script": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, C.POINTER(_i64)]),
 }
 
 _lib = None

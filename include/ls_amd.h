@@ -217,6 +217,66 @@ int ls_sched_eval_batch_dev(ls_ctx *ctx, int32_t n_restarts, const int32_t *stat
                             int64_t max_moves, int64_t window, ls_sched_result *results_d,
                             int64_t *hard_out_d, int64_t *soft_out_d);
 
+/* ------------------------------------------------------------ whole solver
+ *
+ * Host-side mirror of the reference's driver around the GPU path, shaped like the only FFI
+ * the reference has (web/employee-scheduling-wasm-bindgen/src/lib.rs:18-84: create_solver /
+ * execute_solver_round / get_iteration_info / is_solver_finished / get_best_solution / free).
+ * IteratedLocalSearch::execute_round (iterated_local_search.rs:173-202), LocalSearch::execute
+ * (local_search.rs:301-342), History, AcceptanceCriterion, the plug-ins' proposers,
+ * perturbations and initial solutions run on the host exactly as in the reference; every score
+ * and every neighbourhood (local_search.rs:315-325) runs on the GPU of `ctx`.
+ * Seeds: seed string -> Blake2b-256 -> two identically seeded ChaCha20 generators
+ * (examples/nqueens/src/main.rs:28-39,66).  The rand/rand_chacha algorithms are restated from
+ * their published sources; equality with the Rust binaries' streams is unverified (no Rust
+ * toolchain in the build environment).
+ */
+typedef struct ls_solver ls_solver;
+
+typedef struct ls_solver_params {        /* MainArgs, examples/nqueens/src/main.rs:16-26 */
+    uint64_t local_search_max_iterations;
+    uint64_t window_size;
+    uint64_t best_solutions_capacity;
+    uint64_t all_solutions_capacity;
+    uint64_t all_solution_iteration_expiry;   /* must be >= 1: tabu == {current} */
+    uint64_t iterated_local_search_max_iterations;
+    uint64_t max_allow_no_improvement_for;
+} ls_solver_params;
+
+/* get_solution's set-up (examples/nqueens/src/main.rs:35-87).  The context must outlive the solver. */
+int ls_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, const char *seed, const ls_solver_params *params,
+                             ls_solver **out);
+/* get_ils (examples/employee-scheduling/src/lib.rs:57-117).  Employees are indices 0..n_employees-1
+ * in ascending id order; uploads the instance to `ctx`.  n_days_stored = n_days_scored + 1
+ * (the generator's off-by-one, lib.rs:407-411). */
+int ls_solver_create_sched(ls_ctx *ctx, int32_t n_days_scored, int32_t start_weekday, int32_t n_employees,
+                           const uint64_t *holiday_bits, const char *seed, const ls_solver_params *params,
+                           ls_solver **out);
+int ls_solver_execute_round(ls_solver *s);                                   /* execute_solver_round */
+int ls_solver_is_finished(const ls_solver *s, int *finished);                 /* is_solver_finished */
+int ls_solver_get_iteration_info(const ls_solver *s, uint64_t *current, uint64_t *total); /* get_iteration_info */
+/* get_best_solution / the current local minimum.  score[0] = NQueensScore or hard, score[1] = 0 or soft;
+ * solution: rows (N-queens) or employee indices (scheduling), `cap` entries available, *len written.
+ * *have = 0 when the best set is still empty (the reference would panic on unwrap, :165-167). */
+int ls_solver_get_best_solution(const ls_solver *s, int64_t score[2], int64_t *solution, int32_t cap, int32_t *len,
+                                int *have);
+int ls_solver_get_current_solution(const ls_solver *s, int64_t score[2], int64_t *solution, int32_t cap, int32_t *len);
+/* counters: LS iterations run, candidates scored on the GPU, GPU neighbourhood launches */
+int ls_solver_get_stats(const ls_solver *s, uint64_t *ls_iterations, uint64_t *neighbours_scored, uint64_t *gpu_evals);
+int ls_solver_free(ls_solver *s);
+
+/* Host RNG primitives, exported so the tests can pin them (RFC 7693 / RFC 7539 vectors, and
+ * the oracle's independent restatement).  ls_host_rng_script runs `n_ops` operations
+ * (op, a, b) on a ChaCha20Rng::from_seed(seed32) and appends every produced value to `out`:
+ *   0 next_u32 | 1 next_u64 | 2 gen_range_u64 a..=b | 3 gen_range_u32 a..=b | 4 Uniform<u64>(0,a) |
+ *   5 Uniform<u32>(0,a) | 6 shuffle of 0..a (a values) | 7 index::sample(a, b) (b values) |
+ *   8 gen::<f64>() bit pattern | 9 index::sample_weighted(weights[0..a], b) (b values) */
+int ls_host_hash_seed(const char *seed, uint8_t out32[32]);
+int ls_host_chacha20_block(const uint32_t key[8], uint32_t w12, uint32_t w13, uint32_t w14, uint32_t w15,
+                           uint32_t out16[16]);
+int ls_host_rng_script(const uint8_t seed32[32], const int64_t *ops, int64_t n_ops, const double *weights,
+                       uint64_t *out, int64_t cap, int64_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

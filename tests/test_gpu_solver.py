@@ -1,0 +1,134 @@
+"""GPU end-to-end: the product's host driver (C++ mirror of IteratedLocalSearch / LocalSearch /
+plug-ins, every score and neighbourhood on the GPU) against the oracle's independent Python
+restatement with the literal CPU neighbourhood pipeline: same seed => identical trajectory
+(current and best score after every round) and identical final solutions."""
+import numpy as np
+import pytest
+
+import ls_oracle as lo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import ls_amd
+    c = ls_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _nq_params(n, expiry=10_000):
+    p = dict(lo.NQUEENS_MAIN_PARAMS)
+    p["window_size"] = 5 * n                       # examples/nqueens/src/main.rs:130
+    p["all_solution_iteration_expiry"] = expiry
+    return p
+
+
+def _trace_product(solver, rounds):
+    tr = []
+    for _ in range(rounds):
+        if solver.is_finished():
+            break
+        solver.execute_round()
+        b = solver.best()
+        tr.append((solver.current()[0], None if b is None else b[0]))
+    return tr
+
+
+def _trace_oracle(ils, rounds):
+    tr = []
+    for _ in range(rounds):
+        if ils.is_finished():
+            break
+        ils.execute_round()
+        b = ils.get_best_solution()
+        tr.append((ils.current[0], None if b is None else b[0]))
+    return tr
+
+
+@pytest.mark.parametrize("algo", ["scan", "table"])
+def test_nq8_config1_matches_oracle_and_solves(ctx, algo):
+    # config 1 (examples/nqueens defaults, n = 8) incl. the reference's `repeatable` expectations
+    import ls_amd
+    ctx.set_algo(algo)
+    for seed in map(str, range(42, 50)):
+        p = _nq_params(8, expiry=1_000)
+        s = ls_amd.Solver.nqueens(ctx, 8, seed, p)
+        o = lo.IteratedLocalSearch(lo.NQueens(8), p, seed)
+        assert s.current() == o.current                               # same initial permutation and score
+        t1, t2 = _trace_product(s, 40), _trace_oracle(o, 40)
+        assert t1 == t2, seed
+        best = s.best()
+        assert best == o.get_best_solution()
+        assert best[0] == 0, seed                                     # main.rs:194-198
+        s.close()
+    ctx.set_algo("scan")
+
+
+@pytest.mark.parametrize("n,rounds,seed", [(20, 12, "42"), (64, 6, "7"), (200, 3, "abc"), (1024, 2, "42")])
+def test_nqueens_trajectory_matches_oracle(ctx, n, rounds, seed):
+    import ls_amd
+    p = _nq_params(n)
+    s = ls_amd.Solver.nqueens(ctx, n, seed, p)
+    o = lo.IteratedLocalSearch(lo.NQueens(n), p, seed)
+    assert s.current() == o.current
+    assert _trace_product(s, rounds) == _trace_oracle(o, rounds)
+    assert s.current() == o.current
+    assert s.best() == o.get_best_solution()
+    assert s.stats()["ls_iterations"] == o.local_search.ls_iterations
+    s.close()
+
+
+def test_sched_example_trajectory_matches_oracle(ctx):
+    # config 3: examples/employee-scheduling/src/main.rs:11-31
+    import ls_amd
+    p = dict(lo.SCHED_MAIN_PARAMS)
+    o = lo.IteratedLocalSearch(lo.Scheduling((2022, 5, 9), (2022, 6, 8), 7), p, "42")
+    s = ls_amd.Solver.scheduling(ctx, 31, 0, 7, "42", p)
+    assert s.current() == o.current
+    assert _trace_product(s, 4) == _trace_oracle(o, 4)
+    assert s.current() == o.current
+    assert s.best() == o.get_best_solution()
+    st = s.stats()
+    assert st["ls_iterations"] == o.local_search.ls_iterations
+    assert st["neighbours_scored"] == 100 * st["ls_iterations"]      # window always fills (infinite stream)
+    s.close()
+
+
+def test_sched_with_holidays_trajectory(ctx):
+    import ls_amd
+    hol = {0: [0, 1, 14], 3: [3], 6: [30]}
+    bits = np.zeros(7, dtype=np.uint64)
+    for e, ds in hol.items():
+        for d in ds:
+            bits[e] |= np.uint64(1) << np.uint64(d)
+    p = dict(lo.SCHED_MAIN_PARAMS)
+    p["window_size"] = 37
+    o = lo.IteratedLocalSearch(lo.Scheduling((2022, 5, 9), (2022, 6, 8), 7, hol), p, "holiday seed")
+    s = ls_amd.Solver.scheduling(ctx, 31, 0, 7, "holiday seed", p, holiday_bits=bits)
+    assert _trace_product(s, 3) == _trace_oracle(o, 3)
+    assert s.best() == o.get_best_solution()
+    s.close()
+
+
+def test_solver_api_edges(ctx):
+    import ls_amd
+    p = _nq_params(8)
+    s = ls_amd.Solver.nqueens(ctx, 8, "42", p)
+    assert s.best() is None                                          # best set empty before the first round
+    assert s.iteration_info() == dict(current=0, total=10_000)
+    assert not s.is_finished()
+    s.execute_round()
+    assert s.iteration_info()["current"] == 1
+    s.close()
+    bad = dict(p, all_solution_iteration_expiry=0)
+    with pytest.raises(ls_amd.LsError) as ei:
+        ls_amd.Solver.nqueens(ctx, 8, "42", bad)
+    assert ei.value.code == ls_amd._lib.LS_ERR_UNSUPPORTED
+    short = dict(p, iterated_local_search_max_iterations=2)
+    s = ls_amd.Solver.nqueens(ctx, 30, "1", short)
+    for _ in range(2):
+        s.execute_round()
+    assert s.is_finished()
+    s.close()
