@@ -119,8 +119,15 @@ __device__ __forceinline__ NqRanges nq_ranges(int vs, int ve, int rc, long long 
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
-// waves per SIMD a kernel needing `vgprs` registers per lane can hold (512-entry file)
-constexpr int nq_waves_for(int vgprs) { return 512 / vgprs < 1 ? 1 : (512 / vgprs > 8 ? 8 : 512 / vgprs); }
+// Waves per SIMD to run a kernel needing `vgprs` registers per lane at (512-entry file), rounded
+// DOWN to a power of two: measured with tools/valu_rates.hip, the scan kernel's instruction mix
+// issues at 0.92 / 1.16 / 0.89 ns per instruction with 2 / 3 / 4 waves per SIMD — an odd count
+// costs 25 %.
+constexpr int nq_waves_for(int vgprs)
+{
+    const int w = 512 / vgprs;
+    return w >= 8 ? 8 : (w >= 4 ? 4 : (w >= 2 ? 2 : 1));
+}
 
 __device__ __forceinline__ us2 as_us2(unsigned x) { return __builtin_bit_cast(us2, x); }
 __device__ __forceinline__ unsigned as_u32(us2 x) { return __builtin_bit_cast(unsigned, x); }
@@ -286,55 +293,87 @@ struct BoardF32 {
         (void)c;
         const float f0 = (float)v, f1 = (float)(v + 1), f2 = (float)(v + 2), f3 = (float)(v + 3);
         float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f; // mismatching columns per candidate
+        // Four candidates are interleaved so that neighbouring instructions are independent, and
+        // four columns share one asm statement: hipcc pads every asm statement with an s_nop.
+#define LS_F32_COL(r, e)                                                                            \
+    "v_sub_f32_e32 %4, " r ", %20\n\tv_sub_f32_e32 %5, " r ", %21\n\t"                              \
+    "v_sub_f32_e32 %6, " r ", %22\n\tv_sub_f32_e32 %7, " r ", %23\n\t"                              \
+    "v_sub_f32_e64 %8, |%4|, " e "\n\tv_sub_f32_e64 %9, |%5|, " e "\n\t"                            \
+    "v_sub_f32_e64 %10, |%6|, " e "\n\tv_sub_f32_e64 %11, |%7|, " e "\n\t"                          \
+    "v_mul_f32_e64 %4, |%4|, |%8| clamp\n\tv_mul_f32_e64 %5, |%5|, |%9| clamp\n\t"                  \
+    "v_mul_f32_e64 %6, |%6|, |%10| clamp\n\tv_mul_f32_e64 %7, |%7|, |%11| clamp\n\t"                \
+    "v_add_f32_e32 %0, %0, %4\n\tv_add_f32_e32 %1, %1, %5\n\t"                                      \
+    "v_add_f32_e32 %2, %2, %6\n\tv_add_f32_e32 %3, %3, %7\n\t"
+        constexpr int G = NR >= 4 ? 4 : NR;
 #pragma unroll
-        for (int i = 0; i < NR; i++) {
-            // four candidates interleaved so that neighbouring instructions are independent
-            // (a dependent FP32 op issues every ~4 cycles, an independent one every 2)
+        for (int i = 0; i < NR; i += G) {
             float d0, d1, d2, d3, u0, u1, u2, u3;
-            asm("v_sub_f32_e32 %4, %12, %14\n\t"
-                "v_sub_f32_e32 %5, %12, %15\n\t"
-                "v_sub_f32_e32 %6, %12, %16\n\t"
-                "v_sub_f32_e32 %7, %12, %17\n\t"
-                "v_sub_f32_e64 %8, |%4|, %13\n\t"
-                "v_sub_f32_e64 %9, |%5|, %13\n\t"
-                "v_sub_f32_e64 %10, |%6|, %13\n\t"
-                "v_sub_f32_e64 %11, |%7|, %13\n\t"
-                "v_mul_f32_e64 %4, |%4|, |%8| clamp\n\t"
-                "v_mul_f32_e64 %5, |%5|, |%9| clamp\n\t"
-                "v_mul_f32_e64 %6, |%6|, |%10| clamp\n\t"
-                "v_mul_f32_e64 %7, |%7|, |%11| clamp\n\t"
-                "v_add_f32_e32 %0, %0, %4\n\t"
-                "v_add_f32_e32 %1, %1, %5\n\t"
-                "v_add_f32_e32 %2, %2, %6\n\t"
-                "v_add_f32_e32 %3, %3, %7"
-                : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3),
-                  "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
-                : "v"(R[i]), "v"(E[i]), "v"(f0), "v"(f1), "v"(f2), "v"(f3));
+            if constexpr (G == 4) {
+                asm(LS_F32_COL("%12", "%16") LS_F32_COL("%13", "%17") LS_F32_COL("%14", "%18") LS_F32_COL("%15", "%19")
+                    : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3),
+                      "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
+                    : "v"(R[i]), "v"(R[i + 1]), "v"(R[i + 2]), "v"(R[i + 3]), "v"(E[i]), "v"(E[i + 1]), "v"(E[i + 2]),
+                      "v"(E[i + 3]), "v"(f0), "v"(f1), "v"(f2), "v"(f3));
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    // same operand numbering as above with a single column (NR < 4: n <= 128)
+                    asm(LS_F32_COL("%12", "%16")
+                        : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3),
+                          "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
+                        : "v"(R[i + g]), "v"(R[i + g]), "v"(R[i + g]), "v"(R[i + g]), "v"(E[i + g]), "v"(E[i + g]),
+                          "v"(E[i + g]), "v"(E[i + g]), "v"(f0), "v"(f1), "v"(f2), "v"(f3));
+                }
+            }
         }
+#undef LS_F32_COL
         nq_reduce4(NR - (int)m0, NR - (int)m1, NR - (int)m2, NR - (int)m3, cnt);
     }
 };
 
-template <class Board>
-__device__ __forceinline__ void nq_scan_range_regs(const Board &bd, int vbeg, int vend, int c, int conf_old,
-                                                   unsigned long long khi, unsigned long long &best,
-                                                   long long *scores_row, long long cur, int lane)
+// Running minimum of one wavefront, all wave-uniform (scalar registers).  A candidate can only
+// win if its delta does not exceed the best delta so far, which a 32-bit scalar compare decides;
+// the 64-bit key is built for those few only.
+struct NqBest {
+    int delta;
+    unsigned long long key;
+};
+
+template <bool WANT_SCORES>
+__device__ __forceinline__ void nq_consider(NqBest &best, int delta, unsigned long long khi, int v,
+                                            long long *scores_row, long long cur, int lane)
 {
-    for (int v = vbeg; v < vend; v += 4) {
-        int cnt[4];
-        bd.count4(v, c, cnt);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (v + u < vend) {
-                const int delta = cnt[u] - conf_old;
-                best = u64min(best, nq_key(delta, khi, v + u));
-                if (scores_row != nullptr && lane == 0) scores_row[v + u] = cur + 2ll * delta;
-            }
-        }
+    if (delta <= best.delta) {
+        const unsigned long long key = nq_key(delta, khi, v);
+        if (key < best.key) { best.key = key; best.delta = delta; }
+    }
+    if (WANT_SCORES) {
+        if (lane == 0) scores_row[v] = cur + 2ll * delta;
     }
 }
 
-template <class Board>
+template <bool WANT_SCORES, class Board>
+__device__ __forceinline__ void nq_scan_range_regs(const Board &bd, int vbeg, int vend, int c, int conf_old,
+                                                   unsigned long long khi, NqBest &best, long long *scores_row,
+                                                   long long cur, int lane)
+{
+    int v = vbeg;
+    for (; v + 4 <= vend; v += 4) {
+        int cnt[4];
+        bd.count4(v, c, cnt);
+#pragma unroll
+        for (int u = 0; u < 4; u++) nq_consider<WANT_SCORES>(best, cnt[u] - conf_old, khi, v + u, scores_row, cur, lane);
+    }
+    if (v < vend) { // tail: fewer than four values left; surplus results are dropped
+        int cnt[4];
+        bd.count4(v, c, cnt);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (v + u < vend) nq_consider<WANT_SCORES>(best, cnt[u] - conf_old, khi, v + u, scores_row, cur, lane);
+    }
+}
+
+template <class Board, bool WANT_SCORES>
 __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs a)
 {
     __shared__ unsigned long long s_best[4];
@@ -351,7 +390,7 @@ __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs 
     const long long K = nq_k_limit((long long)ncols * n, n, a.window);
     const long long k0 = K * wchunk / n_wchunks;
     const long long k1 = K * (wchunk + 1) / n_wchunks;
-    unsigned long long best = NQ_KEY_EMPTY;
+    NqBest best{0x7fffffff, NQ_KEY_EMPTY};
 
     if (k0 < k1) {
         Board bd;
@@ -374,11 +413,11 @@ __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs 
                     int cnt[4];
                     bd.count4(rc, c, cnt);
                     const int conf_old = cnt[0] - Board::SELF;
-                    long long *srow = a.scores_out
-                                          ? a.scores_out + ((long long)restart * a.max_cols + slot) * n
-                                          : nullptr;
-                    nq_scan_range_regs(bd, rg.d0, rg.d1, c, conf_old, nq_key_hi(0, c, n, slot), best, srow, cur, lane);
-                    nq_scan_range_regs(bd, rg.u0, rg.u1, c, conf_old, nq_key_hi(1, c, n, slot), best, srow, cur, lane);
+                    long long *srow = WANT_SCORES ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
+                    nq_scan_range_regs<WANT_SCORES>(bd, rg.d0, rg.d1, c, conf_old, nq_key_hi(0, c, n, slot), best, srow,
+                                                    cur, lane);
+                    nq_scan_range_regs<WANT_SCORES>(bd, rg.u0, rg.u1, c, conf_old, nq_key_hi(1, c, n, slot), best, srow,
+                                                    cur, lane);
                 }
             }
             k += ve - v0;
@@ -386,7 +425,7 @@ __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs 
             v0 = 0;
         }
     }
-    if (lane == 0) s_best[wib] = best;
+    if (lane == 0) s_best[wib] = best.key;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long b = u64min(u64min(s_best[0], s_best[1]), u64min(s_best[2], s_best[3]));
@@ -646,13 +685,25 @@ static int nq_blocks_per_cu(const void *fn, size_t dyn_lds)
 template <class Board>
 static int launch_scan_board(ls_ctx *ctx, const NqArgs &a, long long bpr_cap)
 {
-    static int bpc = 0;
-    if (!bpc) bpc = nq_blocks_per_cu(reinterpret_cast<const void *>(&nq_scan_regs_kernel<Board>), 0);
+    // Exactly Board::WAVES 256-thread blocks per CU: the register budget alone may admit an odd
+    // number of waves per SIMD, so a dynamic-LDS reservation (never touched) caps residency.
+    constexpr int bpc = Board::WAVES;
+    constexpr size_t lds_cap = bpc >= 8 ? 0 : (size_t)(160 * 1024 / bpc - 2048);
+    static bool attr_done = false;
+    if (!attr_done && lds_cap > 0) {
+        LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_scan_regs_kernel<Board, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+        LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_scan_regs_kernel<Board, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+        attr_done = true;
+    }
     long long total = (long long)ctx->n_cus * bpc;
     long long bpr = total / a.n_restarts;
     if (bpr < 1) bpr = 1;
     if (bpr > bpr_cap) bpr = bpr_cap;
-    hipLaunchKernelGGL(nq_scan_regs_kernel<Board>, dim3((unsigned)(bpr * a.n_restarts)), dim3(256), 0, ctx->stream, a);
+    const dim3 grid((unsigned)(bpr * a.n_restarts));
+    if (a.scores_out) hipLaunchKernelGGL((nq_scan_regs_kernel<Board, true>), grid, dim3(256), lds_cap, ctx->stream, a);
+    else hipLaunchKernelGGL((nq_scan_regs_kernel<Board, false>), grid, dim3(256), lds_cap, ctx->stream, a);
     LS_HIP(ctx, hipGetLastError());
     return LS_OK;
 }

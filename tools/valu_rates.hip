@@ -138,6 +138,51 @@ __global__ __launch_bounds__(256) void k_pkfmaf32(unsigned long long *out, float
     if ((threadIdx.x & 63) == 0) out[(blockIdx.x * 256 + threadIdx.x) >> 6] = t1 - t0;
 }
 
+// The scan kernel's own instruction mix (sub e32, sub e64 |abs|, mul e64 |abs||abs| clamp, add e32; 4 candidates
+// interleaved) as a SHORT loop body (64 instructions) and as a LONG straight-line body (1024 instructions, the
+// unrolled 64-column step) — separates issue rate from instruction-fetch effects.
+#define MIX_COL                                                                                         \
+    "v_sub_f32_e32 %4, %16, %12\n\tv_sub_f32_e32 %5, %16, %13\n\tv_sub_f32_e32 %6, %16, %14\n\tv_sub_f32_e32 %7, %16, %15\n\t" \
+    "v_sub_f32_e64 %8, |%4|, %17\n\tv_sub_f32_e64 %9, |%5|, %17\n\tv_sub_f32_e64 %10, |%6|, %17\n\tv_sub_f32_e64 %11, |%7|, %17\n\t" \
+    "v_mul_f32_e64 %4, |%4|, |%8| clamp\n\tv_mul_f32_e64 %5, |%5|, |%9| clamp\n\tv_mul_f32_e64 %6, |%6|, |%10| clamp\n\tv_mul_f32_e64 %7, |%7|, |%11| clamp\n\t" \
+    "v_add_f32_e32 %0, %0, %4\n\tv_add_f32_e32 %1, %1, %5\n\tv_add_f32_e32 %2, %2, %6\n\tv_add_f32_e32 %3, %3, %7\n\t"
+#define MIX4 MIX_COL MIX_COL MIX_COL MIX_COL
+#define MIX16 MIX4 MIX4 MIX4 MIX4
+#define MIX64 MIX16 MIX16 MIX16 MIX16
+#define MIX_KERNEL(NAME, BODY, DIV)                                                                     \
+    __global__ __launch_bounds__(256) void NAME(unsigned long long *out, float *sink, int iters)        \
+    {                                                                                                   \
+        float a[16];                                                                                    \
+        for (int i = 0; i < 16; i++) a[i] = (float)(threadIdx.x + i);                                   \
+        float s0 = 3.0f, s1 = 5.0f;                                                                     \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                           \
+        for (int it = 0; it < iters / DIV; it++) {                                                      \
+            asm volatile(BODY                                                                           \
+                         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]),   \
+                           "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]),           \
+                           "+v"(a[13]), "+v"(a[14]), "+v"(a[15])                                        \
+                         : "v"(s0), "v"(s1)                                                             \
+                         : "memory");                                                                   \
+        }                                                                                               \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                           \
+        float acc = 0;                                                                                  \
+        for (int i = 0; i < 16; i++) acc += a[i];                                                       \
+        if (acc == 12345.678f) sink[0] = acc;                                                           \
+        if ((threadIdx.x & 63) == 0) out[(blockIdx.x * 256 + threadIdx.x) >> 6] = t1 - t0;              \
+    }
+MIX_KERNEL(k_mix_short64, MIX4, 1)
+MIX_KERNEL(k_mix_long1024, MIX64, 16)
+// all-e32 control of the same length: 1024 x 4-byte encodings
+#define E32_COL                                                                                         \
+    "v_sub_f32_e32 %4, %16, %12\n\tv_sub_f32_e32 %5, %16, %13\n\tv_sub_f32_e32 %6, %16, %14\n\tv_sub_f32_e32 %7, %16, %15\n\t" \
+    "v_sub_f32_e32 %8, %4, %17\n\tv_sub_f32_e32 %9, %5, %17\n\tv_sub_f32_e32 %10, %6, %17\n\tv_sub_f32_e32 %11, %7, %17\n\t" \
+    "v_mul_f32_e32 %4, %4, %8\n\tv_mul_f32_e32 %5, %5, %9\n\tv_mul_f32_e32 %6, %6, %10\n\tv_mul_f32_e32 %7, %7, %11\n\t" \
+    "v_add_f32_e32 %0, %0, %4\n\tv_add_f32_e32 %1, %1, %5\n\tv_add_f32_e32 %2, %2, %6\n\tv_add_f32_e32 %3, %3, %7\n\t"
+#define E4 E32_COL E32_COL E32_COL E32_COL
+#define E16 E4 E4 E4 E4
+#define E64 E16 E16 E16 E16
+MIX_KERNEL(k_e32_long1024, E64, 16)
+
 typedef void (*kern_t)(unsigned long long *, float *, int);
 
 struct Entry { const char *name; kern_t fn; };
@@ -146,6 +191,8 @@ int main(int argc, char **argv)
 {
     const int iters = argc > 1 ? atoi(argv[1]) : 20000;
     Entry tab[] = {
+        {"scan mix, 64-instr loop", k_mix_short64}, {"scan mix, 1024 straight", k_mix_long1024},
+        {"all-e32 mix, 1024 straight", k_e32_long1024},
         {"v_fma_f32", k_fma}, {"v_sub_f32_e32", k_sub32}, {"v_sub_f32_e64|abs|", k_sub64abs},
         {"v_mul_f32_e64|abs|clamp", k_mulclamp}, {"v_add_f32_e32", k_addf}, {"v_min3_f32", k_min3f},
         {"v_med3_f32", k_med3f}, {"v_pk_add_f32", k_pkaddf32}, {"v_pk_fma_f32", k_pkfmaf32},
@@ -170,7 +217,7 @@ int main(int argc, char **argv)
     CHECK(hipEventCreate(&e1));
     printf("%-28s %5s %12s %12s %10s\n", "instruction", "w/SIMD", "cyc/instr/SIMD", "ns/instr/SIMD", "clock GHz");
     for (const Entry &en : tab) {
-        for (int wps : {1, 2, 4}) {
+        for (int wps : {1, 2, 3, 4}) {
             const int blocks = cus * wps; // 256-thread blocks: one wave per SIMD each
             hipLaunchKernelGGL(en.fn, dim3(blocks), dim3(256), 0, 0, out, sink, iters / 10); // warm-up
             CHECK(hipDeviceSynchronize());
