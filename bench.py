@@ -253,6 +253,59 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np):
                                                      ncols_ref.data_ptr(), mc, w, res_d.data_ptr()), 200)
         out[f"{algo}_reference_shaped_window_5n"] = {"neighbours_per_s": R * min(w, mc * (n - 1)) / s,
                                                      "us_per_launch": s * 1e6, "candidates_per_launch": R * min(w, mc * (n - 1))}
+    out.update(sched_measurements(ctx, torch, dev, timed))
+    return out
+
+
+def sched_measurements(ctx, torch, dev, timed):
+    """Scheduling path, kernel throughput with moves and states resident in HBM."""
+    out = {}
+    rng = np.random.default_rng(2022)
+
+    def random_moves(n, D, E):
+        mv = np.zeros((n, 3), dtype=np.int32)
+        for i in range(n):
+            if rng.integers(0, 5) == 0:
+                mv[i] = (0, rng.integers(0, D), rng.integers(0, E))
+            else:
+                a, b = rng.choice(D, size=2, replace=False)
+                mv[i] = (1, a, b)
+        return mv
+
+    # config 3 shape: example instance (7 employees, 31/32 days), window 100, 64 restarts per launch
+    D, S, E, R, W = 31, 32, 7, 64, 100
+    ctx.sched_instance_upload(D, S, 0, E)
+    states = torch.from_numpy(rng.integers(0, E, size=(R, S)).astype(np.int32)).to(dev)
+    mv = torch.from_numpy(np.stack([random_moves(160, D, E) for _ in range(R)])).to(dev)
+    nm = torch.full((R,), 160, dtype=torch.int64, device=dev)
+    res = torch.zeros((R, 4), dtype=torch.int64, device=dev)
+    s = timed(lambda: ctx.sched_eval_batch_dev(R, states.data_ptr(), mv.data_ptr(), nm.data_ptr(), 160, W, res.data_ptr()), 200)
+    out["sched_example_window100_x64_restarts"] = {"neighbours_per_s": R * W / s, "us_per_launch": s * 1e6,
+                                                   "candidates_per_launch": R * W}
+    # config 5 shape: 10 000 employees, holidays U{0..3} per employee, one restart per GPU
+    E = 10_000
+    bits = np.zeros(E, dtype=np.uint64)
+    for e in range(E):
+        for d in rng.choice(D, size=int(rng.integers(0, 4)), replace=False):
+            bits[e] |= np.uint64(1) << np.uint64(d)
+    ctx.sched_instance_upload(D, S, 0, E, bits)
+    state_np = rng.integers(0, E, size=(1, S)).astype(np.int32)
+    states = torch.from_numpy(state_np).to(dev)
+    ex = np.zeros((S * E, 3), dtype=np.int32)          # exhaustive ScheduleMoveProposer order (lib.rs:526-550)
+    for day in range(S):
+        ex[day * E:(day + 1) * E, 1] = day
+        ex[day * E:(day + 1) * E, 2] = (state_np[0, day] + 1 + np.arange(E)) % E
+    res = torch.zeros((1, 4), dtype=torch.int64, device=dev)
+    for name, moves, window in (("sched10k_exhaustive_320k", ex, 10 ** 9),
+                                ("sched10k_random_stream_window_65536", random_moves(70_000, D, E), 65_536)):
+        mv = torch.from_numpy(moves[None]).to(dev)
+        nm = torch.full((1,), len(moves), dtype=torch.int64, device=dev)
+        s = timed(lambda: ctx.sched_eval_batch_dev(1, states.data_ptr(), mv.data_ptr(), nm.data_ptr(), len(moves), window,
+                                                   res.data_ptr()), 50)
+        torch.cuda.synchronize()
+        n_scored = int(res.cpu().numpy()[0, 0])
+        out[name] = {"neighbours_per_s": n_scored / s, "us_per_launch": s * 1e6, "candidates_per_launch": n_scored,
+                     "effective_GBps_at_144B": n_scored * 144 / s / 1e9}
     return out
 
 

@@ -8,6 +8,7 @@
 #include <new>
 
 #include "ls_common.hpp"
+#include "sched_common.hpp"
 
 namespace lsamd {
 
@@ -118,7 +119,7 @@ int ls_ctx_destroy(ls_ctx *ctx)
     DevBuf *bufs[] = {&ctx->nq_rows, &ctx->nq_cur, &ctx->nq_cols, &ctx->nq_ncols, &ctx->nq_results,
                       &ctx->nq_scores, &ctx->nq_keys, &ctx->nq_tabs, &ctx->nq_colscores, &ctx->nq_totals,
                       &ctx->sc_states, &ctx->sc_moves, &ctx->sc_nmoves, &ctx->sc_results, &ctx->sc_hard,
-                      &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sched.holiday_bits};
+                      &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sched.holiday_bits, &ctx->sched.lane_tab};
     for (DevBuf *b : bufs) b->release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -310,6 +311,10 @@ int ls_sched_instance_upload(ls_ctx *ctx, int32_t n_days_scored, int32_t n_days_
     LS_RESERVE(ctx, ctx->sched.holiday_bits, (size_t)n_employees * 8);
     LS_HIP(ctx, hipMemcpyAsync(ctx->sched.holiday_bits.p, holiday_bits, (size_t)n_employees * 8,
                                hipMemcpyHostToDevice, ctx->stream));
+    lsamd::SchedLaneConst tab[64];
+    lsamd::sched_build_lane_table(n_days_scored, start_weekday, tab);
+    LS_RESERVE(ctx, ctx->sched.lane_tab, sizeof tab);
+    LS_HIP(ctx, hipMemcpyAsync(ctx->sched.lane_tab.p, tab, sizeof tab, hipMemcpyHostToDevice, ctx->stream));
     LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->sched.n_days_scored = n_days_scored;
     ctx->sched.n_days_stored = n_days_stored;

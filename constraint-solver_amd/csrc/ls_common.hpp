@@ -39,6 +39,7 @@ struct SchedInstance {
     bool valid = false;
     int n_days_scored = 0, n_days_stored = 0, start_weekday = 0, n_employees = 0;
     DevBuf holiday_bits; // uint64[n_employees]
+    DevBuf lane_tab;     // SchedLaneConst[64]
 };
 
 } // namespace lsamd

@@ -3,10 +3,9 @@
 // examples/employee-scheduling/src/lib.rs (scorer :261-375, helpers :149-222,
 // moves :464-479 / :526-550).
 //
-// One wavefront scores one candidate; lane d holds day d (<= 64 stored days).
+// One wavefront scores one candidate at a time; lane d holds day d (<= 64 stored days).
 // Every constraint term is a function of the day-equality matrix
 //   eq[d] = bitmask over scored days q with employee(q) == employee(d)
-// which a wavefront builds with one readlane + compare per day:
 //   H1 holidays            bit d of holiday_bits[employee(d)]               lib.rs:273-280
 //   H2 consecutive days    bit d+1 of eq[d]                                 lib.rs:286-292
 //   H3 consecutive w/ends  popcount(eq[d] & h3mask[d])  (static per-lane)   lib.rs:295-315
@@ -17,17 +16,26 @@
 //   S1 >2 in 7 days        same with 7 / 3rd occurrence                     lib.rs:330-339
 //   S2 weekday consistency min over a weekday's lanes of popcount(eq & same-weekday),
 //                          counted when the weekday has >= 2 employees      lib.rs:194-218
-//   S3 / S4                max - min of popcount(eq) / popcount(eq & weekend)
-//                          over the scored lanes                            lib.rs:345-365
+//   S3 / S4                max - min of popcount(eq) / popcount(eq & weekend) over the
+//                          scored lanes, from ONE OR-reduction of one-hot counts   lib.rs:345-365
 // All terms are small integers (the reference holds them in f64; exact).
 //
-// Argmin by (hard, soft, date_to_employee vector), first of equals
-// (local_search.rs:29-37; stable sort + first()).  Candidates are <= 2-position
-// edits of one base vector, so the vector order is a closed form over the
-// edits: per edit (class: lowers/none/raises, position key, new value).  Packed
-// with the scores into one 64-bit key per candidate; a second kernel takes the
-// minimum (key, index).
+// A candidate differs from the restart's base vector in at most two days, so its
+// equality matrix is a delta update of the base matrix (built once per wavefront):
+// clear the edited days' bits, set them where the lane's employee equals the new one,
+// and the edited lanes take the ballots of those two comparisons.
+//
+// A wavefront handles candidates in batches of 64: each lane loads one move (coalesced),
+// derives its edit (positions, new employees, tabu flag), gathers the two holiday bits it
+// will need and its half of the argmin key; then the wavefront walks the non-tabu lanes of
+// the batch, broadcasting one edit at a time.  Memory latency is paid once per 64 candidates.
+//
+// Argmin by (hard, soft, date_to_employee vector), first of equals (local_search.rs:29-37).
+// The vector order of <= 2-edit candidates of one base is a closed form over the edits:
+// per edit (class: lowers < none < raises, position key, new value).  Packed with the scores
+// into one 64-bit key per candidate; the last kernel takes the minimum (key, index).
 #include "ls_common.hpp"
+#include "sched_common.hpp"
 
 namespace lsamd {
 
@@ -35,88 +43,30 @@ typedef unsigned long long u64;
 
 constexpr u64 SC_KEY_EMPTY = ~0ull;
 constexpr int SC_BIG = 1 << 20;
+constexpr int SC_COUNT_CHUNK = 1024; // moves per block in the window-count pass
 
 struct SchedInst {
     int D;             // scored days
     int S;             // stored days
-    int start_weekday; // Monday = 0
     int n_employees;
     const u64 *holiday_bits;
+    const SchedLaneConst *lane_tab;
 };
 
-// per-lane constants of the instance
-struct SchedLane {
-    int d;
-    bool scored;
-    u64 scored_mask, weekend_mask;
-    u64 mask2;  // bit d+1 if d+1 < D
-    u64 h3mask; // bits compared with day d inside a weekend-started 9-window
-    u64 wdmask; // scored days on day d's weekday, 0 on weekends / unscored lanes
-    int gsize;
-    bool s2_lead; // first lane of a Mon-Fri weekday group
-};
-
-__device__ __forceinline__ bool sc_weekend(int start_weekday, int q) { return (start_weekday + q) % 7 >= 5; }
-
-__device__ __forceinline__ SchedLane sched_lane_init(const SchedInst &in, int lane)
+__device__ __forceinline__ unsigned wave_or_u32(unsigned x)
 {
-    SchedLane L;
-    const int D = in.D;
-    L.d = lane;
-    L.scored = lane < D;
-    L.scored_mask = D >= 64 ? ~0ull : ((1ull << D) - 1);
-    u64 wm = 0;
-    for (int q = 0; q < 64; q++)
-        if (q < D && sc_weekend(in.start_weekday, q)) wm |= 1ull << q;
-    L.weekend_mask = wm;
-    L.mask2 = (L.scored && lane + 1 < D) ? (1ull << (lane + 1)) : 0;
-    u64 h3 = 0;
-    if (L.scored) {
-        // role date1: windows(9) starting at d with d, d+1 both weekend days; pairs (d,d+7), (d,d+8)
-        if (lane + 8 < D && sc_weekend(in.start_weekday, lane) && sc_weekend(in.start_weekday, lane + 1))
-            h3 |= (1ull << (lane + 7)) | (1ull << (lane + 8));
-        // role date2: window starts at d-1; pairs (d,d+6), (d,d+7)
-        if (lane >= 1 && lane - 1 + 8 < D && sc_weekend(in.start_weekday, lane - 1) &&
-            sc_weekend(in.start_weekday, lane))
-            h3 |= (1ull << (lane + 6)) | (1ull << (lane + 7));
-    }
-    L.h3mask = h3;
-    const bool weekday = (in.start_weekday + lane) % 7 < 5;
-    const u64 every7 = 0x8102040810204081ull; // bits 0, 7, 14, ..., 63
-    L.wdmask = (L.scored && weekday) ? ((every7 << (lane % 7)) & L.scored_mask) : 0;
-    L.gsize = __popcll(L.wdmask);
-    L.s2_lead = L.scored && weekday && lane < 7;
-    return L;
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_QUAD_1032, 0xf, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_QUAD_2301, 0xf, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_ROW_HALF_MIRROR, 0xf, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_ROW_MIRROR, 0xf, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_ROW_BCAST15, 0xa, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
 
-__device__ __forceinline__ int wave_max_dpp(int x)
+// day-equality matrix from scratch: one readlane + compare per scored day
+__device__ __forceinline__ u64 sched_build_eq(int D, int e)
 {
-#define LS_STEP(ctrl, rm)                                                   \
-    {                                                                       \
-        int o = __builtin_amdgcn_update_dpp(x, x, ctrl, rm, 0xf, false);    \
-        x = o > x ? o : x;                                                  \
-    }
-    LS_STEP(LS_DPP_QUAD_1032, 0xf)
-    LS_STEP(LS_DPP_QUAD_2301, 0xf)
-    LS_STEP(LS_DPP_ROW_HALF_MIRROR, 0xf)
-    LS_STEP(LS_DPP_ROW_MIRROR, 0xf)
-    LS_STEP(LS_DPP_ROW_BCAST15, 0xa)
-    LS_STEP(LS_DPP_ROW_BCAST31, 0xc)
-#undef LS_STEP
-    return __builtin_amdgcn_readlane(x, 63);
-}
-
-struct SchedScore {
-    int hard, soft;
-    int t[8];
-};
-
-// Scores the vector held one entry per lane in `e` (lanes >= S hold distinct negative sentinels).
-template <bool WANT_TERMS>
-__device__ __forceinline__ SchedScore sched_score_wave(const SchedInst &in, const SchedLane &L, int e)
-{
-    const int D = in.D;
-    // day-equality matrix, one row per lane
     u64 eq = 0;
 #pragma unroll
     for (int q = 0; q < 64; q++) {
@@ -125,12 +75,24 @@ __device__ __forceinline__ SchedScore sched_score_wave(const SchedInst &in, cons
             if (e == eq_q) eq |= 1ull << q;
         }
     }
-    eq &= L.scored_mask;
-    const int p = L.d;
+    return eq;
+}
+
+struct SchedScore {
+    int hard, soft;
+    int t[8];
+};
+
+// All eight terms from the equality matrix row `eq` of this lane's day and its holiday bit.
+template <bool WANT_TERMS>
+__device__ __forceinline__ SchedScore sched_terms(int D, const SchedLaneConst &L, int p, u64 eq, int holiday_bit)
+{
+    const bool scored = L.flags & 1;
     int h1 = 0, h2 = 0, h3 = 0, h4 = 0, s1 = 0, s2 = 0;
-    int tot_max = 0, tot_min = 0, wk_max = 0, wk_min = 0; // as "max of x" and "max of 64 - x"
-    if (L.scored) {
-        h1 = (unsigned)e < (unsigned)in.n_employees ? (int)((in.holiday_bits[e] >> p) & 1ull) : 0;
+    u64 tot_onehot = 0;
+    unsigned wk_onehot = 0;
+    if (scored) {
+        h1 = holiday_bit;
         h2 = (eq & L.mask2) ? 1 : 0;
         h3 = __popcll(eq & L.h3mask);
         const u64 below = eq & ((1ull << p) - 1);
@@ -157,10 +119,8 @@ __device__ __forceinline__ SchedScore sched_score_wave(const SchedInst &in, cons
             const int hi = p < D - 14 ? p : D - 14;
             h4 = hi - lo + 1 > 0 ? hi - lo + 1 : 0;
         }
-        const int tot = __popcll(eq);
-        const int wk = __popcll(eq & L.weekend_mask);
-        tot_max = tot; tot_min = 64 - tot;
-        wk_max = wk; wk_min = 64 - wk;
+        tot_onehot = 1ull << (__popcll(eq) - 1);                   // 1 <= days of this employee <= 64
+        wk_onehot = 1u << __popcll(eq & L.weekend_mask);           // 0 <= weekend days <= 20
     }
     // S2: min over the lanes of one weekday (stride 7)
     int cnt = L.wdmask ? __popcll(eq & L.wdmask) : SC_BIG;
@@ -171,15 +131,18 @@ __device__ __forceinline__ SchedScore sched_score_wave(const SchedInst &in, cons
         o = __shfl_down(cnt, 28, 64); cnt = o < cnt ? o : cnt;
         o = __shfl_down(cnt, 56, 64); cnt = o < cnt ? o : cnt;
     }
-    if (L.s2_lead && cnt < L.gsize) s2 = cnt;
+    if ((L.flags & 2) && cnt < L.gsize) s2 = cnt;
 
     SchedScore r;
     // hard <= 316, soft (sum part) <= 141: 16-bit fields
     const unsigned hs = (unsigned)wave_sum_i32((h1 + h2 + h3 + h4) | ((s1 + s2) << 16));
-    // lanes outside the scored range contribute 0 to every max
-    const int tmax = wave_max_dpp(tot_max), tmin = 64 - wave_max_dpp(tot_min);
-    const int wmax = wave_max_dpp(wk_max), wmin = 64 - wave_max_dpp(wk_min);
-    const int s3 = tmax - tmin, s4 = wmax - wmin;
+    // max - min of the per-employee counts = distance between the highest and lowest set bit of the
+    // OR over all scored lanes of the one-hot counts
+    const unsigned tot_lo = wave_or_u32((unsigned)tot_onehot), tot_hi = wave_or_u32((unsigned)(tot_onehot >> 32));
+    const unsigned wk_or = wave_or_u32(wk_onehot);
+    const u64 tot_or = ((u64)tot_hi << 32) | tot_lo;
+    const int s3 = (63 - __clzll((long long)tot_or)) - (__ffsll((long long)tot_or) - 1);
+    const int s4 = (31 - __clz((int)wk_or)) - (__ffs((int)wk_or) - 1);
     r.hard = (int)(hs & 0xffffu);
     r.soft = (int)(hs >> 16) + s3 + s4;
     if (WANT_TERMS) {
@@ -190,16 +153,23 @@ __device__ __forceinline__ SchedScore sched_score_wave(const SchedInst &in, cons
     return r;
 }
 
+__device__ __forceinline__ int sched_holiday_bit(const SchedInst &in, int employee, int day)
+{
+    if ((unsigned)employee >= (unsigned)in.n_employees || (unsigned)day >= (unsigned)in.D) return 0;
+    return (int)((in.holiday_bits[employee] >> day) & 1ull);
+}
+
 __global__ __launch_bounds__(256) void sched_score_kernel(SchedInst in, int n_states, const int *states,
                                                           long long *hard, long long *soft, long long *terms)
 {
     const int lane = threadIdx.x & 63;
     const int gw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
     const int n_waves = (gridDim.x * 256) >> 6;
-    const SchedLane L = sched_lane_init(in, lane);
+    const SchedLaneConst L = in.lane_tab[lane];
     for (int s = gw; s < n_states; s += n_waves) {
         const int e = lane < in.S ? states[(long long)s * in.S + lane] : -1 - lane;
-        const SchedScore r = sched_score_wave<true>(in, L, e);
+        const u64 eq = sched_build_eq(in.D, e) & L.scored_mask;
+        const SchedScore r = sched_terms<true>(in.D, L, lane, eq, sched_holiday_bit(in, e, lane));
         if (lane == 0) {
             hard[s] = r.hard;
             soft[s] = r.soft;
@@ -218,62 +188,135 @@ struct SchedEvalArgs {
     const long long *n_moves;   // [n_restarts]
     long long max_moves;
     long long window;
+    int n_chunks;        // count-pass blocks per restart
+    int *chunk_counts;   // [n_restarts][n_chunks] non-tabu moves per chunk
     long long *k_end;    // [n_restarts]  first index not scored
     long long *n_scored; // [n_restarts]
-    u64 *keys;           // [n_restarts][max_moves]
+    int blocks_per_restart;
+    int split;           // wavefronts sharing one 64-candidate batch (1 or 4): small launches are latency-bound
+    u64 *part_key;       // [n_restarts][blocks_per_restart] per-block minimum key
+    long long *part_idx; // [n_restarts][blocks_per_restart] and its move index
     long long *hard_out, *soft_out; // nullable [n_restarts][max_moves]
+    ls_sched_result *results;       // written by pass 2 itself when blocks_per_restart == 1
 };
 
-__device__ __forceinline__ bool sched_move_ok(const ls_sched_move &m, int S, int E)
+__device__ __forceinline__ bool sched_move_ok(int type, int a, int b, int S, int E)
 {
-    if (m.type == 0) return (unsigned)m.a < (unsigned)S && (unsigned)m.b < (unsigned)E;
-    if (m.type == 1) return (unsigned)m.a < (unsigned)S && (unsigned)m.b < (unsigned)S;
+    if (type == 0) return (unsigned)a < (unsigned)S && (unsigned)b < (unsigned)E;
+    if (type == 1) return (unsigned)a < (unsigned)S && (unsigned)b < (unsigned)S;
     return false;
 }
 
-// Pass 1: where does take(window) stop?  Tabu (no-op) candidates do not count
-// (local_search.rs:319-321).  One block per restart.
-__global__ __launch_bounds__(256) void sched_window_kernel(SchedEvalArgs a)
+__device__ __forceinline__ long long sched_nm(const SchedEvalArgs &a, int r)
+{
+    const long long nm = a.n_moves[r];
+    return nm < 0 ? 0 : (nm > a.max_moves ? a.max_moves : nm);
+}
+
+// is move k a real (non-tabu, well-formed) candidate of the state held in s_state?
+__device__ __forceinline__ bool sched_counts(const SchedEvalArgs &a, const ls_sched_move *mv, long long k, long long nm,
+                                             const int *s_state)
+{
+    if (k >= nm) return false;
+    const ls_sched_move m = mv[k];
+    if (!sched_move_ok(m.type, m.a, m.b, a.in.S, a.in.n_employees)) return false;
+    return m.type == 0 ? (s_state[m.a] != m.b) : (s_state[m.a] != s_state[m.b]);
+}
+
+// Pass 1a: non-tabu moves per chunk of SC_COUNT_CHUNK (tabu candidates do not consume window,
+// local_search.rs:319-321).  grid = (n_chunks, n_restarts).
+__global__ __launch_bounds__(256) void sched_count_kernel(SchedEvalArgs a)
+{
+    __shared__ int s_state[64];
+    __shared__ int s_cnt[4];
+    const int r = blockIdx.y;
+    if (threadIdx.x < 64) s_state[threadIdx.x] = (int)threadIdx.x < a.in.S ? a.states[(long long)r * a.in.S + threadIdx.x] : -1;
+    __syncthreads();
+    const long long nm = sched_nm(a, r);
+    const ls_sched_move *mv = a.moves + (long long)r * a.max_moves;
+    const long long k0 = (long long)blockIdx.x * SC_COUNT_CHUNK;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < SC_COUNT_CHUNK / 256; i++) c += sched_counts(a, mv, k0 + i * 256 + threadIdx.x, nm, s_state) ? 1 : 0;
+    c = wave_sum_i32(c);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) a.chunk_counts[(long long)r * a.n_chunks + blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// Pass 1b: where does take(window) stop?  One block per restart: a block-wide prefix scan over
+// the chunk counts finds the chunk in which the running count reaches the window, then the exact
+// position inside that chunk is resolved with ballots.
+__global__ __launch_bounds__(256) void sched_locate_kernel(SchedEvalArgs a)
 {
     __shared__ int s_state[64];
     __shared__ int s_wcnt[4];
-    __shared__ long long s_found;
+    __shared__ int s_chunk;
+    __shared__ long long s_run, s_found;
     const int r = blockIdx.x;
-    const int S = a.in.S;
-    if (threadIdx.x < 64) s_state[threadIdx.x] = threadIdx.x < S ? a.states[(long long)r * S + threadIdx.x] : -1;
-    if (threadIdx.x == 0) s_found = -1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x < 64) s_state[threadIdx.x] = (int)threadIdx.x < a.in.S ? a.states[(long long)r * a.in.S + threadIdx.x] : -1;
+    if (threadIdx.x == 0) { s_chunk = -1; s_run = 0; s_found = -1; }
     __syncthreads();
-    long long nm = a.n_moves[r];
-    nm = nm < 0 ? 0 : (nm > a.max_moves ? a.max_moves : nm);
+    const long long nm = sched_nm(a, r);
     const ls_sched_move *mv = a.moves + (long long)r * a.max_moves;
-    long long run = 0;
-    long long k_end = nm;
-    if (a.window <= 0) { k_end = 0; }
-    else {
-        for (long long t = 0; t < nm; t += 256) {
-            const long long k = t + threadIdx.x;
-            bool flag = false;
-            if (k < nm) {
-                const ls_sched_move m = mv[k];
-                if (sched_move_ok(m, S, a.in.n_employees))
-                    flag = m.type == 0 ? (s_state[m.a] != m.b) : (s_state[m.a] != s_state[m.b]);
+    const int *counts = a.chunk_counts + (long long)r * a.n_chunks;
+    long long run = 0, k_end = nm;
+    if (a.window <= 0) {
+        k_end = 0;
+    } else {
+        if (a.n_chunks == 1 && threadIdx.x == 0) { s_chunk = 0; s_run = 0; } // no count pass was run
+        __syncthreads();
+        for (int t0 = 0; t0 < a.n_chunks && a.n_chunks > 1; t0 += 256) {
+            const int b = t0 + (int)threadIdx.x;
+            const int c = b < a.n_chunks ? counts[b] : 0;
+            int incl = c; // inclusive scan: wavefront, then across the four wavefronts
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
             }
-            const u64 bal = __ballot(flag);
-            const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-            if (lane == 0) s_wcnt[w] = __popcll(bal);
+            if (lane == 63) s_wcnt[w] = incl;
             __syncthreads();
             int before = 0, total = 0;
             for (int i = 0; i < 4; i++) {
                 if (i < w) before += s_wcnt[i];
                 total += s_wcnt[i];
             }
-            const int incl = before + __popcll(bal & ((2ull << lane) - 1));
-            if (flag && run + incl == a.window) s_found = k + 1;
+            incl += before;
+            // exactly one chunk has (count before it) < window <= (count through it)
+            if (b < a.n_chunks && run + incl - c < a.window && run + incl >= a.window) {
+                s_chunk = b;
+                s_run = run + incl - c;
+            }
             __syncthreads();
-            if (s_found >= 0) break;
+            if (s_chunk >= 0) break;
             run += total;
         }
-        if (s_found >= 0) { k_end = s_found; run = a.window; }
+        const int chunk = s_chunk;
+        if (chunk >= 0) {
+            run = s_run;
+            const long long base = (long long)chunk * SC_COUNT_CHUNK;
+            for (int t = 0; t < SC_COUNT_CHUNK; t += 256) {
+                const long long k = base + t + threadIdx.x;
+                const bool flag = sched_counts(a, mv, k, nm, s_state);
+                const u64 bal = __ballot(flag);
+                __syncthreads(); // s_wcnt is reused
+                if (lane == 0) s_wcnt[w] = __popcll(bal);
+                __syncthreads();
+                int before = 0, total = 0;
+                for (int i = 0; i < 4; i++) {
+                    if (i < w) before += s_wcnt[i];
+                    total += s_wcnt[i];
+                }
+                const int incl = before + __popcll(bal & ((2ull << lane) - 1));
+                if (flag && run + incl == a.window) s_found = k + 1;
+                __syncthreads();
+                if (s_found >= 0) break;
+                run += total;
+            }
+            if (s_found >= 0) { k_end = s_found; run = a.window; }
+        }
     }
     if (threadIdx.x == 0) {
         a.k_end[r] = k_end;
@@ -289,77 +332,148 @@ __device__ __forceinline__ u64 sc_edit_key(int pos, int newv, int basev)
     return ((u64)cls << 21) | ((u64)poskey << 15) | (unsigned)newv;
 }
 
-// Pass 2: one wavefront per candidate.
+__device__ __forceinline__ void sched_write_result(const SchedEvalArgs &a, int r, u64 bk, long long bi)
+{
+    ls_sched_result out;
+    out.n_scored = a.n_scored[r];
+    if (bk == SC_KEY_EMPTY) { out.best_index = -1; out.best_hard = 0; out.best_soft = 0; out.n_scored = 0; }
+    else {
+        out.best_index = bi;
+        out.best_hard = (long long)(bk >> 54);
+        out.best_soft = (long long)((bk >> 46) & 0xffu);
+    }
+    a.results[r] = out;
+}
+
+// Pass 2: score every non-tabu candidate k < k_end.
 __global__ __launch_bounds__(256) void sched_eval_kernel(SchedEvalArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = blockIdx.x % a.n_restarts;
-    const int wchunk = (blockIdx.x / a.n_restarts) * 4 + wib;
-    const int n_wchunks = (gridDim.x / a.n_restarts) * 4;
-    const int S = a.in.S;
-    const SchedLane L = sched_lane_init(a.in, lane);
-    const int base = lane < S ? a.states[(long long)r * S + lane] : -1 - lane;
+    const int wave = (blockIdx.x / a.n_restarts) * 4 + wib;
+    const int n_waves = (gridDim.x / a.n_restarts) * 4;
+    const int S = a.in.S, D = a.in.D, E = a.in.n_employees;
     const long long k_end = a.k_end[r];
+    const long long n_batches = ((k_end + 63) >> 6) * a.split; // work units: (batch, part)
+    __shared__ u64 s_key[4];
+    __shared__ long long s_idx[4];
+    u64 best_key = SC_KEY_EMPTY; // this lane's running minimum (key, index)
+    long long best_idx = -1;
+    if (wave < n_batches) {
+    const SchedLaneConst L = a.in.lane_tab[lane];
+    const int base = lane < S ? a.states[(long long)r * S + lane] : -1 - lane;
+    const u64 eq_base = sched_build_eq(D, base) & L.scored_mask;
+    const int hb_base = sched_holiday_bit(a.in, base, lane);
     const ls_sched_move *mv = a.moves + (long long)r * a.max_moves;
-    u64 *keys = a.keys + (long long)r * a.max_moves;
-    const long long k0 = a.max_moves * wchunk / n_wchunks;
-    const long long k1 = a.max_moves * (wchunk + 1) / n_wchunks;
-    for (long long k = k0; k < k1; k++) {
-        u64 key = SC_KEY_EMPTY;
-        if (k < k_end) {
-            ls_sched_move m = mv[k];
-            m.type = __builtin_amdgcn_readfirstlane(m.type);
-            m.a = __builtin_amdgcn_readfirstlane(m.a);
-            m.b = __builtin_amdgcn_readfirstlane(m.b);
-            if (sched_move_ok(m, S, a.in.n_employees)) {
-                const int ea = __builtin_amdgcn_readlane(base, m.a);
-                int na, nb, pb;
-                if (m.type == 0) { na = m.b; pb = m.a; nb = m.b; }
-                else { const int eb = __builtin_amdgcn_readlane(base, m.b); na = eb; pb = m.b; nb = ea; }
-                const int eb0 = __builtin_amdgcn_readlane(base, pb);
-                if (na != ea || nb != eb0) { // not tabu
-                    int e = base;
-                    if (lane == m.a) e = na;
-                    if (lane == pb) e = nb;
-                    const SchedScore sc = sched_score_wave<false>(a.in, L, e);
-                    u64 e1, e2 = (u64)1 << 21; // "no second edit"
-                    if (m.type == 0) e1 = sc_edit_key(m.a, na, ea);
-                    else {
-                        const int p1 = m.a < m.b ? m.a : m.b, p2 = m.a < m.b ? m.b : m.a;
-                        const int v1 = m.a < m.b ? na : nb, b1 = m.a < m.b ? ea : eb0;
-                        const int v2 = m.a < m.b ? nb : na, b2 = m.a < m.b ? eb0 : ea;
-                        e1 = sc_edit_key(p1, v1, b1);
-                        e2 = sc_edit_key(p2, v2, b2);
-                    }
-                    key = ((u64)(unsigned)sc.hard << 54) | ((u64)(unsigned)sc.soft << 46) | (e1 << 23) | e2;
-                    if (lane == 0) {
-                        if (a.hard_out) a.hard_out[(long long)r * a.max_moves + k] = sc.hard;
-                        if (a.soft_out) a.soft_out[(long long)r * a.max_moves + k] = sc.soft;
-                    }
-                }
+
+    for (long long unit = wave; unit < n_batches; unit += n_waves) {
+        const long long batch = unit / a.split;
+        const int part = (int)(unit % a.split);
+        const long long k = (batch << 6) + lane;
+        // ---- per-lane: this lane's move, its edit, its holiday bits, its half of the key
+        int type = -1, ma = 0, mb = 0;
+        if (k < k_end) { const ls_sched_move m = mv[k]; type = m.type; ma = m.a; mb = m.b; }
+        const bool ok = sched_move_ok(type, ma, mb, S, E);
+        const int ia = ok ? ma : 0, ib = (ok && type == 1) ? mb : ia;
+        const int ea = __shfl(base, ia, 64), eb = __shfl(base, ib, 64);
+        // ChangeDay: day a <- employee b (lib.rs:466-470);  SwapDays: a <- e[b], b <- e[a] (:471-478)
+        const int pos1 = ia, new1 = type == 0 ? mb : eb;
+        const int pos2 = ib, new2 = type == 0 ? mb : ea;
+        // candidate != current (tabu, local_search.rs:319); with split > 1 this wavefront takes every split-th lane
+        const bool active = ok && !(new1 == ea && new2 == eb) && (lane & (a.split - 1)) == part;
+        int hbits = 0;
+        u64 lowkey = 0;
+        if (active) {
+            hbits = sched_holiday_bit(a.in, new1, pos1) | (sched_holiday_bit(a.in, new2, pos2) << 1);
+            u64 e1, e2 = (u64)1 << 21; // "no second edit" sorts between lowering and raising edits
+            if (type == 0) e1 = sc_edit_key(pos1, new1, ea);
+            else {
+                const bool a_first = pos1 < pos2;
+                e1 = a_first ? sc_edit_key(pos1, new1, ea) : sc_edit_key(pos2, new2, eb);
+                e2 = a_first ? sc_edit_key(pos2, new2, eb) : sc_edit_key(pos1, new1, ea);
             }
+            lowkey = (e1 << 23) | e2;
         }
-        if (lane == 0) keys[k] = key;
+        const int packed = pos1 | (pos2 << 8) | (hbits << 16);
+        int my_hs = 0;
+        // ---- wave: one non-tabu candidate of the batch at a time
+        u64 todo = __ballot(active);
+        while (todo) {
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int pk = __builtin_amdgcn_readlane(packed, j);
+            const int n1 = __builtin_amdgcn_readlane(new1, j), n2 = __builtin_amdgcn_readlane(new2, j);
+            const int p1 = pk & 0xff, p2 = (pk >> 8) & 0xff;
+            int e = base;
+            if (lane == p1) e = n1;
+            if (lane == p2) e = n2;
+            const bool c1 = e == n1, c2 = e == n2;
+            const u64 m1 = __ballot(c1) & L.scored_mask, m2 = __ballot(c2) & L.scored_mask;
+            const u64 bit1 = p1 < D ? 1ull << p1 : 0, bit2 = p2 < D ? 1ull << p2 : 0;
+            u64 eq = eq_base & ~(bit1 | bit2);
+            if (c1) eq |= bit1;
+            if (c2) eq |= bit2;
+            if (lane == p1) eq = m1;
+            if (lane == p2) eq = m2;
+            int hb = hb_base;
+            if (lane == p1) hb = (pk >> 16) & 1;
+            if (lane == p2) hb = (pk >> 17) & 1;
+            const SchedScore sc = sched_terms<false>(D, L, lane, eq, hb);
+            if (lane == j) my_hs = (sc.hard << 8) | sc.soft;
+        }
+        // ---- per-lane: assemble and store (coalesced)
+        if (active) {
+            const int hard = my_hs >> 8, soft = my_hs & 0xff;
+            const u64 key = ((u64)(unsigned)hard << 54) | ((u64)(unsigned)soft << 46) | lowkey;
+            if (key < best_key) { best_key = key; best_idx = k; } // ascending k per lane: first of equals kept
+            if (a.hard_out) a.hard_out[(long long)r * a.max_moves + k] = hard;
+            if (a.soft_out) a.soft_out[(long long)r * a.max_moves + k] = soft;
+        }
+    }
+    }
+    // minimum (key, index) of the wavefront, then of the block
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned klo = __shfl_xor((unsigned)best_key, m, 64), khi = __shfl_xor((unsigned)(best_key >> 32), m, 64);
+        const unsigned ilo = __shfl_xor((unsigned)best_idx, m, 64), ihi = __shfl_xor((unsigned)((u64)best_idx >> 32), m, 64);
+        const u64 ok = ((u64)khi << 32) | klo;
+        const long long oi = (long long)(((u64)ihi << 32) | ilo);
+        if (ok < best_key || (ok == best_key && ok != SC_KEY_EMPTY && oi < best_idx)) { best_key = ok; best_idx = oi; }
+    }
+    if (lane == 0) { s_key[wib] = best_key; s_idx[wib] = best_idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; i++)
+            if (s_key[i] < best_key || (s_key[i] == best_key && best_key != SC_KEY_EMPTY && s_idx[i] < best_idx)) {
+                best_key = s_key[i]; best_idx = s_idx[i];
+            }
+        if (a.blocks_per_restart == 1) {
+            sched_write_result(a, r, best_key, best_idx);
+        } else {
+            const long long slot = (long long)r * a.blocks_per_restart + blockIdx.x / a.n_restarts;
+            a.part_key[slot] = best_key;
+            a.part_idx[slot] = best_idx;
+        }
     }
 }
 
-// Pass 3: minimum (key, index) per restart.
-__global__ __launch_bounds__(256) void sched_reduce_kernel(SchedEvalArgs a, ls_sched_result *results)
+
+// Pass 3: minimum (key, index) over the per-block minima of pass 2.
+__global__ __launch_bounds__(256) void sched_reduce_kernel(SchedEvalArgs a)
 {
     __shared__ u64 s_key[4];
     __shared__ long long s_idx[4];
     const int r = blockIdx.x;
-    long long nm = a.n_moves[r];
-    nm = nm < 0 ? 0 : (nm > a.max_moves ? a.max_moves : nm);
-    const u64 *keys = a.keys + (long long)r * a.max_moves;
+    const u64 *pk = a.part_key + (long long)r * a.blocks_per_restart;
+    const long long *pi = a.part_idx + (long long)r * a.blocks_per_restart;
     u64 bk = SC_KEY_EMPTY;
     long long bi = -1;
-    for (long long k = threadIdx.x; k < nm; k += 256) {
-        const u64 key = keys[k];
-        if (key < bk) { bk = key; bi = k; } // ascending k per thread: first of equals kept
+    for (int p = threadIdx.x; p < a.blocks_per_restart; p += 256) {
+        const u64 key = pk[p];
+        const long long idx = pi[p];
+        if (key < bk || (key == bk && key != SC_KEY_EMPTY && idx < bi)) { bk = key; bi = idx; }
     }
-    // wave reduce on (key, idx)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const unsigned klo = __shfl_xor((unsigned)bk, m, 64), khi = __shfl_xor((unsigned)(bk >> 32), m, 64);
@@ -373,15 +487,7 @@ __global__ __launch_bounds__(256) void sched_reduce_kernel(SchedEvalArgs a, ls_s
     if (threadIdx.x == 0) {
         for (int i = 1; i < 4; i++)
             if (s_key[i] < bk || (s_key[i] == bk && bk != SC_KEY_EMPTY && s_idx[i] < bi)) { bk = s_key[i]; bi = s_idx[i]; }
-        ls_sched_result out;
-        out.n_scored = a.n_scored[r];
-        if (bk == SC_KEY_EMPTY) { out.best_index = -1; out.best_hard = 0; out.best_soft = 0; out.n_scored = 0; }
-        else {
-            out.best_index = bi;
-            out.best_hard = (long long)(bk >> 54);
-            out.best_soft = (long long)((bk >> 46) & 0xffu);
-        }
-        results[r] = out;
+        sched_write_result(a, r, bk, bi);
     }
 }
 
@@ -391,9 +497,9 @@ static SchedInst make_inst(const ls_ctx *ctx)
     SchedInst in;
     in.D = ctx->sched.n_days_scored;
     in.S = ctx->sched.n_days_stored;
-    in.start_weekday = ctx->sched.start_weekday;
     in.n_employees = ctx->sched.n_employees;
     in.holiday_bits = ctx->sched.holiday_bits.as<u64>();
+    in.lane_tab = ctx->sched.lane_tab.as<SchedLaneConst>();
     return in;
 }
 
@@ -417,41 +523,56 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
     if (ctx->sched.n_employees > 32768)
         return set_err(ctx, LS_ERR_UNSUPPORTED, "n_employees = %d exceeds the 15-bit argmin key field (32768)",
                        ctx->sched.n_employees);
-    LS_RESERVE(ctx, ctx->sc_keys, (size_t)n_restarts * (max_moves > 0 ? max_moves : 1) * 8 + (size_t)n_restarts * 16);
+    const long long n_chunks = max_moves > 0 ? (max_moves + SC_COUNT_CHUNK - 1) / SC_COUNT_CHUNK : 1;
+    if (n_chunks > 65535 * 16)
+        return set_err(ctx, LS_ERR_UNSUPPORTED, "max_moves = %lld is too large", max_moves);
+    // one wavefront per batch of 64 candidates, never more blocks than the chip holds at once
+    const long long batches = max_moves > 0 ? (max_moves + 63) / 64 : 1;
+    const int split = batches * n_restarts >= 4096 ? 1 : 4; // few batches: spread each over four wavefronts
+    long long bpr = (batches * split + 3) / 4;
+    const long long cap = ((long long)ctx->n_cus * 8) / n_restarts;
+    if (bpr > cap) bpr = cap;
+    if (bpr < 1) bpr = 1;
+    // workspace: k_end[R] | n_scored[R] | part_key[R][bpr] | part_idx[R][bpr] | chunk_counts[R][n_chunks]
+    const size_t parts = (size_t)n_restarts * (size_t)bpr;
+    LS_RESERVE(ctx, ctx->sc_keys, (size_t)n_restarts * 16 + parts * 16 + (size_t)n_restarts * n_chunks * 4);
     SchedEvalArgs a;
     a.in = make_inst(ctx);
     a.n_restarts = n_restarts;
     a.states = states_d; a.moves = moves_d; a.n_moves = n_moves_d;
     a.max_moves = max_moves; a.window = window;
-    // layout of sc_keys: k_end[n_restarts] | n_scored[n_restarts] | keys[n_restarts][max_moves]
     a.k_end = ctx->sc_keys.as<long long>();
     a.n_scored = a.k_end + n_restarts;
-    a.keys = reinterpret_cast<u64 *>(a.n_scored + n_restarts);
+    a.blocks_per_restart = (int)bpr;
+    a.split = split;
+    a.part_key = reinterpret_cast<u64 *>(a.n_scored + n_restarts);
+    a.part_idx = reinterpret_cast<long long *>(a.part_key + parts);
+    a.n_chunks = (int)n_chunks;
+    a.chunk_counts = reinterpret_cast<int *>(a.part_idx + parts);
     a.hard_out = hard_out_d; a.soft_out = soft_out_d;
+    a.results = results_d;
     const long long total = (long long)n_restarts * max_moves;
+    const unsigned fill_grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (hard_out_d && total > 0) {
-        hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
-                           dim3(256), 0, ctx->stream, hard_out_d, (long long)INT64_MIN, total);
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream, hard_out_d, (long long)INT64_MIN, total);
         LS_HIP(ctx, hipGetLastError());
     }
     if (soft_out_d && total > 0) {
-        hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
-                           dim3(256), 0, ctx->stream, soft_out_d, (long long)INT64_MIN, total);
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream, soft_out_d, (long long)INT64_MIN, total);
         LS_HIP(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(sched_window_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a);
-    LS_HIP(ctx, hipGetLastError());
-    if (max_moves > 0) {
-        long long want_waves = (max_moves + 3) / 4; // >= 4 candidates per wavefront
-        long long bpr = (want_waves + 3) / 4;
-        const long long cap = ((long long)ctx->n_cus * 8) / n_restarts;
-        if (bpr > cap) bpr = cap;
-        if (bpr < 1) bpr = 1;
-        hipLaunchKernelGGL(sched_eval_kernel, dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
+    if (n_chunks > 1) { // a single chunk is counted by the locate pass itself
+        hipLaunchKernelGGL(sched_count_kernel, dim3((unsigned)n_chunks, (unsigned)n_restarts), dim3(256), 0, ctx->stream, a);
         LS_HIP(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(sched_reduce_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a, results_d);
+    hipLaunchKernelGGL(sched_locate_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a);
     LS_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(sched_eval_kernel, dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
+    LS_HIP(ctx, hipGetLastError());
+    if (bpr > 1) { // with one block per restart pass 2 has already written the result
+        hipLaunchKernelGGL(sched_reduce_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a);
+        LS_HIP(ctx, hipGetLastError());
+    }
     return LS_OK;
 }
 
