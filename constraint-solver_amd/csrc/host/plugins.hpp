@@ -4,7 +4,9 @@
 // every score and every neighbourhood goes through the C ABI to the HIP kernels.
 #pragma once
 
+#include <condition_variable>
 #include <cstdint>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -20,6 +22,111 @@ inline void check_rc(ls_ctx *ctx, int rc, const char *what)
     if (rc != LS_OK) throw std::runtime_error(std::string(what) + ": " + ls_last_error(ctx));
 }
 
+// Lockstep batching of independent restarts: every restart runs the unchanged
+// driver on its own host thread; its GPU requests park here until every live restart has one
+// pending, then ONE batched launch serves them all.  Results are independent of the batching.
+struct NqRequest {
+    int kind; // 0 = column scores (+ total), 1 = neighbourhood
+    const int32_t *rows;
+    int64_t cur_score;
+    const int32_t *cols;
+    int32_t n_cols;
+    int64_t window;
+    int64_t *col_scores_out;
+    int64_t *total_out;
+    ls_nq_result *result_out;
+    bool done;
+};
+
+class NqBatcher {
+public:
+    NqBatcher(ls_ctx *ctx, int32_t n, int live) : ctx_(ctx), n_(n), live_(live) {}
+    void submit(NqRequest *r)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        r->done = false;
+        pending_.push_back(r);
+        if ((int)pending_.size() == live_) flush_locked();
+        else cv_.wait(lk, [&] { return r->done || !error_.empty(); });
+        if (!error_.empty()) throw std::runtime_error(error_);
+    }
+    void thread_done()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        live_--;
+        if (live_ > 0 && (int)pending_.size() == live_) flush_locked();
+    }
+    void fail(const std::string &msg)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        if (error_.empty()) error_ = msg;
+        cv_.notify_all();
+    }
+    uint64_t launches = 0;
+
+private:
+    void flush_locked()
+    {
+        try {
+            if (!error_.empty()) throw std::runtime_error(error_); // a restart failed: release everyone
+            std::vector<NqRequest *> cs, ev;
+            for (NqRequest *r : pending_) (r->kind == 0 ? cs : ev).push_back(r);
+            if (!cs.empty()) {
+                const size_t R = cs.size();
+                rows_.resize(R * n_);
+                colscores_.resize(R * n_);
+                totals_.resize(R);
+                for (size_t i = 0; i < R; i++) std::copy(cs[i]->rows, cs[i]->rows + n_, rows_.begin() + i * n_);
+                check_rc(ctx_, ls_nqueens_col_scores(ctx_, (int32_t)R, n_, rows_.data(), colscores_.data(), totals_.data()),
+                         "ls_nqueens_col_scores");
+                launches++;
+                for (size_t i = 0; i < R; i++) {
+                    if (cs[i]->col_scores_out)
+                        std::copy(colscores_.begin() + i * n_, colscores_.begin() + (i + 1) * n_, cs[i]->col_scores_out);
+                    if (cs[i]->total_out) *cs[i]->total_out = totals_[i];
+                }
+            }
+            if (!ev.empty()) {
+                const size_t R = ev.size();
+                int32_t max_cols = 1;
+                for (NqRequest *r : ev) max_cols = r->n_cols > max_cols ? r->n_cols : max_cols;
+                rows_.resize(R * n_);
+                cols_.assign(R * max_cols, 0);
+                ncols_.resize(R);
+                cur_.resize(R);
+                results_.resize(R);
+                for (size_t i = 0; i < R; i++) {
+                    std::copy(ev[i]->rows, ev[i]->rows + n_, rows_.begin() + i * n_);
+                    std::copy(ev[i]->cols, ev[i]->cols + ev[i]->n_cols, cols_.begin() + i * max_cols);
+                    ncols_[i] = ev[i]->n_cols;
+                    cur_[i] = ev[i]->cur_score;
+                    if (ev[i]->window != ev[0]->window) throw std::runtime_error("restarts of one batch must share the window size");
+                }
+                check_rc(ctx_, ls_nqueens_eval_batch(ctx_, (int32_t)R, n_, rows_.data(), cur_.data(), cols_.data(), ncols_.data(),
+                                                     max_cols, ev[0]->window, results_.data(), nullptr),
+                         "ls_nqueens_eval_batch");
+                launches++;
+                for (size_t i = 0; i < R; i++) *ev[i]->result_out = results_[i];
+            }
+        } catch (const std::exception &e) {
+            if (error_.empty()) error_ = e.what();
+        }
+        for (NqRequest *r : pending_) r->done = true;
+        pending_.clear();
+        cv_.notify_all();
+    }
+    ls_ctx *ctx_;
+    int32_t n_;
+    int live_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<NqRequest *> pending_;
+    std::string error_;
+    std::vector<int32_t> rows_, cols_, ncols_;
+    std::vector<int64_t> cur_, colscores_, totals_;
+    std::vector<ls_nq_result> results_;
+};
+
 // =================================================================== N-queens
 struct NQueensProblem {
     using Solution = std::vector<int64_t>; // rows[col] = row, Integer = i64 (lib.rs:13-21)
@@ -29,10 +136,11 @@ struct NQueensProblem {
 
     ls_ctx *ctx;
     size_t board_size;
+    NqBatcher *batcher = nullptr; // set when this restart is one of a lockstep batch
     // statistics
     uint64_t neighbours_scored = 0, gpu_evals = 0;
 
-    NQueensProblem(ls_ctx *c, size_t n) : ctx(c), board_size(n) {}
+    NQueensProblem(ls_ctx *c, size_t n, NqBatcher *b = nullptr) : ctx(c), board_size(n), batcher(b) {}
 
     std::vector<int32_t> pack(const Solution &s) const
     {
@@ -56,7 +164,11 @@ struct NQueensProblem {
         const std::vector<int32_t> rows = pack(s);
         std::vector<int64_t> cs(s.size());
         int64_t tot = 0;
-        check_rc(ctx, ls_nqueens_col_scores(ctx, 1, (int32_t)s.size(), rows.data(), cs.data(), &tot), "ls_nqueens_col_scores");
+        if (batcher) {
+            NqRequest rq{0, rows.data(), 0, nullptr, 0, 0, cs.data(), &tot, nullptr, false};
+            batcher->submit(&rq);
+        } else
+            check_rc(ctx, ls_nqueens_col_scores(ctx, 1, (int32_t)s.size(), rows.data(), cs.data(), &tot), "ls_nqueens_col_scores");
         if (total) *total = tot;
         return cs;
     }
@@ -101,8 +213,13 @@ struct NQueensProblem {
         if (cols.empty()) return false;
         const std::vector<int32_t> rows = pack(current.solution);
         ls_nq_result res;
-        check_rc(ctx, ls_nqueens_eval(ctx, (int32_t)rows.size(), rows.data(), current.score, cols.data(),
-                                      (int32_t)cols.size(), (int64_t)window, &res, nullptr), "ls_nqueens_eval");
+        if (batcher) {
+            NqRequest rq{1, rows.data(), current.score, cols.data(), (int32_t)cols.size(), (int64_t)window, nullptr, nullptr,
+                         &res, false};
+            batcher->submit(&rq);
+        } else
+            check_rc(ctx, ls_nqueens_eval(ctx, (int32_t)rows.size(), rows.data(), current.score, cols.data(),
+                                          (int32_t)cols.size(), (int64_t)window, &res, nullptr), "ls_nqueens_eval");
         gpu_evals++;
         neighbours_scored += (uint64_t)res.n_scored;
         if (res.best_index < 0) return false;

@@ -1,8 +1,10 @@
 // ls_solver.hip — C entry points for the whole-solver view (include/ls_amd.h, "whole solver"):
 // the host driver of csrc/host/ wired to the GPU path of this library.  Plain host C++; it is a
 // .hip file only so that the one hipcc invocation style builds everything.
+#include <chrono>
 #include <memory>
 #include <new>
+#include <thread>
 
 #include "host/plugins.hpp"
 #include "ls_common.hpp"
@@ -16,6 +18,16 @@ struct ls_solver {
     std::unique_ptr<IteratedLocalSearch<NQueensProblem>> nq_ils;
     std::unique_ptr<SchedProblem> sc;
     std::unique_ptr<IteratedLocalSearch<SchedProblem>> sc_ils;
+};
+
+struct ls_multi_solver {
+    ls_ctx *ctx = nullptr;
+    ls_solver_params params{};
+    size_t board_size = 0;
+    std::vector<std::string> seeds;
+    std::vector<ScoredSolution<NQueensProblem>> best;
+    std::vector<int> have;
+    uint64_t ls_iterations = 0, neighbours_scored = 0, gpu_launches = 0, rounds = 0;
 };
 
 namespace {
@@ -195,6 +207,117 @@ int ls_solver_get_stats(const ls_solver *s, uint64_t *ls_iterations, uint64_t *n
 int ls_solver_free(ls_solver *s)
 {
     delete s;
+    return LS_OK;
+}
+
+int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_restarts, const char *const *seeds,
+                                   const ls_solver_params *params, ls_multi_solver **out)
+{
+    if (!ctx || !out || !seeds || n_restarts < 1) return LS_ERR_INVALID;
+    *out = nullptr;
+    int rc = check_params(ctx, params);
+    if (rc != LS_OK) return rc;
+    if (board_size < 1 || board_size > LS_NQ_MAX_N)
+        return lsamd::set_err(ctx, LS_ERR_UNSUPPORTED, "board_size %llu outside [1, %d]", (unsigned long long)board_size,
+                              LS_NQ_MAX_N);
+    return guarded(ctx, [&]() {
+        std::unique_ptr<ls_multi_solver> m(new ls_multi_solver());
+        m->ctx = ctx;
+        m->params = *params;
+        m->board_size = (size_t)board_size;
+        for (int32_t r = 0; r < n_restarts; r++) {
+            if (!seeds[r]) throw std::runtime_error("seed is NULL");
+            m->seeds.emplace_back(seeds[r]);
+        }
+        m->best.resize((size_t)n_restarts);
+        m->have.assign((size_t)n_restarts, 0);
+        *out = m.release();
+        return LS_OK;
+    });
+}
+
+int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, double max_seconds)
+{
+    if (!m) return LS_ERR_INVALID;
+    return guarded(m->ctx, [&]() {
+        const int R = (int)m->seeds.size();
+        NqBatcher batcher(m->ctx, (int32_t)m->board_size, R);
+        std::vector<std::string> errors((size_t)R);
+        std::vector<uint64_t> ls_it((size_t)R, 0), scored((size_t)R, 0), rounds((size_t)R, 0);
+        const auto t0 = std::chrono::steady_clock::now();
+        auto worker = [&](int r) {
+            try {
+                const ls_solver_params &p = m->params;
+                NQueensProblem problem(m->ctx, m->board_size, &batcher);
+                const ChaCha20Rng solver_rng = ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]);
+                const ChaCha20Rng ils_rng = ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]);
+                LocalSearch<NQueensProblem> ls(&problem, p.local_search_max_iterations, (size_t)p.window_size,
+                                               (size_t)p.best_solutions_capacity, (size_t)p.all_solutions_capacity,
+                                               p.all_solution_iteration_expiry, solver_rng);
+                History<NQueensProblem> history((size_t)p.best_solutions_capacity, (size_t)p.all_solutions_capacity,
+                                                p.all_solution_iteration_expiry);
+                IteratedLocalSearch<NQueensProblem> ils(&problem, std::move(ls), std::move(history),
+                                                        p.iterated_local_search_max_iterations,
+                                                        p.max_allow_no_improvement_for, ils_rng);
+                while (!ils.is_finished() && rounds[(size_t)r] < max_rounds_per_restart) {
+                    ils.execute_round();
+                    rounds[(size_t)r]++;
+                    ScoredSolution<NQueensProblem> b;
+                    if (ils.get_best_solution(b) && NQueensProblem::is_best(b.score)) break; // later rounds are no-ops
+                    if (max_seconds > 0 &&
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > max_seconds)
+                        break;
+                }
+                ScoredSolution<NQueensProblem> b;
+                if (ils.get_best_solution(b)) { m->best[(size_t)r] = b; m->have[(size_t)r] = 1; }
+                ls_it[(size_t)r] = ils.ls_iterations();
+                scored[(size_t)r] = problem.neighbours_scored;
+            } catch (const std::exception &e) {
+                errors[(size_t)r] = e.what();
+                batcher.fail(e.what());
+            }
+            batcher.thread_done();
+        };
+        std::vector<std::thread> threads;
+        for (int r = 0; r < R; r++) threads.emplace_back(worker, r);
+        for (auto &t : threads) t.join();
+        for (const std::string &e : errors)
+            if (!e.empty()) throw std::runtime_error(e);
+        m->ls_iterations = m->neighbours_scored = m->rounds = 0;
+        for (int r = 0; r < R; r++) {
+            m->ls_iterations += ls_it[(size_t)r];
+            m->neighbours_scored += scored[(size_t)r];
+            m->rounds += rounds[(size_t)r];
+        }
+        m->gpu_launches = batcher.launches;
+        return LS_OK;
+    });
+}
+
+int ls_multi_solver_get_best(const ls_multi_solver *m, int32_t restart, int64_t score[2], int64_t *solution, int32_t cap,
+                             int32_t *len, int *have)
+{
+    if (!m || !score || restart < 0 || (size_t)restart >= m->seeds.size()) return LS_ERR_INVALID;
+    if (have) *have = m->have[(size_t)restart];
+    if (!m->have[(size_t)restart]) { if (len) *len = 0; return LS_OK; }
+    score[0] = m->best[(size_t)restart].score; score[1] = 0;
+    return copy_solution(m->best[(size_t)restart].solution, solution, cap, len);
+}
+
+int ls_multi_solver_get_stats(const ls_multi_solver *m, uint64_t *ls_iterations, uint64_t *neighbours_scored,
+                              uint64_t *gpu_launches, uint64_t *rounds)
+{
+    if (!m) return LS_ERR_INVALID;
+    if (ls_iterations) *ls_iterations = m->ls_iterations;
+    if (neighbours_scored) *neighbours_scored = m->neighbours_scored;
+    if (gpu_launches) *gpu_launches = m->gpu_launches;
+    if (rounds) *rounds = m->rounds;
+    return LS_OK;
+}
+
+int ls_multi_solver_free(ls_multi_solver *m)
+{
+    delete m;
     return LS_OK;
 }
 

@@ -266,6 +266,47 @@ class Solver:
         return dict(ls_iterations=a.value, neighbours_scored=b.value, gpu_evals=c.value)
 
 
+class MultiSolver:
+    """ls_multi_solver: R independent N-queens restarts on one GPU in lockstep (one batched launch
+    per step); each restart's result equals running it alone."""
+
+    def __init__(self, ctx: Context, board_size: int, seeds, params: dict):
+        self._ctx, self._l, self.n, self.seeds = ctx, ctx._l, int(board_size), [str(s) for s in seeds]
+        arr = (C.c_char_p * len(self.seeds))(*[s.encode() for s in self.seeds])
+        h = C.c_void_p()
+        p = _params(params)
+        ctx._check(self._l.ls_multi_solver_create_nqueens(ctx._h, self.n, len(self.seeds), C.cast(arr, C.c_void_p),
+                                                          C.byref(p), C.byref(h)))
+        self._h = h
+
+    def run(self, max_rounds_per_restart=2 ** 62, max_seconds=0.0):
+        self._ctx._check(self._l.ls_multi_solver_run(self._h, int(max_rounds_per_restart), float(max_seconds)))
+
+    def best(self, restart: int):
+        sc = np.zeros(2, dtype=np.int64)
+        sol = np.zeros(self.n, dtype=np.int64)
+        n, have = C.c_int32(), C.c_int()
+        self._ctx._check(self._l.ls_multi_solver_get_best(self._h, int(restart), _vp(sc), _vp(sol), self.n, C.byref(n),
+                                                          C.byref(have)))
+        return (int(sc[0]), tuple(int(x) for x in sol[:n.value])) if have.value else None
+
+    def stats(self):
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._ctx._check(self._l.ls_multi_solver_get_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(ls_iterations=a.value, neighbours_scored=b.value, gpu_launches=c.value, rounds=d.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.ls_multi_solver_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # host RNG primitives (no GPU needed)
 def host_hash_seed(seed: str) -> bytes:
     out = (C.c_uint8 * 32)()

@@ -265,6 +265,23 @@ int ls_solver_get_current_solution(const ls_solver *s, int64_t score[2], int64_t
 int ls_solver_get_stats(const ls_solver *s, uint64_t *ls_iterations, uint64_t *neighbours_scored, uint64_t *gpu_evals);
 int ls_solver_free(ls_solver *s);
 
+/* Many independent restarts on one GPU, in lockstep (the reference's only
+ * multi-seed convention is consecutive seed strings, examples/nqueens/src/main.rs:167).  Each
+ * restart is a complete, unchanged solver on its own host thread; their GPU requests are served
+ * by ONE batched launch per step (ls_nqueens_eval_batch / ls_nqueens_col_scores), so the result
+ * of every restart is identical to running it alone.  ls_multi_solver_run drives all restarts
+ * until each is finished, has found a best-possible solution, or a limit is reached. */
+typedef struct ls_multi_solver ls_multi_solver;
+int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_restarts, const char *const *seeds,
+                                   const ls_solver_params *params, ls_multi_solver **out);
+int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, double max_seconds);
+int ls_multi_solver_get_best(const ls_multi_solver *m, int32_t restart, int64_t score[2], int64_t *solution,
+                             int32_t cap, int32_t *len, int *have);
+/* totals over all restarts: LS iterations, candidates scored, batched GPU launches, rounds executed */
+int ls_multi_solver_get_stats(const ls_multi_solver *m, uint64_t *ls_iterations, uint64_t *neighbours_scored,
+                              uint64_t *gpu_launches, uint64_t *rounds);
+int ls_multi_solver_free(ls_multi_solver *m);
+
 /* Host RNG primitives, exported so the tests can pin them (RFC 7693 / RFC 7539 vectors, and
  * the oracle's independent restatement).  ls_host_rng_script runs `n_ops` operations
  * (op, a, b) on a ChaCha20Rng::from_seed(seed32) and appends every produced value to `out`:

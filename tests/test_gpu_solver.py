@@ -132,3 +132,35 @@ def test_solver_api_edges(ctx):
         s.execute_round()
     assert s.is_finished()
     s.close()
+
+
+def test_multi_restart_lockstep_equals_single_runs(ctx):
+    # restarts are independent; batching their launches must not change any result
+    import ls_amd
+    n, rounds = 64, 5
+    seeds = [str(s) for s in range(42, 48)]
+    p = _nq_params(n)
+    singles = []
+    for seed in seeds:
+        s = ls_amd.Solver.nqueens(ctx, n, seed, p)
+        for _ in range(rounds):
+            s.execute_round()
+            b = s.best()
+            if b is not None and b[0] == 0:
+                break
+        singles.append(s.best())
+        s.close()
+    m = ls_amd.MultiSolver(ctx, n, seeds, p)
+    m.run(max_rounds_per_restart=rounds)
+    assert [m.best(r) for r in range(len(seeds))] == singles
+    st = m.stats()
+    assert st["gpu_launches"] < 2 * st["ls_iterations"]            # launches are shared between restarts
+    m.close()
+    # oracle cross-check of one of them
+    o = lo.IteratedLocalSearch(lo.NQueens(n), p, seeds[1])
+    for _ in range(rounds):
+        o.execute_round()
+        b = o.get_best_solution()
+        if b is not None and b[0] == 0:
+            break
+    assert o.get_best_solution() == singles[1]
