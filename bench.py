@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse ranks on one GPU)")
+    ap.add_argument("--all-on-device", type=int, default=None,
+                    help="rehearsal only: put every rank on this one device (use with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -88,11 +91,17 @@ def main():
             print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the evaluator has no CPU fallback")
+    if args.all_on_device is not None:
+        local_rank = args.all_on_device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     n, R = args.n, args.restarts_per_gpu
     # restart r -> rank r mod world; R restarts per GPU
@@ -142,7 +151,7 @@ def main():
     elapsed = time.perf_counter() - t0
     launch_ms = [a.elapsed_time(b) for a, b in ev]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -194,11 +203,16 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
-                "kernel": "nq_scan_regs_kernel<64>" if (args.algo == "scan" and 2048 < n <= 4096) else f"nq_{args.algo}",
+                "kernel": ("nq_scan_regs_kernel<BoardF32<64>, false>" if (args.algo == "scan" and 2048 < n <= 4096)
+                           else ("nq_table_eval_kernel" if args.algo == "table" else "nq_scan_*")),
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "algorithmic_bytes_per_neighbour": bpn,
                 "note": "algorithmic bytes per SURVEY 8(d) (4n+16 per neighbour); the 16 KiB state is shared by all "
-                        "candidates of a restart and is held in registers/LDS, so the effective rate can exceed the HBM peak",
+                        "candidates of a restart and is held in registers, so the effective rate exceeds the HBM peak; the "
+                        "kernel's real limiter is VALU issue (4 fp32 instructions per candidate and column), see DESIGN.md 3.1",
+                "issue_bound": {"instr_per_neighbour": 4 * n, "ns_per_instr_per_simd": 0.92, "simds": 4 * info["n_cus"],
+                                "neighbours_per_s_at_bound": 4 * info["n_cus"] / (4 * n * 0.92e-9),
+                                "frac_of_issue_bound": value / (4 * info["n_cus"] / (4 * n * 0.92e-9))},
             },
             "global_best": {"score": best[0][0], "restart": best[2]},
         }
