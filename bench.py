@@ -187,7 +187,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32",
+            "dtype": "f32" if args.algo == "scan" and n <= 4096 else "int32",
             "data": "synthetic",
             "config": {
                 "workload": f"nqueens n={n}, {R} independent restarts per GPU ({R * world} total, restart r on rank r mod {world}), "
@@ -195,6 +195,8 @@ def main():
                             f"uniform-random boards seeded by restart id, algo={args.algo}",
                 "n": n, "restarts_per_gpu": R, "neighbours_per_step_per_gpu": neighbours_per_step,
                 "algo": args.algo, "device": info["name"], "n_cus": info["n_cus"],
+                "arithmetic": "state int32, scores int64; the scan kernel tests attacks with exact integer-valued fp32 "
+                              "arithmetic (|values| < 2^24), see DESIGN.md 3.1",
             },
             "roofline": {
                 "bound": "hbm",

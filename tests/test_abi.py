@@ -58,3 +58,11 @@ def test_product_never_references_oracle():
                 with open(os.path.join(dirpath, fn)) as f:
                     src = f.read()
                 assert "import oracle" not in src and "liboracle" not in src and "orc_" not in src, fn
+
+
+def test_rust_sys_bindings_cover_the_header():
+    # bindings/rust is source-only (no Rust toolchain here) but must at least name every C function
+    root = os.path.dirname(os.path.dirname(os.path.abspath(_lib.HEADER_PATH)))
+    with open(os.path.join(root, "bindings", "rust", "local-search-amd", "src", "sys.rs")) as f:
+        rs = f.read()
+    assert sorted(set(re.findall(r"pub fn (ls_[a-z0-9_]+)\(", rs))) == _declared_functions()

@@ -252,3 +252,45 @@ def test_scan_formulations_agree(monkeypatch, variant):
             rows = _board(rng, n, "uniform")
             cols = rng.permutation(n)[:n_cols]
             _check(c, "scan", rows, cols, 5 * n, "table")
+
+
+def test_device_entry_is_graph_capturable(ctx):
+    # the *_dev entry point does no allocation / synchronisation once its workspaces exist, so an LS
+    # step can be captured into a hipGraph and replayed (north star: streams and graphs, no tracer)
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(21)
+    n, R, mc = 512, 4, 6
+    dev = torch.device("cuda:0")
+    rows_np = np.stack([_board(rng, n, "uniform") for _ in range(R)]).astype(np.int32)
+    cols_np = np.stack([rng.permutation(n)[:mc] for _ in range(R)]).astype(np.int32)
+    cur_np = np.array([orc.nq_score(rows_np[r]) for r in range(R)], dtype=np.int64)
+    rows, cols = torch.from_numpy(rows_np).to(dev), torch.from_numpy(cols_np).to(dev)
+    cur, ncols = torch.from_numpy(cur_np).to(dev), torch.full((R,), mc, dtype=torch.int32, device=dev)
+    res = torch.zeros((R, 4), dtype=torch.int64, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    ctx.set_algo("scan")
+    ctx.set_stream(stream.cuda_stream)
+    try:
+        def launch():
+            ctx.nqueens_eval_batch_dev(R, n, rows.data_ptr(), cur.data_ptr(), cols.data_ptr(), ncols.data_ptr(), mc,
+                                       5 * n, res.data_ptr())
+        with torch.cuda.stream(stream):
+            launch()                                   # warm-up: allocates the context's workspaces
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            launch()
+        for trial in range(3):                         # replay on changing inputs
+            rows_np = np.stack([_board(rng, n, "perm") for _ in range(R)]).astype(np.int32)
+            cur_np = np.array([orc.nq_score(rows_np[r]) for r in range(R)], dtype=np.int64)
+            rows.copy_(torch.from_numpy(rows_np)); cur.copy_(torch.from_numpy(cur_np))
+            res.zero_()
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            out = res.cpu().numpy()
+            for r in range(R):
+                exp = orc.nq_neighbourhood(rows_np[r], cols_np[r], 5 * n, "table", want_scores=False)
+                assert out[r, 0] == exp["n_scored"] and out[r, 1] == exp["best_index"] and out[r, 2] == exp["best_score"]
+    finally:
+        ctx.set_stream(None)
