@@ -91,6 +91,13 @@ static __global__ void fill_i64_kernel(long long *p, long long value, long long 
         p[i] = value;
 }
 
+static __global__ void fill_i32_kernel(int *p, int value, long long count)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (long long)gridDim.x * blockDim.x)
+        p[i] = value;
+}
+
 // ------------------------------------------------------------ wavefront utils
 // DPP controls (gfx9 family, wave64)
 #define LS_DPP_QUAD_1032 0xB1

@@ -776,7 +776,14 @@ static int build_tables(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, i
     const int stride = 5 * n + 8;
     const size_t bytes = (size_t)n_restarts * stride * sizeof(int);
     LS_RESERVE(ctx, ctx->nq_tabs, bytes);
-    LS_HIP(ctx, hipMemsetAsync(ctx->nq_tabs.p, 0, bytes, ctx->stream));
+    {   // cleared by a kernel, not hipMemsetAsync: keeps a captured hipGraph all-kernel (memset nodes
+        // did not re-execute reliably on replay with ROCm 7.x) and avoids the memset path's latency
+        const long long cnt = (long long)n_restarts * stride;
+        long long g = (cnt + 255) / 256;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, ctx->nq_tabs.as<int>(), 0, cnt);
+        LS_HIP(ctx, hipGetLastError());
+    }
     int gx = (n + 255) / 256;
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(nq_tables_build_kernel, dim3(gx, n_restarts), dim3(256), 0, ctx->stream, rows_d, n,
@@ -792,7 +799,9 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
                       ls_nq_result *results_d, long long *scores_out_d)
 {
     LS_RESERVE(ctx, ctx->nq_keys, (size_t)n_restarts * 8);
-    LS_HIP(ctx, hipMemsetAsync(ctx->nq_keys.p, 0xFF, (size_t)n_restarts * 8, ctx->stream));
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((n_restarts + 255) / 256), dim3(256), 0, ctx->stream,
+                       ctx->nq_keys.as<long long>(), -1ll, (long long)n_restarts); // NQ_KEY_EMPTY
+    LS_HIP(ctx, hipGetLastError());
     NqArgs a;
     a.rows = rows_d; a.cur_scores = cur_d; a.cols = cols_d; a.n_cols = n_cols_d;
     a.n = n; a.n_restarts = n_restarts; a.max_cols = max_cols; a.window = window;
@@ -844,7 +853,11 @@ int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, lon
     int *tabs = nullptr; int stride = 0;
     int rc = build_tables(ctx, n_restarts, n, rows_d, &tabs, &stride);
     if (rc != LS_OK) return rc;
-    if (scores_d) LS_HIP(ctx, hipMemsetAsync(scores_d, 0, (size_t)n_restarts * 8, ctx->stream));
+    if (scores_d) {
+        hipLaunchKernelGGL(fill_i64_kernel, dim3((n_restarts + 255) / 256), dim3(256), 0, ctx->stream, scores_d, 0ll,
+                           (long long)n_restarts);
+        LS_HIP(ctx, hipGetLastError());
+    }
     int gx = (n + 255) / 256;
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(nq_col_scores_kernel, dim3(gx, n_restarts), dim3(256), 0, ctx->stream, rows_d, n, tabs,
