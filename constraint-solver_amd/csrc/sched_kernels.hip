@@ -34,6 +34,8 @@
 // The vector order of <= 2-edit candidates of one base is a closed form over the edits:
 // per edit (class: lowers < none < raises, position key, new value).  Packed with the scores
 // into one 64-bit key per candidate; the last kernel takes the minimum (key, index).
+#include <cstdlib>
+
 #include "ls_common.hpp"
 #include "sched_common.hpp"
 
@@ -459,6 +461,231 @@ __global__ __launch_bounds__(256) void sched_eval_kernel(SchedEvalArgs a)
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Pass 2 for schedules of at most 32 stored days (both configurations the reference ships): a
+// candidate occupies HALF a wavefront (lane & 31 = day), so two candidates are scored per pass and
+// every mask is 32-bit.  A 64-bit ballot is naturally the pair (candidate A, candidate B).
+// Reductions stay inside each half: four DPP row steps + row_bcast:15 leave the half totals in
+// lanes 31 and 63.
+
+__device__ __forceinline__ int half_sum_i32(int x) // lanes 16-31 / 48-63 end up holding their half's total
+{
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_QUAD_1032, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_QUAD_2301, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_ROW_HALF_MIRROR, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_ROW_MIRROR, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_ROW_BCAST15, 0xa, 0xf, false);
+    return x;
+}
+
+__device__ __forceinline__ unsigned half_or_u32(unsigned x)
+{
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_QUAD_1032, 0xf, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_QUAD_2301, 0xf, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_ROW_HALF_MIRROR, 0xf, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_ROW_MIRROR, 0xf, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_ROW_BCAST15, 0xa, 0xf, false);
+    return x;
+}
+
+struct SchedLane32 {
+    unsigned scored_mask, weekend_mask, mask2, h3mask, wdmask;
+    int gsize, flags;
+};
+
+// per-lane partial terms of one candidate row; the three values are reduced per half by the caller
+struct SchedPartial32 {
+    int hs;            // (h1+h2+h3+h4) | (s1+s2) << 16
+    unsigned tot_onehot, wk_onehot;
+};
+
+__device__ __forceinline__ SchedPartial32 sched_terms32(int D, const SchedLane32 &L, int p, int lane, unsigned eq, int holiday_bit)
+{
+    SchedPartial32 r;
+    int h = 0, sf = 0;
+    r.tot_onehot = 0;
+    r.wk_onehot = 0;
+    if (L.flags & 1) {
+        h = holiday_bit + ((eq & L.mask2) ? 1 : 0) + __popc(eq & L.h3mask);
+        const unsigned below = eq & ((1u << p) - 1);
+        const int prev = below ? 31 - __clz((int)below) : -1;
+        unsigned t = eq >> p; // bit 0 = day p itself
+        t &= t - 1;
+        t &= t - 1;
+        const int q3 = t ? p + __ffs((int)t) - 1 : SC_BIG;
+        t &= t - 1;
+        const int q4 = t ? p + __ffs((int)t) - 1 : SC_BIG;
+        {
+            int lo = prev + 1;
+            lo = lo > p - 6 ? lo : p - 6;
+            lo = lo > 0 ? lo : 0;
+            lo = lo > q3 - 6 ? lo : q3 - 6;
+            const int hi = p < D - 7 ? p : D - 7;
+            sf = hi - lo + 1 > 0 ? hi - lo + 1 : 0;
+        }
+        {
+            int lo = prev + 1;
+            lo = lo > p - 13 ? lo : p - 13;
+            lo = lo > 0 ? lo : 0;
+            lo = lo > q4 - 13 ? lo : q4 - 13;
+            const int hi = p < D - 14 ? p : D - 14;
+            h += hi - lo + 1 > 0 ? hi - lo + 1 : 0;
+        }
+        r.tot_onehot = 1u << (__popc(eq) - 1);
+        r.wk_onehot = 1u << __popc(eq & L.weekend_mask);
+    }
+    // S2: min over the lanes of one weekday (stride 7) without leaving the half
+    int cnt = L.wdmask ? __popc(eq & L.wdmask) : SC_BIG;
+#pragma unroll
+    for (int off = 7; off <= 28; off <<= 1) {
+        const int o = __shfl(cnt, p + off < 32 ? lane + off : lane, 64);
+        cnt = o < cnt ? o : cnt;
+    }
+    if ((L.flags & 2) && cnt < L.gsize) sf += cnt;
+    r.hs = h | (sf << 16);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void sched_eval32_kernel(SchedEvalArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31;      // day
+    const bool upper = lane >= 32; // which of the two candidates of a pass this lane works for
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = blockIdx.x % a.n_restarts;
+    const int wave = (blockIdx.x / a.n_restarts) * 4 + wib;
+    const int n_waves = (gridDim.x / a.n_restarts) * 4;
+    const int S = a.in.S, D = a.in.D, E = a.in.n_employees;
+    const long long k_end = a.k_end[r];
+    const long long n_units = ((k_end + 63) >> 6) * a.split; // work units: (batch, part)
+    __shared__ u64 s_key[4];
+    __shared__ long long s_idx[4];
+    u64 best_key = SC_KEY_EMPTY;
+    long long best_idx = -1;
+    if (wave < n_units) {
+        const SchedLaneConst L64 = a.in.lane_tab[li];
+        SchedLane32 L;
+        L.scored_mask = (unsigned)L64.scored_mask; L.weekend_mask = (unsigned)L64.weekend_mask;
+        L.mask2 = (unsigned)L64.mask2; L.h3mask = (unsigned)L64.h3mask; L.wdmask = (unsigned)L64.wdmask;
+        L.gsize = L64.gsize; L.flags = L64.flags;
+        const int base = li < S ? a.states[(long long)r * S + li] : -1 - li; // both halves hold the base vector
+        unsigned eq_base = 0;
+#pragma unroll
+        for (int q = 0; q < 32; q++)
+            if (q < D && base == __builtin_amdgcn_readlane(base, q)) eq_base |= 1u << q;
+        eq_base &= L.scored_mask;
+        const int hb_base = sched_holiday_bit(a.in, base, li);
+        const ls_sched_move *mv = a.moves + (long long)r * a.max_moves;
+
+        for (long long unit = wave; unit < n_units; unit += n_waves) {
+            const long long batch = unit / a.split;
+            const int part = (int)(unit % a.split);
+            const long long k = (batch << 6) + lane;
+            // ---- per-lane: this lane's move, its edit, its holiday bits, its half of the key
+            int type = -1, ma = 0, mb = 0;
+            if (k < k_end) { const ls_sched_move m = mv[k]; type = m.type; ma = m.a; mb = m.b; }
+            const bool ok = sched_move_ok(type, ma, mb, S, E);
+            const int ia = ok ? ma : 0, ib = (ok && type == 1) ? mb : ia;
+            const int ea = __shfl(base, ia, 64), eb = __shfl(base, ib, 64);
+            const int pos1 = ia, new1 = type == 0 ? mb : eb;
+            const int pos2 = ib, new2 = type == 0 ? mb : ea;
+            const bool active = ok && !(new1 == ea && new2 == eb) && (lane & (a.split - 1)) == part;
+            int hbits = 0;
+            u64 lowkey = 0;
+            if (active) {
+                hbits = sched_holiday_bit(a.in, new1, pos1) | (sched_holiday_bit(a.in, new2, pos2) << 1);
+                u64 e1, e2 = (u64)1 << 21;
+                if (type == 0) e1 = sc_edit_key(pos1, new1, ea);
+                else {
+                    const bool a_first = pos1 < pos2;
+                    e1 = a_first ? sc_edit_key(pos1, new1, ea) : sc_edit_key(pos2, new2, eb);
+                    e2 = a_first ? sc_edit_key(pos2, new2, eb) : sc_edit_key(pos1, new1, ea);
+                }
+                lowkey = (e1 << 23) | e2;
+            }
+            const int packed = pos1 | (pos2 << 8) | (hbits << 16);
+            int my_hs = 0;
+            // ---- wave: two non-tabu candidates of the batch per pass (lower half / upper half)
+            u64 todo = __ballot(active);
+            while (todo) {
+                const int jA = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const bool haveB = todo != 0;
+                const int jB = haveB ? __ffsll((long long)todo) - 1 : jA;
+                todo &= todo - 1;
+                const int pkA = __builtin_amdgcn_readlane(packed, jA), pkB = __builtin_amdgcn_readlane(packed, jB);
+                const int n1A = __builtin_amdgcn_readlane(new1, jA), n1B = __builtin_amdgcn_readlane(new1, jB);
+                const int n2A = __builtin_amdgcn_readlane(new2, jA), n2B = __builtin_amdgcn_readlane(new2, jB);
+                const int pk = upper ? pkB : pkA, n1 = upper ? n1B : n1A, n2 = upper ? n2B : n2A;
+                const int p1 = pk & 0xff, p2 = (pk >> 8) & 0xff;
+                int e = base;
+                if (li == p1) e = n1;
+                if (li == p2) e = n2;
+                const bool c1 = e == n1, c2 = e == n2;
+                const u64 b1 = __ballot(c1), b2 = __ballot(c2);
+                const unsigned m1 = (upper ? (unsigned)(b1 >> 32) : (unsigned)b1) & L.scored_mask;
+                const unsigned m2 = (upper ? (unsigned)(b2 >> 32) : (unsigned)b2) & L.scored_mask;
+                const unsigned bit1 = p1 < D ? 1u << p1 : 0, bit2 = p2 < D ? 1u << p2 : 0;
+                unsigned eq = eq_base & ~(bit1 | bit2);
+                if (c1) eq |= bit1;
+                if (c2) eq |= bit2;
+                if (li == p1) eq = m1;
+                if (li == p2) eq = m2;
+                int hb = hb_base;
+                if (li == p1) hb = (pk >> 16) & 1;
+                if (li == p2) hb = (pk >> 17) & 1;
+                const SchedPartial32 pt = sched_terms32(D, L, li, lane, eq, hb);
+                const int hs = half_sum_i32(pt.hs);
+                const unsigned tor = half_or_u32(pt.tot_onehot), wor = half_or_u32(pt.wk_onehot);
+#define LS_FINISH(LN, J)                                                                              \
+    {                                                                                                 \
+        const unsigned hsx = (unsigned)__builtin_amdgcn_readlane(hs, LN);                             \
+        const unsigned t_or = (unsigned)__builtin_amdgcn_readlane((int)tor, LN);                      \
+        const unsigned w_or = (unsigned)__builtin_amdgcn_readlane((int)wor, LN);                      \
+        const int s3 = (31 - __clz((int)t_or)) - (__ffs((int)t_or) - 1);                              \
+        const int s4 = (31 - __clz((int)w_or)) - (__ffs((int)w_or) - 1);                              \
+        const int hard = (int)(hsx & 0xffffu), soft = (int)(hsx >> 16) + s3 + s4;                     \
+        if (lane == (J)) my_hs = (hard << 8) | soft;                                                  \
+    }
+                LS_FINISH(31, jA)
+                if (haveB) LS_FINISH(63, jB)
+#undef LS_FINISH
+            }
+            // ---- per-lane: assemble (key, index); optional per-candidate outputs
+            if (active) {
+                const int hard = my_hs >> 8, soft = my_hs & 0xff;
+                const u64 key = ((u64)(unsigned)hard << 54) | ((u64)(unsigned)soft << 46) | lowkey;
+                if (key < best_key) { best_key = key; best_idx = k; }
+                if (a.hard_out) a.hard_out[(long long)r * a.max_moves + k] = hard;
+                if (a.soft_out) a.soft_out[(long long)r * a.max_moves + k] = soft;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned klo = __shfl_xor((unsigned)best_key, m, 64), khi = __shfl_xor((unsigned)(best_key >> 32), m, 64);
+        const unsigned ilo = __shfl_xor((unsigned)best_idx, m, 64), ihi = __shfl_xor((unsigned)((u64)best_idx >> 32), m, 64);
+        const u64 ok = ((u64)khi << 32) | klo;
+        const long long oi = (long long)(((u64)ihi << 32) | ilo);
+        if (ok < best_key || (ok == best_key && ok != SC_KEY_EMPTY && oi < best_idx)) { best_key = ok; best_idx = oi; }
+    }
+    if (lane == 0) { s_key[wib] = best_key; s_idx[wib] = best_idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; i++)
+            if (s_key[i] < best_key || (s_key[i] == best_key && best_key != SC_KEY_EMPTY && s_idx[i] < best_idx)) {
+                best_key = s_key[i]; best_idx = s_idx[i];
+            }
+        if (a.blocks_per_restart == 1) {
+            sched_write_result(a, r, best_key, best_idx);
+        } else {
+            const long long slot = (long long)r * a.blocks_per_restart + blockIdx.x / a.n_restarts;
+            a.part_key[slot] = best_key;
+            a.part_idx[slot] = best_idx;
+        }
+    }
+}
+
 // Pass 3: minimum (key, index) over the per-block minima of pass 2.
 __global__ __launch_bounds__(256) void sched_reduce_kernel(SchedEvalArgs a)
 {
@@ -567,7 +794,10 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
     }
     hipLaunchKernelGGL(sched_locate_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a);
     LS_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(sched_eval_kernel, dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
+    if (ctx->sched.n_days_stored <= 32 && !getenv("LS_SCHED_FORCE_64"))
+        hipLaunchKernelGGL(sched_eval32_kernel, dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(sched_eval_kernel, dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
     LS_HIP(ctx, hipGetLastError());
     if (bpr > 1) { // with one block per restart pass 2 has already written the result
         hipLaunchKernelGGL(sched_reduce_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a);
