@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (not part of the test suite): random N-queens and scheduling
+neighbourhoods through every kernel path vs the CPU oracle.  Usage: python tools/soak.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "constraint-solver_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np  # noqa: E402
+
+import ls_amd  # noqa: E402
+import oracle as orc  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+t_end = time.time() + budget
+stats = dict(nq=0, nq_candidates=0, sched=0, sched_candidates=0, sched_scores=0)
+
+
+def fail(msg, **kw):
+    print("MISMATCH:", msg)
+    for k, v in kw.items():
+        print(" ", k, "=", v if not hasattr(v, "tolist") else v.tolist())
+    sys.exit(1)
+
+
+def nq_case(ctx):
+    n = int(rng.choice([rng.integers(1, 70), rng.integers(60, 600), rng.integers(500, 4200), rng.integers(4097, 9000)],
+                       p=[0.35, 0.35, 0.25, 0.05]))
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        rows = rng.permutation(n)
+    elif kind == 1:
+        rows = rng.integers(0, n, size=n)
+    elif kind == 2:                                   # few distinct rows: massive ties and conflicts
+        rows = rng.integers(0, max(1, n // 50 + 1), size=n)
+    else:                                             # near-diagonal
+        rows = np.clip(np.arange(n) + rng.integers(-2, 3, size=n), 0, n - 1)
+    n_cols = int(rng.integers(0, min(n, 8) + 1))
+    cols = rng.integers(0, n, size=n_cols) if rng.integers(0, 4) == 0 else rng.permutation(n)[:n_cols]
+    window = int(rng.choice([0, 1, rng.integers(1, 3 * n + 2), n_cols * (n - 1), 10 ** 12]))
+    form = "literal" if n <= 48 else ("delta" if n <= 400 else "table")
+    exp = orc.nq_neighbourhood(rows, cols, window, form)
+    cur = orc.nq_score(rows)
+    for algo in ("scan", "table"):
+        ctx.set_algo(algo)
+        got, scores = ctx.nqueens_eval(rows, cur, cols, window, want_scores=True)
+        if (got["n_scored"], got["best_index"]) != (exp["n_scored"], exp["best_index"]) or \
+                (exp["best_index"] >= 0 and got["best_score"] != exp["best_score"]) or not np.array_equal(scores, exp["scores"]):
+            fail(f"nqueens {algo}", n=n, rows=rows, cols=cols, window=window, got=got,
+                 exp={k: exp[k] for k in ("n_scored", "best_index", "best_score")})
+        got2, _ = ctx.nqueens_eval(rows, cur, cols, window)          # production path (no score output)
+        if got2 != got:
+            fail(f"nqueens {algo}: debug and production paths differ", n=n, rows=rows, cols=cols, window=window)
+    stats["nq"] += 1
+    stats["nq_candidates"] += exp["n_scored"]
+
+
+def sched_case(ctx):
+    D = int(rng.choice([rng.integers(1, 32), 31, rng.integers(32, 65)], p=[0.4, 0.3, 0.3]))
+    S = int(min(64, D + rng.integers(0, 2)))
+    E = int(rng.choice([1, 2, 3, 7, 40, 1000]))
+    start_wd = int(rng.integers(0, 7))
+    hol = {}
+    bits = np.zeros(E, dtype=np.uint64)
+    for e in range(min(E, 30)):
+        for d in rng.choice(D, size=int(min(D, rng.integers(0, 4))), replace=False):
+            hol.setdefault(e, []).append(int(d))
+            bits[e] |= np.uint64(1) << np.uint64(int(d))
+    # oracle instance with the same start weekday: 2024-01-01 is a Monday
+    import datetime as dt
+    start = dt.date(2024, 1, 1) + dt.timedelta(days=start_wd)
+    end = start + dt.timedelta(days=D - 1)
+    inst = orc.Sched((start.year, start.month, start.day), (end.year, end.month, end.day), hol)
+    assert inst.n_scored_days == D and inst.start_weekday == start_wd
+    ctx.sched_instance_upload(D, S, start_wd, E, bits)
+    pool = min(E, int(rng.choice([1, 2, 4, 12, 1000])))
+    states = rng.integers(0, pool, size=(16, S))
+    hard, soft, terms = ctx.sched_score(states, want_terms=True)
+    for i in range(len(states)):
+        h, s, t = inst.score(states[i], terms=True)
+        if (hard[i], soft[i]) != (h, s) or terms[i].tolist() != t.tolist():
+            fail("sched score", D=D, S=S, E=E, wd=start_wd, hol=hol, state=states[i], got=terms[i], exp=t)
+    stats["sched_scores"] += len(states)
+    state = states[0]
+    n_moves = int(rng.choice([0, 1, rng.integers(1, 200), rng.integers(200, 3000)]))
+    moves = np.zeros((n_moves, 3), dtype=np.int64)
+    for i in range(n_moves):
+        if rng.integers(0, 5) == 0 or S < 2:
+            moves[i] = (0, rng.integers(0, S), rng.integers(0, pool))
+        else:
+            moves[i] = (1, rng.integers(0, S), rng.integers(0, S))
+    window = int(rng.choice([0, 1, rng.integers(1, n_moves + 2), 10 ** 12]))
+    if n_moves == 0:
+        return
+    exp = inst.neighbourhood(state, moves, window)
+    got, gh, gs = ctx.sched_eval(state, moves, window, want_scores=True)
+    if (got["n_scored"], got["best_index"]) != (exp["n_scored"], exp["best_index"]) or \
+            (exp["best_index"] >= 0 and (got["best_hard"], got["best_soft"]) != (exp["best_hard"], exp["best_soft"])) or \
+            not np.array_equal(gh, exp["hard"]) or not np.array_equal(gs, exp["soft"]):
+        fail("sched neighbourhood", D=D, S=S, E=E, wd=start_wd, hol=hol, state=state, moves=moves, window=window, got=got,
+             exp={k: exp[k] for k in ("n_scored", "best_index", "best_hard", "best_soft")})
+    got2, _, _ = ctx.sched_eval(state, moves, window)
+    if got2 != got:
+        fail("sched: debug and production paths differ", D=D, S=S, E=E, state=state, moves=moves, window=window)
+    stats["sched"] += 1
+    stats["sched_candidates"] += exp["n_scored"]
+
+
+with ls_amd.Context(0) as ctx:
+    last = time.time()
+    while time.time() < t_end:
+        nq_case(ctx)
+        sched_case(ctx)
+        if time.time() - last > 30:
+            print("progress", stats, flush=True)
+            last = time.time()
+print("SOAK OK", stats, "seed", seed)
