@@ -212,9 +212,12 @@ def main():
                 "note": "algorithmic bytes per SURVEY 8(d) (4n+16 per neighbour); the 16 KiB state is shared by all "
                         "candidates of a restart and is held in registers, so the effective rate exceeds the HBM peak; the "
                         "kernel's real limiter is VALU issue (4 fp32 instructions per candidate and column), see DESIGN.md 3.1",
-                "issue_bound": {"instr_per_neighbour": 4 * n, "ns_per_instr_per_simd": 0.92, "simds": 4 * info["n_cus"],
-                                "neighbours_per_s_at_bound": 4 * info["n_cus"] / (4 * n * 0.92e-9),
-                                "frac_of_issue_bound": value / (4 * info["n_cus"] / (4 * n * 0.92e-9))},
+                # one wavefront per candidate: n/64 columns per lane x 4 full-rate fp32 instructions, issued at
+                # 0.92 ns per wave-instruction per SIMD with 2 waves/SIMD (tools/valu_rates.hip)
+                "issue_bound": {"wave_instr_per_neighbour": 4 * n // 64, "ns_per_instr_per_simd": 0.92,
+                                "simds": 4 * info["n_cus"],
+                                "neighbours_per_s_at_bound": 4 * info["n_cus"] / (4 * n / 64 * 0.92e-9),
+                                "frac_of_issue_bound": (value / world) / (4 * info["n_cus"] / (4 * n / 64 * 0.92e-9))},
             },
             "global_best": {"score": best[0][0], "restart": best[2]},
         }

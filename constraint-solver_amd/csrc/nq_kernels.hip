@@ -116,6 +116,9 @@ __device__ __forceinline__ NqRanges nq_ranges(int vs, int ve, int rc, long long 
 // Variants differ only in how a match is turned into a count (measured on
 // MI355X); all produce identical counts.
 //   SELF = what the column's own queen adds when its own square is counted.
+// (A third formulation — int32 compares into scalar masks, 3 v_cmp + 2 s_or + 1 v_addc per column —
+// was the first version and ran at 1.28e9 neighbours/s; it is gone: v_cmp->sgpr is half rate and the
+// scalar ORs serialise behind it.)
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
@@ -140,55 +143,6 @@ __device__ __forceinline__ us2 pk_min_u16_raw(us2 x, us2 y)
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
-
-// per-lane counts < 2^15, wave totals <= n + 2 < 2^16: reduce two candidates per register
-__device__ __forceinline__ void nq_reduce4(int c0, int c1, int c2, int c3, int (&cnt)[4])
-{
-    const unsigned t01 = (unsigned)wave_sum_i32(c0 | (c1 << 16));
-    const unsigned t23 = (unsigned)wave_sum_i32(c2 | (c3 << 16));
-    cnt[0] = (int)(t01 & 0xffffu); cnt[1] = (int)(t01 >> 16);
-    cnt[2] = (int)(t23 & 0xffffu); cnt[3] = (int)(t23 >> 16);
-}
-
-// 32-bit integer lanes: lane l holds columns j = l + 64*i, i < NR  (n <= 64*NR).  The
-// three equality masks are OR-ed on the scalar unit and added with one carry-add
-// (3 v_cmp + 2 s_or + 1 v_addc per column).  Kept as the plain formulation the other
-// two are measured against (LS_NQ_SCAN_VARIANT=2); v_cmp with a scalar destination is
-// a half-rate instruction on gfx950 and the s_or chain serialises behind it.
-template <int NR>
-struct BoardI32 {
-    static constexpr int CAP = 64 * NR;
-    static constexpr int SELF = 1;
-    static constexpr int WAVES = nq_waves_for(3 * NR + 32);
-    int R[NR], A[NR], B[NR];
-    __device__ __forceinline__ void load(const int *__restrict__ rows, int n, int lane)
-    {
-#pragma unroll
-        for (int i = 0; i < NR; i++) {
-            const int j = lane + 64 * i;
-            const bool in = j < n;
-            const int r = in ? rows[j] : 0;
-            R[i] = in ? r : NQ_SENT;
-            A[i] = in ? r - j : NQ_SENT;
-            B[i] = in ? r + j : NQ_SENT;
-        }
-    }
-    __device__ __forceinline__ void prepare(int, int) {}
-    __device__ __forceinline__ void count4(int v, int c, int (&cnt)[4]) const
-    {
-        const int va = v - c, vb = v + c;
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-#pragma unroll
-        for (int i = 0; i < NR; i++) {
-            const int r = R[i], a = A[i], b = B[i];
-            c0 += (int)((r == v) | (a == va) | (b == vb));
-            c1 += (int)((r == v + 1) | (a == va + 1) | (b == vb + 1));
-            c2 += (int)((r == v + 2) | (a == va + 2) | (b == vb + 2));
-            c3 += (int)((r == v + 3) | (a == va + 3) | (b == vb + 3));
-        }
-        nq_reduce4(c0, c1, c2, c3, cnt);
-    }
-};
 
 // Packed 16-bit lanes: register i of lane l holds columns l + 64*(2i) (low half)
 // and l + 64*(2i+1) (high half)  (n <= 128*NRP <= 8192).  A is stored biased by
@@ -221,8 +175,11 @@ struct BoardPk16 {
             R[i] = as_us2(pr); A[i] = as_us2(pa); B[i] = as_us2(pb);
         }
     }
+    static constexpr bool MISMATCH = true; // lanes4 counts mismatching halves (<= 2*NRP <= 128)
+    static constexpr int READ_UNROLL = 2;
+    static constexpr int LANE_TOTAL = 2 * NRP;
     __device__ __forceinline__ void prepare(int, int) {}
-    __device__ __forceinline__ void count4(int v, int c, int (&cnt)[4]) const
+    __device__ __forceinline__ unsigned lanes4(int v, int c) const
     {
         const unsigned rep = 0x00010001u;
         const unsigned Vr = (unsigned)v * rep, Va = (unsigned)(v - c + n) * rep, Vb = (unsigned)(v + c) * rep;
@@ -244,10 +201,8 @@ struct BoardPk16 {
             LS_PK_STEP(m3, 3u)
 #undef LS_PK_STEP
         }
-        // matches per lane = halves - mismatches
-        const int c0 = 2 * NRP - (int)(m0.x + m0.y), c1 = 2 * NRP - (int)(m1.x + m1.y);
-        const int c2 = 2 * NRP - (int)(m2.x + m2.y), c3 = 2 * NRP - (int)(m3.x + m3.y);
-        nq_reduce4(c0, c1, c2, c3, cnt);
+        return (unsigned)(m0.x + m0.y) | ((unsigned)(m1.x + m1.y) << 8) | ((unsigned)(m2.x + m2.y) << 16) |
+               ((unsigned)(m3.x + m3.y) << 24);
     }
 };
 
@@ -288,7 +243,10 @@ struct BoardF32 {
 #pragma unroll
         for (int i = 0; i < NR; i++) E[i] = __builtin_fabsf((float)(lane + 64 * i - c));
     }
-    __device__ __forceinline__ void count4(int v, int c, int (&cnt)[4]) const
+    static constexpr bool MISMATCH = true; // lanes4 counts mismatching columns (<= NR <= 64)
+    static constexpr int READ_UNROLL = 4;
+    static constexpr int LANE_TOTAL = NR;
+    __device__ __forceinline__ unsigned lanes4(int v, int c) const
     {
         (void)c;
         const float f0 = (float)v, f1 = (float)(v + 1), f2 = (float)(v + 2), f3 = (float)(v + 3);
@@ -327,49 +285,59 @@ struct BoardF32 {
             }
         }
 #undef LS_F32_COL
-        nq_reduce4(NR - (int)m0, NR - (int)m1, NR - (int)m2, NR - (int)m3, cnt);
+        return (unsigned)(int)m0 | ((unsigned)(int)m1 << 8) | ((unsigned)(int)m2 << 16) | ((unsigned)(int)m3 << 24);
     }
 };
 
-// Running minimum of one wavefront, all wave-uniform (scalar registers).  A candidate can only
-// win if its delta does not exceed the best delta so far, which a 32-bit scalar compare decides;
-// the 64-bit key is built for those few only.
-struct NqBest {
-    int delta;
-    unsigned long long key;
-};
-
-template <bool WANT_SCORES>
-__device__ __forceinline__ void nq_consider(NqBest &best, int delta, unsigned long long khi, int v,
-                                            long long *scores_row, long long cur, int lane)
+// Attack count of one square from the per-lane packed counts (used once per column, for conf_old).
+template <class Board> __device__ __forceinline__ int nq_count_first(unsigned packed)
 {
-    if (delta <= best.delta) {
-        const unsigned long long key = nq_key(delta, khi, v);
-        if (key < best.key) { best.key = key; best.delta = delta; }
-    }
-    if (WANT_SCORES) {
-        if (lane == 0) scores_row[v] = cur + 2ll * delta;
-    }
+    const int s = wave_sum_i32((int)(packed & 0xffu));
+    return Board::MISMATCH ? 64 * Board::LANE_TOTAL - s : s;
 }
 
+// 64 candidates per pass.  Sixteen steps of four candidates each leave per-lane counts (one byte
+// per candidate) in a wave-private LDS tile, row = step, column = lane; then lane q OWNS candidate q:
+// it sums byte (q & 3) of row (q >> 2) over the 64 lanes, forms delta and key, and keeps its own
+// running minimum.  One tile transpose per 64 candidates replaces a 6-step DPP reduction, the
+// conversions and the scalar key work per candidate; the debug score store becomes coalesced.
+// Rows are 68 dwords apart so that the sixteen row groups of a b128 read hit different banks.
+constexpr int NQ_TILE_STRIDE = 68;
+constexpr int NQ_TILE_DWORDS = 16 * NQ_TILE_STRIDE;
+
 template <bool WANT_SCORES, class Board>
-__device__ __forceinline__ void nq_scan_range_regs(const Board &bd, int vbeg, int vend, int c, int conf_old,
-                                                   unsigned long long khi, NqBest &best, long long *scores_row,
-                                                   long long cur, int lane)
+__device__ __forceinline__ void nq_scan_range_regs(const Board &bd, unsigned *tile, int vbeg, int vend, int c,
+                                                   int conf_old, unsigned long long khi, unsigned long long &best,
+                                                   long long *scores_row, long long cur, int lane)
 {
-    int v = vbeg;
-    for (; v + 4 <= vend; v += 4) {
-        int cnt[4];
-        bd.count4(v, c, cnt);
-#pragma unroll
-        for (int u = 0; u < 4; u++) nq_consider<WANT_SCORES>(best, cnt[u] - conf_old, khi, v + u, scores_row, cur, lane);
-    }
-    if (v < vend) { // tail: fewer than four values left; surplus results are dropped
-        int cnt[4];
-        bd.count4(v, c, cnt);
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (v + u < vend) nq_consider<WANT_SCORES>(best, cnt[u] - conf_old, khi, v + u, scores_row, cur, lane);
+#pragma unroll 1
+    for (int vb = vbeg; vb < vend; vb += 64) {
+        const int left = vend - vb;
+        const int steps = left >= 64 ? 16 : (left + 3) >> 2;
+        __builtin_amdgcn_wave_barrier(); // the previous pass's reads are program-ordered before these writes
+#pragma unroll 1 // one copy of the (fully unrolled) column scan; unrolling this loop spills the board
+        for (int st = 0; st < steps; st++) tile[st * NQ_TILE_STRIDE + lane] = bd.lanes4(vb + 4 * st, c);
+        // The tile is private to this wavefront and LDS operations of one wavefront complete in order, so no
+        // s_barrier is needed; the fences only stop the compiler from moving the reads above other lanes' writes.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned *row = tile + (lane >> 2) * NQ_TILE_STRIDE;
+        const int sh = (lane & 3) * 8;
+        int sum = 0;
+#pragma clang loop unroll_count(Board::READ_UNROLL) // b128 reads in flight; more would spill the register-resident board
+        for (int l4 = 0; l4 < 16; l4++) {
+            const uint4 x = *reinterpret_cast<const uint4 *>(row + 4 * l4);
+            sum += (int)((x.x >> sh) & 0xffu) + (int)((x.y >> sh) & 0xffu) + (int)((x.z >> sh) & 0xffu) +
+                   (int)((x.w >> sh) & 0xffu);
+        }
+        const int v = vb + lane;
+        if (v < vend) {
+            const int cnt = Board::MISMATCH ? 64 * Board::LANE_TOTAL - sum : sum;
+            const int delta = cnt - conf_old;
+            best = u64min(best, nq_key(delta, khi, v));
+            if (WANT_SCORES) scores_row[v] = cur + 2ll * delta;
+        }
     }
 }
 
@@ -377,6 +345,7 @@ template <class Board, bool WANT_SCORES>
 __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs a)
 {
     __shared__ unsigned long long s_best[4];
+    __shared__ __attribute__((aligned(16))) unsigned s_tile[4 * NQ_TILE_DWORDS];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int restart = blockIdx.x % a.n_restarts;
@@ -390,7 +359,8 @@ __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs 
     const long long K = nq_k_limit((long long)ncols * n, n, a.window);
     const long long k0 = K * wchunk / n_wchunks;
     const long long k1 = K * (wchunk + 1) / n_wchunks;
-    NqBest best{0x7fffffff, NQ_KEY_EMPTY};
+    unsigned long long best = NQ_KEY_EMPTY; // per-lane running minimum
+    unsigned *tile = s_tile + wib * NQ_TILE_DWORDS;
 
     if (k0 < k1) {
         Board bd;
@@ -410,13 +380,11 @@ __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs 
                 if (rg.d1 > rg.d0 || rg.u1 > rg.u0) {
                     bd.prepare(c, lane);
                     // conf(c, rows[c]): scan the own square, drop the own queen's matches
-                    int cnt[4];
-                    bd.count4(rc, c, cnt);
-                    const int conf_old = cnt[0] - Board::SELF;
+                    const int conf_old = nq_count_first<Board>(bd.lanes4(rc, c)) - Board::SELF;
                     long long *srow = WANT_SCORES ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
-                    nq_scan_range_regs<WANT_SCORES>(bd, rg.d0, rg.d1, c, conf_old, nq_key_hi(0, c, n, slot), best, srow,
+                    nq_scan_range_regs<WANT_SCORES>(bd, tile, rg.d0, rg.d1, c, conf_old, nq_key_hi(0, c, n, slot), best, srow,
                                                     cur, lane);
-                    nq_scan_range_regs<WANT_SCORES>(bd, rg.u0, rg.u1, c, conf_old, nq_key_hi(1, c, n, slot), best, srow,
+                    nq_scan_range_regs<WANT_SCORES>(bd, tile, rg.u0, rg.u1, c, conf_old, nq_key_hi(1, c, n, slot), best, srow,
                                                     cur, lane);
                 }
             }
@@ -425,7 +393,8 @@ __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs 
             v0 = 0;
         }
     }
-    if (lane == 0) s_best[wib] = best.key;
+    best = wave_min_u64(best);
+    if (lane == 0) s_best[wib] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long b = u64min(u64min(s_best[0], s_best[1]), u64min(s_best[2], s_best[3]));
@@ -688,7 +657,7 @@ static int launch_scan_board(ls_ctx *ctx, const NqArgs &a, long long bpr_cap)
     // Exactly Board::WAVES 256-thread blocks per CU: the register budget alone may admit an odd
     // number of waves per SIMD, so a dynamic-LDS reservation (never touched) caps residency.
     constexpr int bpc = Board::WAVES;
-    constexpr size_t lds_cap = bpc >= 8 ? 0 : (size_t)(160 * 1024 / bpc - 2048);
+    constexpr size_t lds_cap = bpc >= 8 ? 0 : (size_t)(160 * 1024 / bpc - 2048 - 4 * NQ_TILE_DWORDS * 4);
     static bool attr_done = false;
     if (!attr_done && lds_cap > 0) {
         LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_scan_regs_kernel<Board, false>),
@@ -706,18 +675,6 @@ static int launch_scan_board(ls_ctx *ctx, const NqArgs &a, long long bpr_cap)
     else hipLaunchKernelGGL((nq_scan_regs_kernel<Board, false>), grid, dim3(256), lds_cap, ctx->stream, a);
     LS_HIP(ctx, hipGetLastError());
     return LS_OK;
-}
-
-static int launch_scan_i32(ls_ctx *ctx, const NqArgs &a, long long cap)
-{
-    const int n = a.n;
-    if (n <= 64) return launch_scan_board<BoardI32<1>>(ctx, a, cap);
-    if (n <= 128) return launch_scan_board<BoardI32<2>>(ctx, a, cap);
-    if (n <= 256) return launch_scan_board<BoardI32<4>>(ctx, a, cap);
-    if (n <= 512) return launch_scan_board<BoardI32<8>>(ctx, a, cap);
-    if (n <= 1024) return launch_scan_board<BoardI32<16>>(ctx, a, cap);
-    if (n <= 2048) return launch_scan_board<BoardI32<32>>(ctx, a, cap);
-    return launch_scan_board<BoardI32<64>>(ctx, a, cap);
 }
 
 static int launch_scan_pk16(ls_ctx *ctx, const NqArgs &a, long long cap)
@@ -752,9 +709,8 @@ static int launch_scan(ls_ctx *ctx, const NqArgs &a, long long k_max)
     if (want_waves < 1) want_waves = 1;
     const long long bpr_cap = (want_waves + 3) / 4;
     // 0 = default: FP32 registers (n <= 4096), packed u16 registers (n <= 8192), LDS beyond;
-    // 1 = packed u16, 2 = int32 masks (tuning/measurement knobs, LS_NQ_SCAN_VARIANT)
+    // 1 = packed u16 also for n <= 4096 (measurement knob, LS_NQ_SCAN_VARIANT)
     const int variant = ctx->nq_scan_variant;
-    if (n <= 4096 && variant == 2) return launch_scan_i32(ctx, a, bpr_cap);
     if (n <= 4096 && variant != 1) return launch_scan_f32(ctx, a, bpr_cap);
     if (n <= 8192) return launch_scan_pk16(ctx, a, bpr_cap);
     const int n_pad = (n + 63) & ~63;

@@ -240,10 +240,10 @@ def test_device_pointer_entry_matches_host_entry(ctx):
         assert raw[r, 2] == host[r]["best_score"]
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("variant", ["1"])
 def test_scan_formulations_agree(monkeypatch, variant):
-    # the register-scan kernel has three inner-loop formulations (fp32 product test = default,
-    # packed-u16 min3, int32 compare masks); all must be bit-identical to the oracle
+    # the register-scan kernel has two inner-loop formulations (fp32 product test = default,
+    # packed-u16 min3); both must be bit-identical to the oracle
     import ls_amd
     monkeypatch.setenv("LS_NQ_SCAN_VARIANT", variant)
     with ls_amd.Context(0, algo="scan") as c:
