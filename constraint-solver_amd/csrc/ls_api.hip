@@ -96,6 +96,7 @@ int ls_ctx_create(int device_id, ls_ctx **out)
     }
     ctx->stream = ctx->own_stream;
     if (const char *v = getenv("LS_NQ_SCAN_VARIANT")) ctx->nq_scan_variant = atoi(v);
+    ctx->sched_force_64 = getenv("LS_SCHED_FORCE_64") != nullptr;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->wave_size = prop.warpSize;
     ctx->clock_khz = prop.clockRate;

@@ -49,6 +49,7 @@ struct ls_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int nq_algo = LS_NQ_ALGO_SCAN;
+    bool sched_force_64 = false; // LS_SCHED_FORCE_64: use the full-wavefront scheduling kernel even for <= 32 days
     int nq_scan_variant = 0; // register-scan formulation: 0 auto (fp32), 1 packed u16 (LS_NQ_SCAN_VARIANT)
     int n_cus = 0;
     int wave_size = 0;

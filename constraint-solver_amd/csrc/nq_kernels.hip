@@ -658,7 +658,8 @@ static int launch_scan_board(ls_ctx *ctx, const NqArgs &a, long long bpr_cap)
     // number of waves per SIMD, so a dynamic-LDS reservation (never touched) caps residency.
     constexpr int bpc = Board::WAVES;
     constexpr size_t lds_cap = bpc >= 8 ? 0 : (size_t)(160 * 1024 / bpc - 2048 - 4 * NQ_TILE_DWORDS * 4);
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {false}; // per device: function attributes belong to the device's code object
+    bool &attr_done = attr_done_dev[ctx->device & 63];
     if (!attr_done && lds_cap > 0) {
         LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_scan_regs_kernel<Board, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));

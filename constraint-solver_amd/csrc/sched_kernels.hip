@@ -794,7 +794,7 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
     }
     hipLaunchKernelGGL(sched_locate_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a);
     LS_HIP(ctx, hipGetLastError());
-    if (ctx->sched.n_days_stored <= 32 && !getenv("LS_SCHED_FORCE_64"))
+    if (ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64)
         hipLaunchKernelGGL(sched_eval32_kernel, dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
     else
         hipLaunchKernelGGL(sched_eval_kernel, dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
