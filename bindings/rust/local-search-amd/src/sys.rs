@@ -46,6 +46,14 @@ extern "C" {
     pub fn ls_nqueens_eval_batch_dev(ctx: *mut ls_ctx, n_restarts: i32, n: i32, rows_d: *const i32,
                                      cur_scores_d: *const i64, cols_d: *const i32, n_cols_d: *const i32, max_cols: i32,
                                      window: i64, results_d: *mut ls_nq_result, scores_out_d: *mut i64) -> c_int;
+    pub fn ls_nqueens_eval_batch_next(ctx: *mut ls_ctx, n_restarts: i32, n: i32, rows: *const i32, cur_scores: *const i64,
+                                      cols: *const i32, n_cols: *const i32, max_cols: i32, window: i64,
+                                      results: *mut ls_nq_result, next_col_scores: *mut i64) -> c_int;
+    pub fn ls_nqueens_eval_batch_next_dev(ctx: *mut ls_ctx, n_restarts: i32, n: i32, rows_d: *const i32,
+                                          cur_scores_d: *const i64, cols_d: *const i32, n_cols_d: *const i32,
+                                          max_cols: i32, window: i64, results_d: *mut ls_nq_result,
+                                          next_rows_d: *mut i32, next_col_scores_d: *mut i64,
+                                          next_scores_d: *mut i64) -> c_int;
     pub fn ls_nqueens_col_scores(ctx: *mut ls_ctx, n_restarts: i32, n: i32, rows: *const i32, col_scores: *mut i64,
                                  scores: *mut i64) -> c_int;
     pub fn ls_nqueens_col_scores_dev(ctx: *mut ls_ctx, n_restarts: i32, n: i32, rows_d: *const i32,

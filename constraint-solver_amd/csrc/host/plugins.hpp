@@ -4,6 +4,8 @@
 // every score and every neighbourhood goes through the C ABI to the HIP kernels.
 #pragma once
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <mutex>
@@ -32,10 +34,10 @@ struct NqRequest {
     const int32_t *cols;
     int32_t n_cols;
     int64_t window;
-    int64_t *col_scores_out;
+    int64_t *col_scores_out; // kind 0: column scores of rows; kind 1: of the WINNER board (same round trip)
     int64_t *total_out;
     ls_nq_result *result_out;
-    bool done;
+    std::atomic<bool> done;
 };
 
 class NqBatcher {
@@ -44,10 +46,24 @@ public:
     void submit(NqRequest *r)
     {
         std::unique_lock<std::mutex> lk(m_);
-        r->done = false;
+        r->done.store(false, std::memory_order_relaxed);
         pending_.push_back(r);
-        if ((int)pending_.size() == live_) flush_locked();
-        else cv_.wait(lk, [&] { return r->done || !error_.empty(); });
+        if ((int)pending_.size() == live_) {
+            flush_locked();
+        } else {
+            // a lockstep step lasts a few hundred microseconds: spin briefly before sleeping, a futex
+            // wake-up per restart per step would otherwise dominate
+            lk.unlock();
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!r->done.load(std::memory_order_acquire) && !failed_.load(std::memory_order_relaxed) &&
+                   std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(400)) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            lk.lock();
+            cv_.wait(lk, [&] { return r->done.load(std::memory_order_acquire) || !error_.empty(); });
+        }
         if (!error_.empty()) throw std::runtime_error(error_);
     }
     void thread_done()
@@ -60,6 +76,7 @@ public:
     {
         std::unique_lock<std::mutex> lk(m_);
         if (error_.empty()) error_ = msg;
+        failed_.store(true);
         cv_.notify_all();
     }
     uint64_t launches = 0;
@@ -95,6 +112,7 @@ private:
                 ncols_.resize(R);
                 cur_.resize(R);
                 results_.resize(R);
+                colscores_.resize(R * n_);
                 for (size_t i = 0; i < R; i++) {
                     std::copy(ev[i]->rows, ev[i]->rows + n_, rows_.begin() + i * n_);
                     std::copy(ev[i]->cols, ev[i]->cols + ev[i]->n_cols, cols_.begin() + i * max_cols);
@@ -102,16 +120,22 @@ private:
                     cur_[i] = ev[i]->cur_score;
                     if (ev[i]->window != ev[0]->window) throw std::runtime_error("restarts of one batch must share the window size");
                 }
-                check_rc(ctx_, ls_nqueens_eval_batch(ctx_, (int32_t)R, n_, rows_.data(), cur_.data(), cols_.data(), ncols_.data(),
-                                                     max_cols, ev[0]->window, results_.data(), nullptr),
-                         "ls_nqueens_eval_batch");
+                check_rc(ctx_, ls_nqueens_eval_batch_next(ctx_, (int32_t)R, n_, rows_.data(), cur_.data(), cols_.data(),
+                                                          ncols_.data(), max_cols, ev[0]->window, results_.data(),
+                                                          colscores_.data()),
+                         "ls_nqueens_eval_batch_next");
                 launches++;
-                for (size_t i = 0; i < R; i++) *ev[i]->result_out = results_[i];
+                for (size_t i = 0; i < R; i++) {
+                    *ev[i]->result_out = results_[i];
+                    if (ev[i]->col_scores_out)
+                        std::copy(colscores_.begin() + i * n_, colscores_.begin() + (i + 1) * n_, ev[i]->col_scores_out);
+                }
             }
         } catch (const std::exception &e) {
             if (error_.empty()) error_ = e.what();
+            failed_.store(true);
         }
-        for (NqRequest *r : pending_) r->done = true;
+        for (NqRequest *r : pending_) r->done.store(true, std::memory_order_release);
         pending_.clear();
         cv_.notify_all();
     }
@@ -122,6 +146,7 @@ private:
     std::condition_variable cv_;
     std::vector<NqRequest *> pending_;
     std::string error_;
+    std::atomic<bool> failed_{false};
     std::vector<int32_t> rows_, cols_, ncols_;
     std::vector<int64_t> cur_, colscores_, totals_;
     std::vector<ls_nq_result> results_;
@@ -138,7 +163,13 @@ struct NQueensProblem {
     size_t board_size;
     NqBatcher *batcher = nullptr; // set when this restart is one of a lockstep batch
     // statistics
-    uint64_t neighbours_scored = 0, gpu_evals = 0;
+    uint64_t neighbours_scored = 0, gpu_evals = 0, gpu_col_score_calls = 0;
+    // column scores of the board the loop will expand next, delivered by the previous neighbourhood's
+    // round trip (or by score()): saves one GPU round trip per LS iteration
+    mutable Solution cached_board;
+    mutable std::vector<int64_t> cached_cs;
+    mutable int64_t cached_total = 0;
+    mutable bool cache_valid = false;
 
     NQueensProblem(ls_ctx *c, size_t n, NqBatcher *b = nullptr) : ctx(c), board_size(n), batcher(b) {}
 
@@ -161,15 +192,23 @@ struct NQueensProblem {
     // get_col_scores (lib.rs:74-87) on the GPU; also returns the sum (lib.rs:130-139)
     std::vector<int64_t> col_scores(const Solution &s, int64_t *total) const
     {
+        if (cache_valid && s == cached_board) {
+            if (total) *total = cached_total;
+            return cached_cs;
+        }
+        const_cast<NQueensProblem *>(this)->gpu_col_score_calls++;
         const std::vector<int32_t> rows = pack(s);
         std::vector<int64_t> cs(s.size());
         int64_t tot = 0;
         if (batcher) {
-            NqRequest rq{0, rows.data(), 0, nullptr, 0, 0, cs.data(), &tot, nullptr, false};
+            NqRequest rq;
+            rq.kind = 0; rq.rows = rows.data(); rq.cur_score = 0; rq.cols = nullptr; rq.n_cols = 0; rq.window = 0;
+            rq.col_scores_out = cs.data(); rq.total_out = &tot; rq.result_out = nullptr;
             batcher->submit(&rq);
         } else
             check_rc(ctx, ls_nqueens_col_scores(ctx, 1, (int32_t)s.size(), rows.data(), cs.data(), &tot), "ls_nqueens_col_scores");
         if (total) *total = tot;
+        cached_board = s; cached_cs = cs; cached_total = tot; cache_valid = true;
         return cs;
     }
     Score score(const Solution &s) const
@@ -213,19 +252,27 @@ struct NQueensProblem {
         if (cols.empty()) return false;
         const std::vector<int32_t> rows = pack(current.solution);
         ls_nq_result res;
+        std::vector<int64_t> next_cs(rows.size());
         if (batcher) {
-            NqRequest rq{1, rows.data(), current.score, cols.data(), (int32_t)cols.size(), (int64_t)window, nullptr, nullptr,
-                         &res, false};
+            NqRequest rq;
+            rq.kind = 1; rq.rows = rows.data(); rq.cur_score = current.score; rq.cols = cols.data();
+            rq.n_cols = (int32_t)cols.size(); rq.window = (int64_t)window;
+            rq.col_scores_out = next_cs.data(); rq.total_out = nullptr; rq.result_out = &res;
             batcher->submit(&rq);
-        } else
-            check_rc(ctx, ls_nqueens_eval(ctx, (int32_t)rows.size(), rows.data(), current.score, cols.data(),
-                                          (int32_t)cols.size(), (int64_t)window, &res, nullptr), "ls_nqueens_eval");
+        } else {
+            const int32_t nc = (int32_t)cols.size();
+            check_rc(ctx, ls_nqueens_eval_batch_next(ctx, 1, (int32_t)rows.size(), rows.data(), &current.score, cols.data(),
+                                                     &nc, nc, (int64_t)window, &res, next_cs.data()),
+                     "ls_nqueens_eval_batch_next");
+        }
         gpu_evals++;
         neighbours_scored += (uint64_t)res.n_scored;
         if (res.best_index < 0) return false;
         out.solution = current.solution;
         out.solution[(size_t)res.best_col] = res.best_value; // MoveIterator, lib.rs:226-228
         out.score = res.best_score;
+        // the loop continues from this board (local_search.rs:335): its column scores came back with the result
+        cached_board = out.solution; cached_cs.swap(next_cs); cached_total = res.best_score; cache_valid = true;
         return true;
     }
 

@@ -32,6 +32,7 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
                       ls_nq_result *results_d, long long *scores_out_d);
 int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, long long *col_scores_d,
                       long long *scores_d);
+int nq_apply_best_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, const ls_nq_result *results_d, int *next_rows_d);
 // sched_kernels.hip
 int sched_score_dev(ls_ctx *ctx, int n_states, const int *states_d, long long *hard_d, long long *soft_d,
                     long long *terms_d);
@@ -118,7 +119,7 @@ int ls_ctx_destroy(ls_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->nq_rows, &ctx->nq_cur, &ctx->nq_cols, &ctx->nq_ncols, &ctx->nq_results,
-                      &ctx->nq_scores, &ctx->nq_keys, &ctx->nq_tabs, &ctx->nq_colscores, &ctx->nq_totals,
+                      &ctx->nq_scores, &ctx->nq_keys, &ctx->nq_tabs, &ctx->nq_colscores, &ctx->nq_totals, &ctx->nq_next_rows,
                       &ctx->sc_states, &ctx->sc_moves, &ctx->sc_nmoves, &ctx->sc_results, &ctx->sc_hard,
                       &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sched.holiday_bits, &ctx->sched.lane_tab};
     for (DevBuf *b : bufs) b->release();
@@ -242,6 +243,64 @@ int ls_nqueens_eval_batch(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int3
     if (rc != LS_OK) return rc;
     LS_HIP(ctx, hipMemcpyAsync(results, ctx->nq_results.p, res_b, hipMemcpyDeviceToHost, ctx->stream));
     if (sc_b) LS_HIP(ctx, hipMemcpyAsync(scores_out, ctx->nq_scores.p, sc_b, hipMemcpyDeviceToHost, ctx->stream));
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LS_OK;
+}
+
+int ls_nqueens_eval_batch_next_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows_d,
+                                   const int64_t *cur_scores_d, const int32_t *cols_d, const int32_t *n_cols_d,
+                                   int32_t max_cols, int64_t window, ls_nq_result *results_d, int32_t *next_rows_d,
+                                   int64_t *next_col_scores_d, int64_t *next_scores_d)
+{
+    int rc = ls_nqueens_eval_batch_dev(ctx, n_restarts, n, rows_d, cur_scores_d, cols_d, n_cols_d, max_cols, window,
+                                       results_d, nullptr);
+    if (rc != LS_OK) return rc;
+    LS_REQUIRE(ctx, next_rows_d && next_col_scores_d, "null device pointer");
+    rc = nq_apply_best_dev(ctx, n_restarts, n, rows_d, results_d, next_rows_d);
+    if (rc != LS_OK) return rc;
+    return nq_col_scores_dev(ctx, n_restarts, n, next_rows_d, reinterpret_cast<long long *>(next_col_scores_d),
+                             reinterpret_cast<long long *>(next_scores_d));
+}
+
+int ls_nqueens_eval_batch_next(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows,
+                               const int64_t *cur_scores, const int32_t *cols, const int32_t *n_cols, int32_t max_cols,
+                               int64_t window, ls_nq_result *results, int64_t *next_col_scores)
+{
+    LS_BIND(ctx);
+    int rc = nq_check_dims(ctx, n_restarts, n, max_cols, window);
+    if (rc != LS_OK) return rc;
+    LS_REQUIRE(ctx, rows && cur_scores && n_cols && results && next_col_scores && (cols || max_cols == 0), "null pointer");
+    for (long long i = 0; i < (long long)n_restarts * n; i++)
+        LS_REQUIRE(ctx, rows[i] >= 0 && rows[i] < n, "rows[%lld] = %d outside [0, %d)", i, rows[i], n);
+    for (int r = 0; r < n_restarts; r++) {
+        LS_REQUIRE(ctx, n_cols[r] >= 0 && n_cols[r] <= max_cols, "n_cols[%d] = %d outside [0, max_cols = %d]", r,
+                   n_cols[r], max_cols);
+        for (int s = 0; s < n_cols[r]; s++) {
+            const int c = cols[(long long)r * max_cols + s];
+            LS_REQUIRE(ctx, c >= 0 && c < n, "cols[%d][%d] = %d outside [0, %d)", r, s, c, n);
+        }
+    }
+    const size_t rows_b = (size_t)n_restarts * n * 4, cur_b = (size_t)n_restarts * 8,
+                 cols_b = (size_t)n_restarts * max_cols * 4, nc_b = (size_t)n_restarts * 4,
+                 res_b = (size_t)n_restarts * sizeof(ls_nq_result), cs_b = (size_t)n_restarts * n * 8;
+    LS_RESERVE(ctx, ctx->nq_rows, rows_b);
+    LS_RESERVE(ctx, ctx->nq_cur, cur_b);
+    LS_RESERVE(ctx, ctx->nq_cols, cols_b);
+    LS_RESERVE(ctx, ctx->nq_ncols, nc_b);
+    LS_RESERVE(ctx, ctx->nq_results, res_b);
+    LS_RESERVE(ctx, ctx->nq_next_rows, rows_b);
+    LS_RESERVE(ctx, ctx->nq_colscores, cs_b);
+    LS_HIP(ctx, hipMemcpyAsync(ctx->nq_rows.p, rows, rows_b, hipMemcpyHostToDevice, ctx->stream));
+    LS_HIP(ctx, hipMemcpyAsync(ctx->nq_cur.p, cur_scores, cur_b, hipMemcpyHostToDevice, ctx->stream));
+    if (cols_b) LS_HIP(ctx, hipMemcpyAsync(ctx->nq_cols.p, cols, cols_b, hipMemcpyHostToDevice, ctx->stream));
+    LS_HIP(ctx, hipMemcpyAsync(ctx->nq_ncols.p, n_cols, nc_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = ls_nqueens_eval_batch_next_dev(ctx, n_restarts, n, ctx->nq_rows.as<int>(), ctx->nq_cur.as<int64_t>(),
+                                        ctx->nq_cols.as<int>(), ctx->nq_ncols.as<int>(), max_cols, window,
+                                        ctx->nq_results.as<ls_nq_result>(), ctx->nq_next_rows.as<int>(),
+                                        ctx->nq_colscores.as<int64_t>(), nullptr);
+    if (rc != LS_OK) return rc;
+    LS_HIP(ctx, hipMemcpyAsync(results, ctx->nq_results.p, res_b, hipMemcpyDeviceToHost, ctx->stream));
+    LS_HIP(ctx, hipMemcpyAsync(next_col_scores, ctx->nq_colscores.p, cs_b, hipMemcpyDeviceToHost, ctx->stream));
     LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LS_OK;
 }

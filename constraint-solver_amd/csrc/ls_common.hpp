@@ -59,7 +59,7 @@ struct ls_ctx {
 
     // persistent workspaces (grow-only)
     lsamd::DevBuf nq_rows, nq_cur, nq_cols, nq_ncols, nq_results, nq_scores, nq_keys, nq_tabs,
-        nq_colscores, nq_totals;
+        nq_colscores, nq_totals, nq_next_rows;
     lsamd::DevBuf sc_states, sc_moves, sc_nmoves, sc_results, sc_hard, sc_soft, sc_keys, sc_terms;
     lsamd::SchedInstance sched;
 };

@@ -804,6 +804,29 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
     return LS_OK;
 }
 
+// winner board of each restart: rows with the selected move applied (MoveIterator, lib.rs:226-228)
+__global__ __launch_bounds__(256) void nq_apply_best_kernel(const int *rows, int n, const ls_nq_result *results, int *next_rows)
+{
+    const int r = blockIdx.y;
+    const ls_nq_result res = results[r];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        int v = rows[(long long)r * n + j];
+        if (res.best_index >= 0 && j == res.best_col) v = res.best_value;
+        next_rows[(long long)r * n + j] = v;
+    }
+}
+
+int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, long long *col_scores_d, long long *scores_d);
+
+int nq_apply_best_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, const ls_nq_result *results_d, int *next_rows_d)
+{
+    int gx = (n + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(nq_apply_best_kernel, dim3(gx, n_restarts), dim3(256), 0, ctx->stream, rows_d, n, results_d, next_rows_d);
+    LS_HIP(ctx, hipGetLastError());
+    return LS_OK;
+}
+
 int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, long long *col_scores_d,
                       long long *scores_d)
 {

@@ -100,6 +100,22 @@ class Context:
                     best_col=r.best_col, best_value=r.best_value) for r in res]
         return out, scores
 
+    def nqueens_eval_batch_next(self, rows, cur_scores, cols, n_cols, window):
+        """Like nqueens_eval_batch, plus get_col_scores of every restart's winner board [R, n]."""
+        rows = _c(rows, np.int32)
+        R, n = rows.shape
+        cur = _c(cur_scores, np.int64).reshape(R)
+        cols = _c(cols, np.int32).reshape(R, -1)
+        max_cols = cols.shape[1]
+        ncols = _c(n_cols, np.int32).reshape(R)
+        res = (NqResult * R)()
+        nxt = np.empty((R, n), dtype=np.int64)
+        self._check(self._l.ls_nqueens_eval_batch_next(self._h, R, n, _vp(rows), _vp(cur), _vp(cols), _vp(ncols), max_cols,
+                                                       int(window), C.cast(res, C.c_void_p), _vp(nxt)))
+        out = [dict(n_scored=r.n_scored, best_index=r.best_index, best_score=r.best_score,
+                    best_col=r.best_col, best_value=r.best_value) for r in res]
+        return out, nxt
+
     def nqueens_eval(self, rows, cur_score, cols, window, want_scores=False):
         rows = _c(rows, np.int32).reshape(1, -1)
         cols = _c(cols, np.int32).reshape(1, -1)

@@ -71,6 +71,8 @@ SIGNATURES = {
     "ls_nqueens_eval": (C.c_int, [_vp, _i32, _vp, _i64, _vp, _i32, _i64, _vp, _vp]),
     "ls_nqueens_eval_batch": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
     "ls_nqueens_eval_batch_dev": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
+    "ls_nqueens_eval_batch_next": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
+    "ls_nqueens_eval_batch_next_dev": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
     "ls_nqueens_col_scores": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "ls_nqueens_col_scores_dev": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "ls_sched_instance_upload": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp]),

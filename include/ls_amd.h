@@ -148,6 +148,23 @@ int ls_nqueens_eval_batch_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n,
                               const int32_t *cols_d, const int32_t *n_cols_d, int32_t max_cols,
                               int64_t window, ls_nq_result *results_d, int64_t *scores_out_d);
 
+/* Neighbourhood AND the proposer's input for the next LS iteration in one round trip: besides the
+ * results, next_col_scores[n_restarts][n] receives get_col_scores (lib.rs:74-87) of each restart's
+ * winner board (rows with rows[best_col] = best_value; of rows itself when nothing was scored) —
+ * what iter_local_moves computes first when the loop continues from the winner
+ * (local_search.rs:335, nqueens lib.rs:182).  The winner's total is results[r].best_score. */
+int ls_nqueens_eval_batch_next(ls_ctx *ctx, int32_t n_restarts, int32_t n,
+                               const int32_t *rows, const int64_t *cur_scores,
+                               const int32_t *cols, const int32_t *n_cols, int32_t max_cols,
+                               int64_t window, ls_nq_result *results, int64_t *next_col_scores);
+/* Device-pointer flavour (asynchronous): next_rows_d[n_restarts][n] receives the winner boards,
+ * next_col_scores_d[n_restarts][n] their column scores, next_scores_d[n_restarts] (nullable) the sums. */
+int ls_nqueens_eval_batch_next_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n,
+                                   const int32_t *rows_d, const int64_t *cur_scores_d,
+                                   const int32_t *cols_d, const int32_t *n_cols_d, int32_t max_cols,
+                                   int64_t window, ls_nq_result *results_d, int32_t *next_rows_d,
+                                   int64_t *next_col_scores_d, int64_t *next_scores_d);
+
 /* get_col_scores + its sum (examples/nqueens/src/lib.rs:74-87,130-139) for a
  * batch of boards, by occupancy count tables: col_scores[n_restarts][n]
  * (nullable), scores[n_restarts] (nullable).  This is the vector the move

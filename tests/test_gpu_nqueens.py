@@ -294,3 +294,27 @@ def test_device_entry_is_graph_capturable(ctx):
                 assert out[r, 0] == exp["n_scored"] and out[r, 1] == exp["best_index"] and out[r, 2] == exp["best_score"]
     finally:
         ctx.set_stream(None)
+
+
+def test_eval_next_returns_winner_column_scores(ctx):
+    # one round trip: neighbourhood result + get_col_scores of the winner board (the proposer's next input)
+    rng = np.random.default_rng(31)
+    n, R, mc = 300, 5, 4
+    rows = np.stack([_board(rng, n, "uniform") for _ in range(R)])
+    cols = np.stack([rng.permutation(n)[:mc] for _ in range(R)])
+    n_cols = np.array([mc, mc, 0, 1, mc])
+    cur = [orc.nq_score(rows[r]) for r in range(R)]
+    for algo in ALGOS:
+        ctx.set_algo(algo)
+        out, nxt = ctx.nqueens_eval_batch_next(rows, cur, cols, n_cols, 2 * n)
+        ref, _ = ctx.nqueens_eval_batch(rows, cur, cols, n_cols, 2 * n)
+        assert out == ref
+        for r in range(R):
+            b = rows[r].copy()
+            if out[r]["best_index"] >= 0:
+                b[out[r]["best_col"]] = out[r]["best_value"]
+            exp = orc.nq_col_scores(b)                      # literal lib.rs:74-87
+            assert np.array_equal(nxt[r], exp)
+            if out[r]["best_index"] >= 0:
+                assert exp.sum() == out[r]["best_score"]
+    ctx.set_algo("scan")
