@@ -24,7 +24,7 @@
 // Kernel families
 //   SCAN  (default, north-star shape): one wavefront per candidate; the packed
 //         state lives in the wavefront's registers (n <= 4096) or in LDS
-//         (n <= 32768); per-lane match counts are reduced with DPP adds; each
+//         (n <= 32768); per-lane match counts are reduced with DPP adds or a wave-private LDS transpose; each
 //         wavefront keeps a running key minimum, blocks combine through LDS and
 //         publish with one 64-bit atomicMin.
 //   TABLE occupancy histograms (rows / two diagonals) built once per board;
@@ -35,7 +35,6 @@ namespace lsamd {
 
 constexpr int NQ_DELTA_BIAS = 1 << 17; // |delta| <= n + 2 <= 32770
 constexpr unsigned long long NQ_KEY_EMPTY = ~0ull;
-constexpr int NQ_SENT = -(1 << 30); // padding value that can never satisfy an equality
 
 struct NqArgs {
     const int *rows;             // [n_restarts][n]
@@ -402,35 +401,51 @@ __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs 
     }
 }
 
-// LDS-resident state for n > 4096 (any n <= LS_NQ_MAX_N): 4*ceil64(n) bytes.
-__device__ __forceinline__ int nq_count1_lds(const int *sR, int n_pad, int lane, int v, int va, int vb)
+// LDS-resident state for n > 4096 (any n <= LS_NQ_MAX_N): the board as floats, 4*ceil64(n) bytes,
+// shared by the 16 wavefronts of a 1024-thread block (so that even n = 32768, whose 128 KB allow one
+// block per CU, runs 4 waves per SIMD).  Same fp32 product test as BoardF32; |j - c| is formed on the
+// fly (two extra instructions per column visit, shared by the four interleaved candidates).
+#define LS_F32_LDS_STEP                                                                              \
+    "v_sub_f32_e32 %4, %12, %14\n\tv_sub_f32_e32 %5, %12, %15\n\t"                                   \
+    "v_sub_f32_e32 %6, %12, %16\n\tv_sub_f32_e32 %7, %12, %17\n\t"                                   \
+    "v_sub_f32_e64 %8, |%4|, |%13|\n\tv_sub_f32_e64 %9, |%5|, |%13|\n\t"                             \
+    "v_sub_f32_e64 %10, |%6|, |%13|\n\tv_sub_f32_e64 %11, |%7|, |%13|\n\t"                           \
+    "v_mul_f32_e64 %4, |%4|, |%8| clamp\n\tv_mul_f32_e64 %5, |%5|, |%9| clamp\n\t"                   \
+    "v_mul_f32_e64 %6, |%6|, |%10| clamp\n\tv_mul_f32_e64 %7, |%7|, |%11| clamp\n\t"                 \
+    "v_add_f32_e32 %0, %0, %4\n\tv_add_f32_e32 %1, %1, %5\n\t"                                       \
+    "v_add_f32_e32 %2, %2, %6\n\tv_add_f32_e32 %3, %3, %7"
+
+// attack counts (wave-uniform) of (c, v) .. (c, v+3): columns scanned minus mismatches
+__device__ __forceinline__ void nq_count4_lds(const float *sR, int n_pad, int lane, int v, int c, int (&cnt)[4])
 {
-    int c = 0;
+    const float f0 = (float)v, f1 = (float)(v + 1), f2 = (float)(v + 2), f3 = (float)(v + 3);
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    float jc = (float)(lane - c); // j - c for this lane's column of the current visit
     for (int j = lane; j < n_pad; j += 64) {
-        const int r = sR[j];
-        c += (int)((r == v) | (r - j == va) | (r + j == vb));
+        const float r = sR[j];
+        float d0, d1, d2, d3, u0, u1, u2, u3;
+        asm(LS_F32_LDS_STEP
+            : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(u0), "=&v"(u1),
+              "=&v"(u2), "=&v"(u3)
+            : "v"(r), "v"(jc), "v"(f0), "v"(f1), "v"(f2), "v"(f3));
+        jc += 64.0f;
     }
-    return wave_sum_i32(c);
+    // per-lane mismatches <= n_pad/64 <= 512; wave totals of matches <= n + 2 < 2^16: two per register
+    const int visits = n_pad >> 6;
+    const unsigned t01 = (unsigned)wave_sum_i32((visits - (int)m0) | ((visits - (int)m1) << 16));
+    const unsigned t23 = (unsigned)wave_sum_i32((visits - (int)m2) | ((visits - (int)m3) << 16));
+    cnt[0] = (int)(t01 & 0xffffu); cnt[1] = (int)(t01 >> 16);
+    cnt[2] = (int)(t23 & 0xffffu); cnt[3] = (int)(t23 >> 16);
 }
 
-__device__ __forceinline__ void nq_scan_range_lds(const int *sR, int n_pad, int vbeg, int vend, int c,
+__device__ __forceinline__ void nq_scan_range_lds(const float *sR, int n_pad, int vbeg, int vend, int c,
                                                   int conf_old, unsigned long long khi,
                                                   unsigned long long &best, long long *scores_row,
                                                   long long cur, int lane)
 {
     for (int v = vbeg; v < vend; v += 4) {
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        const int va = v - c, vb = v + c;
-        for (int j = lane; j < n_pad; j += 64) {
-            const int r = sR[j];
-            const int a = r - j, b = r + j;
-            c0 += (int)((r == v) | (a == va) | (b == vb));
-            c1 += (int)((r == v + 1) | (a == va + 1) | (b == vb + 1));
-            c2 += (int)((r == v + 2) | (a == va + 2) | (b == vb + 2));
-            c3 += (int)((r == v + 3) | (a == va + 3) | (b == vb + 3));
-        }
-        // per-lane counts <= 3*512; wave totals <= n + 2 <= 32770 < 2^16
-        const int cnt[4] = {wave_sum_i32(c0), wave_sum_i32(c1), wave_sum_i32(c2), wave_sum_i32(c3)};
+        int cnt[4];
+        nq_count4_lds(sR, n_pad, lane, v, c, cnt);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (v + u < vend) {
@@ -442,21 +457,24 @@ __device__ __forceinline__ void nq_scan_range_lds(const int *sR, int n_pad, int 
     }
 }
 
-__global__ __launch_bounds__(256) void nq_scan_lds_kernel(NqArgs a)
+constexpr int NQ_LDS_BLOCK = 1024;
+
+__global__ __launch_bounds__(NQ_LDS_BLOCK) void nq_scan_lds_kernel(NqArgs a)
 {
-    extern __shared__ int s_dyn[]; // [n_pad] state, then 4 x u64 best (8-byte aligned: n_pad % 64 == 0)
+    extern __shared__ float s_dynf[]; // [n_pad] state as floats, then 16 x u64 best (8-byte aligned: n_pad % 64 == 0)
+    constexpr int WPB = NQ_LDS_BLOCK / 64;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int restart = blockIdx.x % a.n_restarts;
-    const int wchunk = (blockIdx.x / a.n_restarts) * 4 + wib;
-    const int n_wchunks = (gridDim.x / a.n_restarts) * 4;
+    const int wchunk = (blockIdx.x / a.n_restarts) * WPB + wib;
+    const int n_wchunks = (gridDim.x / a.n_restarts) * WPB;
     const int n = a.n;
     const int n_pad = (n + 63) & ~63;
-    int *sR = s_dyn;
-    unsigned long long *s_best = reinterpret_cast<unsigned long long *>(s_dyn + n_pad);
+    float *sR = s_dynf;
+    unsigned long long *s_best = reinterpret_cast<unsigned long long *>(s_dynf + n_pad);
     const int *__restrict__ rows = a.rows + (long long)restart * n;
     const int *__restrict__ cols = a.cols + (long long)restart * a.max_cols;
-    for (int j = threadIdx.x; j < n_pad; j += 256) sR[j] = j < n ? rows[j] : NQ_SENT;
+    for (int j = threadIdx.x; j < n_pad; j += NQ_LDS_BLOCK) sR[j] = j < n ? (float)rows[j] : 1.0e9f; // padding never matches
     __syncthreads();
     int ncols = a.n_cols[restart];
     ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
@@ -474,18 +492,20 @@ __global__ __launch_bounds__(256) void nq_scan_lds_kernel(NqArgs a)
             const int ve = (left < (long long)(n - v0)) ? (int)(v0 + left) : n;
             const int c = cols[slot];
             if ((unsigned)c < (unsigned)n) {
-                const int rc = sR[c];
+                const int rc = rows[c];
                 const long long base = (long long)slot * (n - 1);
                 const NqRanges rg = nq_ranges(v0, ve, rc, base, a.window);
                 if (rg.d1 > rg.d0 || rg.u1 > rg.u0) {
-                    const int conf_old = nq_count1_lds(sR, n_pad, lane, rc, rc - c, rc + c) - 1;
+                    int cnt[4];
+                    nq_count4_lds(sR, n_pad, lane, rc, c, cnt);
+                    const int conf_old = cnt[0] - 1; // the own queen satisfies the product test once
                     long long *srow = a.scores_out
                                           ? a.scores_out + ((long long)restart * a.max_cols + slot) * n
                                           : nullptr;
-                    nq_scan_range_lds(sR, n_pad, rg.d0, rg.d1, c, conf_old, nq_key_hi(0, c, n, slot), best, srow,
-                                      cur, lane);
-                    nq_scan_range_lds(sR, n_pad, rg.u0, rg.u1, c, conf_old, nq_key_hi(1, c, n, slot), best, srow,
-                                      cur, lane);
+                    nq_scan_range_lds(sR, n_pad, rg.d0, rg.d1, c, conf_old, nq_key_hi(0, c, n, slot), best,
+                                      srow, cur, lane);
+                    nq_scan_range_lds(sR, n_pad, rg.u0, rg.u1, c, conf_old, nq_key_hi(1, c, n, slot), best,
+                                      srow, cur, lane);
                 }
             }
             k += ve - v0;
@@ -496,7 +516,8 @@ __global__ __launch_bounds__(256) void nq_scan_lds_kernel(NqArgs a)
     if (lane == 0) s_best[wib] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long b = u64min(u64min(s_best[0], s_best[1]), u64min(s_best[2], s_best[3]));
+        unsigned long long b = s_best[0];
+        for (int i = 1; i < WPB; i++) b = u64min(b, s_best[i]);
         if (b != NQ_KEY_EMPTY) atomicMin(&a.best_keys[restart], b);
     }
 }
@@ -713,17 +734,20 @@ static int launch_scan(ls_ctx *ctx, const NqArgs &a, long long k_max)
     // 1 = packed u16 also for n <= 4096 (measurement knob, LS_NQ_SCAN_VARIANT)
     const int variant = ctx->nq_scan_variant;
     if (n <= 4096 && variant != 1) return launch_scan_f32(ctx, a, bpr_cap);
-    if (n <= 8192) return launch_scan_pk16(ctx, a, bpr_cap);
+    if (n <= 8192 && variant == 1) return launch_scan_pk16(ctx, a, bpr_cap);
     const int n_pad = (n + 63) & ~63;
-    const size_t lds = (size_t)n_pad * 4 + 32;
+    const size_t lds = (size_t)n_pad * 4 + 16 * 8;
     LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_scan_lds_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    const int bpc = nq_blocks_per_cu(reinterpret_cast<const void *>(&nq_scan_lds_kernel), lds);
-    long long total = (long long)ctx->n_cus * bpc;
-    long long bpr = total / a.n_restarts;
+    // 1024-thread blocks: two per CU fill the wave slots; LDS may allow only one
+    int bpc = (int)((160 * 1024) / (lds + 256));
+    bpc = bpc < 1 ? 1 : (bpc > 2 ? 2 : bpc);
+    const long long want_blocks = (want_waves + 15) / 16;
+    long long bpr = ((long long)ctx->n_cus * bpc) / a.n_restarts;
     if (bpr < 1) bpr = 1;
-    if (bpr > bpr_cap) bpr = bpr_cap;
-    hipLaunchKernelGGL(nq_scan_lds_kernel, dim3((unsigned)(bpr * a.n_restarts)), dim3(256), lds, ctx->stream, a);
+    if (bpr > want_blocks) bpr = want_blocks;
+    if (bpr < 1) bpr = 1;
+    hipLaunchKernelGGL(nq_scan_lds_kernel, dim3((unsigned)(bpr * a.n_restarts)), dim3(NQ_LDS_BLOCK), lds, ctx->stream, a);
     LS_HIP(ctx, hipGetLastError());
     return LS_OK;
 }
