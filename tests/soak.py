@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised parity soak (not part of the test suite): random N-queens and scheduling
-neighbourhoods through every kernel path vs the CPU oracle.  Usage: python tools/soak.py [seconds] [seed]"""
+"""Randomised parity soak (test infrastructure; not collected by pytest): random N-queens and scheduling
+neighbourhoods through every kernel path vs the CPU oracle.  Usage: python tests/soak.py [seconds] [seed]"""
 import os
 import sys
 import time
