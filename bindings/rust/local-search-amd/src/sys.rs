@@ -64,6 +64,9 @@ extern "C" {
                           terms: *mut i64) -> c_int;
     pub fn ls_sched_eval(ctx: *mut ls_ctx, state: *const i32, moves: *const ls_sched_move, n_moves: i64, window: i64,
                          out: *mut ls_sched_result, hard_out: *mut i64, soft_out: *mut i64) -> c_int;
+    pub fn ls_sched_moves_upload(ctx: *mut ls_ctx, moves: *const ls_sched_move, n_moves: i64) -> c_int;
+    pub fn ls_sched_eval_resident(ctx: *mut ls_ctx, state: *const i32, n_moves: i64, window: i64,
+                                  out: *mut ls_sched_result) -> c_int;
     pub fn ls_sched_eval_batch(ctx: *mut ls_ctx, n_restarts: i32, states: *const i32, moves: *const ls_sched_move,
                                n_moves: *const i64, max_moves: i64, window: i64, results: *mut ls_sched_result,
                                hard_out: *mut i64, soft_out: *mut i64) -> c_int;

@@ -310,6 +310,7 @@ struct SchedProblem {
     std::vector<ls_sched_move> stream;
     ChaCha20Rng stream_rng;
     bool stream_started = false;
+    size_t resident = 0; // entries of `stream` already on the device (ls_sched_moves_upload)
 
     SchedProblem(ls_ctx *c, int32_t d, int32_t s, int32_t e) : ctx(c), n_days_scored(d), n_days_stored(s), n_employees(e) {}
 
@@ -354,9 +355,14 @@ struct SchedProblem {
         size_t want = window + window / 4 + 16;
         for (;;) {
             extend_stream(rng, want);
+            if (resident < want) { // the stream is the same for the whole run: keep it on the device
+                extend_stream(rng, want + want / 2);
+                check_rc(ctx, ls_sched_moves_upload(ctx, stream.data(), (int64_t)stream.size()), "ls_sched_moves_upload");
+                resident = stream.size();
+            }
             ls_sched_result res;
-            check_rc(ctx, ls_sched_eval(ctx, current.solution.data(), stream.data(), (int64_t)want, (int64_t)window, &res,
-                                        nullptr, nullptr), "ls_sched_eval");
+            check_rc(ctx, ls_sched_eval_resident(ctx, current.solution.data(), (int64_t)want, (int64_t)window, &res),
+                     "ls_sched_eval_resident");
             gpu_evals++;
             if ((size_t)res.n_scored == window) {
                 neighbours_scored += (uint64_t)res.n_scored;

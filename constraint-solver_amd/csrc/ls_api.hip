@@ -121,7 +121,8 @@ int ls_ctx_destroy(ls_ctx *ctx)
     DevBuf *bufs[] = {&ctx->nq_rows, &ctx->nq_cur, &ctx->nq_cols, &ctx->nq_ncols, &ctx->nq_results,
                       &ctx->nq_scores, &ctx->nq_keys, &ctx->nq_tabs, &ctx->nq_colscores, &ctx->nq_totals, &ctx->nq_next_rows,
                       &ctx->sc_states, &ctx->sc_moves, &ctx->sc_nmoves, &ctx->sc_results, &ctx->sc_hard,
-                      &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sched.holiday_bits, &ctx->sched.lane_tab};
+                      &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sched.holiday_bits, &ctx->sched.lane_tab,
+                      &ctx->sc_resident_moves};
     for (DevBuf *b : bufs) b->release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -482,6 +483,65 @@ int ls_sched_eval_batch(ls_ctx *ctx, int32_t n_restarts, const int32_t *states, 
         LS_HIP(ctx, hipMemcpyAsync(hard_out, ctx->sc_hard.p, out_b, hipMemcpyDeviceToHost, ctx->stream));
     if (soft_out && out_b)
         LS_HIP(ctx, hipMemcpyAsync(soft_out, ctx->sc_soft.p, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LS_OK;
+}
+
+static int sched_check_moves(ls_ctx *ctx, const ls_sched_move *moves, long long n, int r)
+{
+    const int S = ctx->sched.n_days_stored, E = ctx->sched.n_employees;
+    for (long long k = 0; k < n; k++) {
+        const ls_sched_move &m = moves[k];
+        if (m.type == 0)
+            LS_REQUIRE(ctx, m.a >= 0 && m.a < S && m.b >= 0 && m.b < E, "move %lld of restart %d: bad ChangeDay(%d, %d)", k, r,
+                       m.a, m.b);
+        else if (m.type == 1)
+            LS_REQUIRE(ctx, m.a >= 0 && m.a < S && m.b >= 0 && m.b < S, "move %lld of restart %d: bad SwapDays(%d, %d)", k, r,
+                       m.a, m.b);
+        else
+            return set_err(ctx, LS_ERR_INVALID, "move %lld of restart %d: unknown type %d", k, r, m.type);
+    }
+    return LS_OK;
+}
+
+int ls_sched_moves_upload(ls_ctx *ctx, const ls_sched_move *moves, int64_t n_moves)
+{
+    LS_BIND(ctx);
+    if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
+    LS_REQUIRE(ctx, n_moves >= 0 && (moves || n_moves == 0), "bad arguments");
+    int rc = sched_check_moves(ctx, moves, n_moves, 0);
+    if (rc != LS_OK) return rc;
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the stream may still read the previous list
+    LS_RESERVE(ctx, ctx->sc_resident_moves, (size_t)n_moves * sizeof(ls_sched_move));
+    if (n_moves)
+        LS_HIP(ctx, hipMemcpyAsync(ctx->sc_resident_moves.p, moves, (size_t)n_moves * sizeof(ls_sched_move),
+                                   hipMemcpyHostToDevice, ctx->stream));
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sc_resident_n = n_moves;
+    return LS_OK;
+}
+
+int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, int64_t window, ls_sched_result *out)
+{
+    LS_BIND(ctx);
+    if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
+    LS_REQUIRE(ctx, state && out && window >= 0, "bad arguments");
+    LS_REQUIRE(ctx, n_moves >= 0 && n_moves <= ctx->sc_resident_n, "n_moves = %lld exceeds the resident list (%lld)",
+               (long long)n_moves, ctx->sc_resident_n);
+    const int S = ctx->sched.n_days_stored;
+    int rc = sched_check_state(ctx, state, S);
+    if (rc != LS_OK) return rc;
+    LS_RESERVE(ctx, ctx->sc_states, (size_t)S * 4);
+    LS_RESERVE(ctx, ctx->sc_nmoves, 8);
+    LS_RESERVE(ctx, ctx->sc_results, sizeof(ls_sched_result));
+    LS_HIP(ctx, hipMemcpyAsync(ctx->sc_states.p, state, (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
+    const long long nm = n_moves;
+    LS_HIP(ctx, hipMemcpyAsync(ctx->sc_nmoves.p, &nm, 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = sched_eval_batch_dev(ctx, 1, ctx->sc_states.as<int>(), ctx->sc_resident_moves.as<ls_sched_move>(),
+                              ctx->sc_nmoves.as<long long>(), n_moves, window, ctx->sc_results.as<ls_sched_result>(), nullptr,
+                              nullptr);
+    if (rc != LS_OK) return rc;
+    LS_HIP(ctx, hipMemcpyAsync(out, ctx->sc_results.p, sizeof(ls_sched_result), hipMemcpyDeviceToHost, ctx->stream));
     LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LS_OK;
 }

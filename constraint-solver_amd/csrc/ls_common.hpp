@@ -62,6 +62,8 @@ struct ls_ctx {
         nq_colscores, nq_totals, nq_next_rows;
     lsamd::DevBuf sc_states, sc_moves, sc_nmoves, sc_results, sc_hard, sc_soft, sc_keys, sc_terms;
     lsamd::SchedInstance sched;
+    lsamd::DevBuf sc_resident_moves; // ls_sched_moves_upload
+    long long sc_resident_n = 0;
 };
 
 namespace lsamd {

@@ -191,6 +191,16 @@ class Context:
                                                 want_scores)
         return out[0], (hard[0] if hard is not None else None), (soft[0] if soft is not None else None)
 
+    def sched_moves_upload(self, moves):
+        mv = _c(moves, np.int32).reshape(-1, 3)
+        self._check(self._l.ls_sched_moves_upload(self._h, _vp(mv), len(mv)))
+
+    def sched_eval_resident(self, state, n_moves, window):
+        st = _c(state, np.int32)
+        res = SchedResult()
+        self._check(self._l.ls_sched_eval_resident(self._h, _vp(st), int(n_moves), int(window), C.byref(res)))
+        return dict(n_scored=res.n_scored, best_index=res.best_index, best_hard=res.best_hard, best_soft=res.best_soft)
+
     def sched_eval_batch_dev(self, n_restarts, states_d, moves_d, n_moves_d, max_moves, window, results_d,
                              hard_out_d=None, soft_out_d=None):
         self._check(self._l.ls_sched_eval_batch_dev(

@@ -78,6 +78,8 @@ SIGNATURES = {
     "ls_sched_instance_upload": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp]),
     "ls_sched_score": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "ls_sched_eval": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "ls_sched_moves_upload": (C.c_int, [_vp, _vp, _i64]),
+    "ls_sched_eval_resident": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "ls_sched_eval_batch": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "ls_sched_eval_batch_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "ls_solver_create_nqueens": (C.c_int, [_vp, C.c_uint64, C.c_char_p, _vp, C.POINTER(_vp)]),

@@ -221,6 +221,13 @@ int ls_sched_eval(ls_ctx *ctx, const int32_t *state, const ls_sched_move *moves,
                   int64_t n_moves, int64_t window, ls_sched_result *out,
                   int64_t *hard_out, int64_t *soft_out);
 
+/* The random proposer's move stream never changes during a run (its iterator owns a CLONE of the
+ * generator, lib.rs:488, and nothing advances the original), so it can stay on the device:
+ * ls_sched_moves_upload replaces the context's resident list; ls_sched_eval_resident evaluates its
+ * first n_moves entries against `state` exactly like ls_sched_eval. */
+int ls_sched_moves_upload(ls_ctx *ctx, const ls_sched_move *moves, int64_t n_moves);
+int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, int64_t window, ls_sched_result *out);
+
 /* Batched over restarts: states[n_restarts][n_days_stored],
  * moves[n_restarts][max_moves] (first n_moves[r] used), results[n_restarts]. */
 int ls_sched_eval_batch(ls_ctx *ctx, int32_t n_restarts, const int32_t *states,

@@ -168,3 +168,18 @@ def test_errors(ctx):
     with pytest.raises(ls_amd.LsError):
         c2.sched_instance_upload(31, 32, 0, 1, np.array([1 << 40], dtype=np.uint64))  # holiday outside range
     c2.close()
+
+
+def test_resident_move_list_matches_host_list(ctx):
+    inst, D, S = _upload(ctx, (2022, 5, 9), (2022, 6, 8), 7)
+    rng = np.random.default_rng(8)
+    state = rng.integers(0, 7, size=S)
+    moves = _random_moves(rng, 900, D, 7, state)
+    ctx.sched_moves_upload(moves)
+    for n_moves, window in ((900, 100), (137, 10 ** 9), (0, 5), (900, 0)):
+        a = ctx.sched_eval_resident(state, n_moves, window)
+        b, _, _ = ctx.sched_eval(state, moves[:n_moves], window) if n_moves else (dict(n_scored=0, best_index=-1, best_hard=0, best_soft=0), None, None)
+        assert a == b
+    import ls_amd
+    with pytest.raises(ls_amd.LsError):
+        ctx.sched_eval_resident(state, 901, 10)

@@ -60,6 +60,16 @@ def main():
         out["sched_example_seed42"] = run_solver(s, 250, 20 if quick else 120)
         s.close()
 
+        # config 5, end to end on one GPU (one restart per GPU): 10 000 employees, window 65 536, holidays U{0..3}
+        rng5 = np.random.default_rng(5)
+        bits5 = np.zeros(10_000, dtype=np.uint64)
+        for e in range(10_000):
+            for d in rng5.choice(31, size=int(rng5.integers(0, 4)), replace=False):
+                bits5[e] |= np.uint64(1) << np.uint64(d)
+        s = ls_amd.Solver.scheduling(ctx, 31, 0, 10_000, "42", dict(SCHED, window_size=65_536), holiday_bits=bits5)
+        out["sched10k_window65536_seed42"] = run_solver(s, 250, 10 if quick else 60)
+        s.close()
+
         # config 5 shape, kernel throughput: 10 000 employees x 31 days, holidays h ~ U{0..3} per employee
         rng = np.random.default_rng(5)
         E, D, S = 10_000, 31, 32
