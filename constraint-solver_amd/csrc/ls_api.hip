@@ -124,6 +124,8 @@ int ls_ctx_destroy(ls_ctx *ctx)
                       &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sched.holiday_bits, &ctx->sched.lane_tab,
                       &ctx->sc_resident_moves};
     for (DevBuf *b : bufs) b->release();
+    ctx->stage_in.release();
+    ctx->stage_out.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return LS_OK;
@@ -284,25 +286,31 @@ int ls_nqueens_eval_batch_next(ls_ctx *ctx, int32_t n_restarts, int32_t n, const
     const size_t rows_b = (size_t)n_restarts * n * 4, cur_b = (size_t)n_restarts * 8,
                  cols_b = (size_t)n_restarts * max_cols * 4, nc_b = (size_t)n_restarts * 4,
                  res_b = (size_t)n_restarts * sizeof(ls_nq_result), cs_b = (size_t)n_restarts * n * 8;
-    LS_RESERVE(ctx, ctx->nq_rows, rows_b);
-    LS_RESERVE(ctx, ctx->nq_cur, cur_b);
-    LS_RESERVE(ctx, ctx->nq_cols, cols_b);
-    LS_RESERVE(ctx, ctx->nq_ncols, nc_b);
-    LS_RESERVE(ctx, ctx->nq_results, res_b);
+    // inputs: cur | rows | cols | n_cols  ->  one pinned block, one copy
+    const size_t o_cur = 0, o_rows = align256(o_cur + cur_b), o_cols = align256(o_rows + rows_b),
+                 o_nc = align256(o_cols + cols_b), in_b = align256(o_nc + nc_b);
+    // outputs: results | next_col_scores  <-  one copy
+    const size_t o_res = 0, o_cs = align256(o_res + res_b), out_b = align256(o_cs + cs_b);
+    {
+        hipError_t e = ctx->stage_in.reserve(in_b);
+        if (e == hipSuccess) e = ctx->stage_out.reserve(out_b);
+        if (e != hipSuccess) return set_err(ctx, LS_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
+    }
     LS_RESERVE(ctx, ctx->nq_next_rows, rows_b);
-    LS_RESERVE(ctx, ctx->nq_colscores, cs_b);
-    LS_HIP(ctx, hipMemcpyAsync(ctx->nq_rows.p, rows, rows_b, hipMemcpyHostToDevice, ctx->stream));
-    LS_HIP(ctx, hipMemcpyAsync(ctx->nq_cur.p, cur_scores, cur_b, hipMemcpyHostToDevice, ctx->stream));
-    if (cols_b) LS_HIP(ctx, hipMemcpyAsync(ctx->nq_cols.p, cols, cols_b, hipMemcpyHostToDevice, ctx->stream));
-    LS_HIP(ctx, hipMemcpyAsync(ctx->nq_ncols.p, n_cols, nc_b, hipMemcpyHostToDevice, ctx->stream));
-    rc = ls_nqueens_eval_batch_next_dev(ctx, n_restarts, n, ctx->nq_rows.as<int>(), ctx->nq_cur.as<int64_t>(),
-                                        ctx->nq_cols.as<int>(), ctx->nq_ncols.as<int>(), max_cols, window,
-                                        ctx->nq_results.as<ls_nq_result>(), ctx->nq_next_rows.as<int>(),
-                                        ctx->nq_colscores.as<int64_t>(), nullptr);
+    Staging &si = ctx->stage_in, &so = ctx->stage_out;
+    memcpy(si.h<char>(o_cur), cur_scores, cur_b);
+    memcpy(si.h<char>(o_rows), rows, rows_b);
+    if (cols_b) memcpy(si.h<char>(o_cols), cols, cols_b);
+    memcpy(si.h<char>(o_nc), n_cols, nc_b);
+    LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = ls_nqueens_eval_batch_next_dev(ctx, n_restarts, n, si.d<int>(o_rows), si.d<int64_t>(o_cur), si.d<int>(o_cols),
+                                        si.d<int>(o_nc), max_cols, window, so.d<ls_nq_result>(o_res),
+                                        ctx->nq_next_rows.as<int>(), so.d<int64_t>(o_cs), nullptr);
     if (rc != LS_OK) return rc;
-    LS_HIP(ctx, hipMemcpyAsync(results, ctx->nq_results.p, res_b, hipMemcpyDeviceToHost, ctx->stream));
-    LS_HIP(ctx, hipMemcpyAsync(next_col_scores, ctx->nq_colscores.p, cs_b, hipMemcpyDeviceToHost, ctx->stream));
+    LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
     LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(results, so.h<char>(o_res), res_b);
+    memcpy(next_col_scores, so.h<char>(o_cs), cs_b);
     return LS_OK;
 }
 
@@ -531,18 +539,22 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
     const int S = ctx->sched.n_days_stored;
     int rc = sched_check_state(ctx, state, S);
     if (rc != LS_OK) return rc;
-    LS_RESERVE(ctx, ctx->sc_states, (size_t)S * 4);
-    LS_RESERVE(ctx, ctx->sc_nmoves, 8);
-    LS_RESERVE(ctx, ctx->sc_results, sizeof(ls_sched_result));
-    LS_HIP(ctx, hipMemcpyAsync(ctx->sc_states.p, state, (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
-    const long long nm = n_moves;
-    LS_HIP(ctx, hipMemcpyAsync(ctx->sc_nmoves.p, &nm, 8, hipMemcpyHostToDevice, ctx->stream));
-    rc = sched_eval_batch_dev(ctx, 1, ctx->sc_states.as<int>(), ctx->sc_resident_moves.as<ls_sched_move>(),
-                              ctx->sc_nmoves.as<long long>(), n_moves, window, ctx->sc_results.as<ls_sched_result>(), nullptr,
-                              nullptr);
+    const size_t o_nm = 0, o_st = 256, in_b = align256(o_st + (size_t)S * 4), out_b = 256;
+    {
+        hipError_t e = ctx->stage_in.reserve(in_b);
+        if (e == hipSuccess) e = ctx->stage_out.reserve(out_b);
+        if (e != hipSuccess) return set_err(ctx, LS_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
+    }
+    Staging &si = ctx->stage_in, &so = ctx->stage_out;
+    *si.h<long long>(o_nm) = n_moves;
+    memcpy(si.h<char>(o_st), state, (size_t)S * 4);
+    LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = sched_eval_batch_dev(ctx, 1, si.d<int>(o_st), ctx->sc_resident_moves.as<ls_sched_move>(), si.d<long long>(o_nm),
+                              n_moves, window, so.d<ls_sched_result>(0), nullptr, nullptr);
     if (rc != LS_OK) return rc;
-    LS_HIP(ctx, hipMemcpyAsync(out, ctx->sc_results.p, sizeof(ls_sched_result), hipMemcpyDeviceToHost, ctx->stream));
+    LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
     LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = *so.h<ls_sched_result>(0);
     return LS_OK;
 }
 

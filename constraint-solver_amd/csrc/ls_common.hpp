@@ -35,6 +35,37 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+// Pinned host staging + one contiguous device block: a host-pointer call packs all its inputs, moves
+// them with ONE host-to-device copy, and gets all its outputs back with ONE device-to-host copy
+// (pageable hipMemcpyAsync calls cost several microseconds each and dominate small launches).
+struct Staging {
+    void *host = nullptr;   // hipHostMalloc
+    void *dev = nullptr;    // hipMalloc
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        release();
+        size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
+        hipError_t e = hipHostMalloc(&host, want, hipHostMallocDefault);
+        if (e != hipSuccess) { host = nullptr; return e; }
+        e = hipMalloc(&dev, want);
+        if (e != hipSuccess) { (void)hipHostFree(host); host = nullptr; dev = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (host) (void)hipHostFree(host);
+        if (dev) (void)hipFree(dev);
+        host = dev = nullptr; cap = 0;
+    }
+    template <class T> T *h(size_t off) const { return reinterpret_cast<T *>(static_cast<char *>(host) + off); }
+    template <class T> T *d(size_t off) const { return reinterpret_cast<T *>(static_cast<char *>(dev) + off); }
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 struct SchedInstance {
     bool valid = false;
     int n_days_scored = 0, n_days_stored = 0, start_weekday = 0, n_employees = 0;
@@ -63,6 +94,7 @@ struct ls_ctx {
     lsamd::DevBuf sc_states, sc_moves, sc_nmoves, sc_results, sc_hard, sc_soft, sc_keys, sc_terms;
     lsamd::SchedInstance sched;
     lsamd::DevBuf sc_resident_moves; // ls_sched_moves_upload
+    lsamd::Staging stage_in, stage_out;
     long long sc_resident_n = 0;
 };
 
