@@ -29,10 +29,9 @@ int set_err(const ls_ctx *ctx, int code, const char *fmt, ...)
 // nq_kernels.hip
 int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, const long long *cur_d,
                       const int *cols_d, const int *n_cols_d, int max_cols, long long window,
-                      ls_nq_result *results_d, long long *scores_out_d);
+                      ls_nq_result *results_d, long long *scores_out_d, int *next_rows_d);
 int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, long long *col_scores_d,
                       long long *scores_d);
-int nq_apply_best_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, const ls_nq_result *results_d, int *next_rows_d);
 // sched_kernels.hip
 int sched_score_dev(ls_ctx *ctx, int n_states, const int *states_d, long long *hard_d, long long *soft_d,
                     long long *terms_d);
@@ -204,7 +203,7 @@ int ls_nqueens_eval_batch_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, const 
                "null device pointer");
     return nq_eval_batch_dev(ctx, n_restarts, n, rows_d, reinterpret_cast<const long long *>(cur_scores_d), cols_d,
                              n_cols_d, max_cols, nq_clamp_window(window, max_cols, n), results_d,
-                             reinterpret_cast<long long *>(scores_out_d));
+                             reinterpret_cast<long long *>(scores_out_d), nullptr);
 }
 
 int ls_nqueens_eval_batch(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows,
@@ -242,7 +241,7 @@ int ls_nqueens_eval_batch(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int3
     rc = nq_eval_batch_dev(ctx, n_restarts, n, ctx->nq_rows.as<int>(), ctx->nq_cur.as<long long>(),
                            ctx->nq_cols.as<int>(), ctx->nq_ncols.as<int>(), max_cols,
                            nq_clamp_window(window, max_cols, n), ctx->nq_results.as<ls_nq_result>(),
-                           sc_b ? ctx->nq_scores.as<long long>() : nullptr);
+                           sc_b ? ctx->nq_scores.as<long long>() : nullptr, nullptr);
     if (rc != LS_OK) return rc;
     LS_HIP(ctx, hipMemcpyAsync(results, ctx->nq_results.p, res_b, hipMemcpyDeviceToHost, ctx->stream));
     if (sc_b) LS_HIP(ctx, hipMemcpyAsync(scores_out, ctx->nq_scores.p, sc_b, hipMemcpyDeviceToHost, ctx->stream));
@@ -255,11 +254,13 @@ int ls_nqueens_eval_batch_next_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, c
                                    int32_t max_cols, int64_t window, ls_nq_result *results_d, int32_t *next_rows_d,
                                    int64_t *next_col_scores_d, int64_t *next_scores_d)
 {
-    int rc = ls_nqueens_eval_batch_dev(ctx, n_restarts, n, rows_d, cur_scores_d, cols_d, n_cols_d, max_cols, window,
-                                       results_d, nullptr);
+    LS_BIND(ctx);
+    int rc = nq_check_dims(ctx, n_restarts, n, max_cols, window);
     if (rc != LS_OK) return rc;
-    LS_REQUIRE(ctx, next_rows_d && next_col_scores_d, "null device pointer");
-    rc = nq_apply_best_dev(ctx, n_restarts, n, rows_d, results_d, next_rows_d);
+    LS_REQUIRE(ctx, rows_d && cur_scores_d && n_cols_d && results_d && (cols_d || max_cols == 0) && next_rows_d &&
+                        next_col_scores_d, "null device pointer");
+    rc = nq_eval_batch_dev(ctx, n_restarts, n, rows_d, reinterpret_cast<const long long *>(cur_scores_d), cols_d, n_cols_d,
+                           max_cols, nq_clamp_window(window, max_cols, n), results_d, nullptr, next_rows_d);
     if (rc != LS_OK) return rc;
     return nq_col_scores_dev(ctx, n_restarts, n, next_rows_d, reinterpret_cast<long long *>(next_col_scores_d),
                              reinterpret_cast<long long *>(next_scores_d));

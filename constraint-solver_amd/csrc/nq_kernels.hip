@@ -632,36 +632,91 @@ __global__ __launch_bounds__(256) void nq_col_scores_kernel(const int *rows_all,
 }
 
 // ================================================================= finalize
-__global__ void nq_finalize_kernel(NqArgs a, ls_nq_result *results)
+// One block per restart: decode the winning key into the result record, put the key back to EMPTY for
+// the next call (so no separate clearing launch is needed), and - when asked - write the winner board
+// (rows with the selected move applied: MoveIterator, lib.rs:226-228) for the fused column-score pass.
+__global__ __launch_bounds__(256) void nq_finalize_kernel(NqArgs a, ls_nq_result *results, int *next_rows)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_restarts) return;
+    __shared__ ls_nq_result s_out;
+    const int r = blockIdx.x;
     const int n = a.n;
-    int ncols = a.n_cols[r];
-    ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
-    const long long total = (long long)ncols * (n - 1);
-    ls_nq_result out;
-    out.n_scored = a.window < total ? (a.window < 0 ? 0 : a.window) : total;
-    const unsigned long long key = a.best_keys[r];
-    if (key == NQ_KEY_EMPTY || out.n_scored == 0) {
-        out.n_scored = key == NQ_KEY_EMPTY ? 0 : out.n_scored;
-        out.best_index = -1;
-        out.best_score = 0;
-        out.best_col = -1;
-        out.best_value = -1;
-    } else {
-        const int slot = (int)(key & 0x7fffu);
-        const int v = (int)((key >> 15) & 0x7fffu);
-        const int colkey = (int)((key >> 30) & 0x7fffu);
-        const int is_up = (int)((key >> 45) & 1u);
-        const int c = is_up ? n - 1 - colkey : colkey;
-        const int delta = (int)(key >> 46) - NQ_DELTA_BIAS;
-        out.best_index = (long long)slot * n + v;
-        out.best_score = a.cur_scores[r] + 2ll * delta;
-        out.best_col = c;
-        out.best_value = v;
+    if (threadIdx.x == 0) {
+        int ncols = a.n_cols[r];
+        ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
+        const long long total = (long long)ncols * (n - 1);
+        ls_nq_result out;
+        out.n_scored = a.window < total ? (a.window < 0 ? 0 : a.window) : total;
+        const unsigned long long key = a.best_keys[r];
+        a.best_keys[r] = NQ_KEY_EMPTY;
+        if (key == NQ_KEY_EMPTY || out.n_scored == 0) {
+            out.n_scored = key == NQ_KEY_EMPTY ? 0 : out.n_scored;
+            out.best_index = -1;
+            out.best_score = 0;
+            out.best_col = -1;
+            out.best_value = -1;
+        } else {
+            const int slot = (int)(key & 0x7fffu);
+            const int v = (int)((key >> 15) & 0x7fffu);
+            const int colkey = (int)((key >> 30) & 0x7fffu);
+            const int is_up = (int)((key >> 45) & 1u);
+            const int c = is_up ? n - 1 - colkey : colkey;
+            const int delta = (int)(key >> 46) - NQ_DELTA_BIAS;
+            out.best_index = (long long)slot * n + v;
+            out.best_score = a.cur_scores[r] + 2ll * delta;
+            out.best_col = c;
+            out.best_value = v;
+        }
+        results[r] = out;
+        s_out = out;
     }
-    results[r] = out;
+    if (next_rows == nullptr) return;
+    __syncthreads();
+    const ls_nq_result res = s_out;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        int v = a.rows[(long long)r * n + j];
+        if (res.best_index >= 0 && j == res.best_col) v = res.best_value;
+        next_rows[(long long)r * n + j] = v;
+    }
+}
+
+// get_col_scores + sum of one board per block with the occupancy tables in LDS (n <= NQ_CS_LDS_MAX_N):
+// one launch instead of clear + build + clear + score.
+constexpr int NQ_CS_LDS_MAX_N = 6400; // 5n ints <= 125 KB
+__global__ __launch_bounds__(1024) void nq_col_scores_lds_kernel(const int *rows_all, int n, long long *col_scores,
+                                                                 long long *totals)
+{
+    extern __shared__ int s_tab[]; // cntR[n] | cntA[2n] | cntB[2n]
+    __shared__ long long s_sum[16];
+    const int r = blockIdx.x;
+    const int *rows = rows_all + (long long)r * n;
+    int *tR = s_tab, *tA = s_tab + n, *tB = s_tab + 3 * n;
+    for (int i = threadIdx.x; i < 5 * n; i += 1024) s_tab[i] = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += 1024) {
+        const int q = rows[j];
+        if ((unsigned)q < (unsigned)n) {
+            atomicAdd(&tR[q], 1);
+            atomicAdd(&tA[q - j + n], 1);
+            atomicAdd(&tB[q + j], 1);
+        }
+    }
+    __syncthreads();
+    long long local = 0;
+    for (int j = threadIdx.x; j < n; j += 1024) {
+        const int q = rows[j];
+        long long sc = 0;
+        if ((unsigned)q < (unsigned)n) sc = (long long)tR[q] + tA[q - j + n] + tB[q + j] - 3;
+        if (col_scores) col_scores[(long long)r * n + j] = sc;
+        local += sc;
+    }
+    const int lo = wave_sum_i32((int)local);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = lo;
+    __syncthreads();
+    if (threadIdx.x == 0 && totals) {
+        long long t = 0;
+        for (int i = 0; i < 16; i++) t += s_sum[i];
+        totals[r] = t;
+    }
 }
 
 // ================================================================ launchers
@@ -777,12 +832,20 @@ static int build_tables(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, i
 
 int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, const long long *cur_d,
                       const int *cols_d, const int *n_cols_d, int max_cols, long long window,
-                      ls_nq_result *results_d, long long *scores_out_d)
+                      ls_nq_result *results_d, long long *scores_out_d, int *next_rows_d)
 {
-    LS_RESERVE(ctx, ctx->nq_keys, (size_t)n_restarts * 8);
-    hipLaunchKernelGGL(fill_i64_kernel, dim3((n_restarts + 255) / 256), dim3(256), 0, ctx->stream,
-                       ctx->nq_keys.as<long long>(), -1ll, (long long)n_restarts); // NQ_KEY_EMPTY
-    LS_HIP(ctx, hipGetLastError());
+    {   // the finalize kernel leaves every key it read EMPTY again: clear only what it has not seen yet
+        const void *before = ctx->nq_keys.p;
+        LS_RESERVE(ctx, ctx->nq_keys, (size_t)n_restarts * 8);
+        if (ctx->nq_keys.p != before) ctx->nq_keys_ready = 0;
+        const long long ready = ctx->nq_keys_ready;
+        ctx->nq_keys_ready = 0; // until this call's finalize is queued
+        if (ready < n_restarts) {
+            hipLaunchKernelGGL(fill_i64_kernel, dim3((n_restarts + 255) / 256), dim3(256), 0, ctx->stream,
+                               ctx->nq_keys.as<long long>(), -1ll, (long long)n_restarts); // NQ_KEY_EMPTY
+            LS_HIP(ctx, hipGetLastError());
+        }
+    }
     NqArgs a;
     a.rows = rows_d; a.cur_scores = cur_d; a.cols = cols_d; a.n_cols = n_cols_d;
     a.n = n; a.n_restarts = n_restarts; a.max_cols = max_cols; a.window = window;
@@ -822,38 +885,28 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
             if (rc != LS_OK) return rc;
         }
     }
-    hipLaunchKernelGGL(nq_finalize_kernel, dim3((n_restarts + 63) / 64), dim3(64), 0, ctx->stream, a,
-                       results_d);
+    hipLaunchKernelGGL(nq_finalize_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a, results_d, next_rows_d);
     LS_HIP(ctx, hipGetLastError());
-    return LS_OK;
-}
-
-// winner board of each restart: rows with the selected move applied (MoveIterator, lib.rs:226-228)
-__global__ __launch_bounds__(256) void nq_apply_best_kernel(const int *rows, int n, const ls_nq_result *results, int *next_rows)
-{
-    const int r = blockIdx.y;
-    const ls_nq_result res = results[r];
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
-        int v = rows[(long long)r * n + j];
-        if (res.best_index >= 0 && j == res.best_col) v = res.best_value;
-        next_rows[(long long)r * n + j] = v;
-    }
-}
-
-int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, long long *col_scores_d, long long *scores_d);
-
-int nq_apply_best_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, const ls_nq_result *results_d, int *next_rows_d)
-{
-    int gx = (n + 255) / 256;
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(nq_apply_best_kernel, dim3(gx, n_restarts), dim3(256), 0, ctx->stream, rows_d, n, results_d, next_rows_d);
-    LS_HIP(ctx, hipGetLastError());
+    ctx->nq_keys_ready = n_restarts;
     return LS_OK;
 }
 
 int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, long long *col_scores_d,
                       long long *scores_d)
 {
+    if (n <= NQ_CS_LDS_MAX_N) {
+        const size_t lds = (size_t)5 * n * sizeof(int);
+        static bool attr_done_dev[64] = {false};
+        if (!attr_done_dev[ctx->device & 63]) {
+            LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_col_scores_lds_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 5 * NQ_CS_LDS_MAX_N * (int)sizeof(int)));
+            attr_done_dev[ctx->device & 63] = true;
+        }
+        hipLaunchKernelGGL(nq_col_scores_lds_kernel, dim3(n_restarts), dim3(1024), lds, ctx->stream, rows_d, n, col_scores_d,
+                           scores_d);
+        LS_HIP(ctx, hipGetLastError());
+        return LS_OK;
+    }
     int *tabs = nullptr; int stride = 0;
     int rc = build_tables(ctx, n_restarts, n, rows_d, &tabs, &stride);
     if (rc != LS_OK) return rc;
