@@ -206,9 +206,12 @@ int ls_nqueens_eval_batch_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, const 
                              reinterpret_cast<long long *>(scores_out_d), nullptr);
 }
 
-int ls_nqueens_eval_batch(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows,
-                          const int64_t *cur_scores, const int32_t *cols, const int32_t *n_cols, int32_t max_cols,
-                          int64_t window, ls_nq_result *results, int64_t *scores_out)
+// Shared host-pointer path: validate, pack the inputs into the pinned staging block (one H2D copy), run the
+// neighbourhood (+ optionally the winner's column scores), fetch results (+ column scores) with one D2H copy.
+// Only the parity-mode per-candidate score array (up to GBs) is copied separately.
+static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows, const int64_t *cur_scores,
+                        const int32_t *cols, const int32_t *n_cols, int32_t max_cols, int64_t window,
+                        ls_nq_result *results, int64_t *scores_out, int64_t *next_col_scores)
 {
     LS_BIND(ctx);
     int rc = nq_check_dims(ctx, n_restarts, n, max_cols, window);
@@ -226,27 +229,46 @@ int ls_nqueens_eval_batch(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int3
     }
     const size_t rows_b = (size_t)n_restarts * n * 4, cur_b = (size_t)n_restarts * 8,
                  cols_b = (size_t)n_restarts * max_cols * 4, nc_b = (size_t)n_restarts * 4,
-                 res_b = (size_t)n_restarts * sizeof(ls_nq_result),
+                 res_b = (size_t)n_restarts * sizeof(ls_nq_result), cs_b = next_col_scores ? (size_t)n_restarts * n * 8 : 0,
                  sc_b = scores_out ? (size_t)n_restarts * max_cols * n * 8 : 0;
-    LS_RESERVE(ctx, ctx->nq_rows, rows_b);
-    LS_RESERVE(ctx, ctx->nq_cur, cur_b);
-    LS_RESERVE(ctx, ctx->nq_cols, cols_b);
-    LS_RESERVE(ctx, ctx->nq_ncols, nc_b);
-    LS_RESERVE(ctx, ctx->nq_results, res_b);
+    // inputs: cur | rows | cols | n_cols ;  outputs: results | next_col_scores
+    const size_t o_cur = 0, o_rows = align256(o_cur + cur_b), o_cols = align256(o_rows + rows_b),
+                 o_nc = align256(o_cols + cols_b), in_b = align256(o_nc + nc_b);
+    const size_t o_res = 0, o_cs = align256(o_res + res_b), out_b = align256(o_cs + cs_b);
+    {
+        hipError_t e = ctx->stage_in.reserve(in_b);
+        if (e == hipSuccess) e = ctx->stage_out.reserve(out_b);
+        if (e != hipSuccess) return set_err(ctx, LS_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
+    }
+    if (cs_b) LS_RESERVE(ctx, ctx->nq_next_rows, rows_b);
     if (sc_b) LS_RESERVE(ctx, ctx->nq_scores, sc_b);
-    LS_HIP(ctx, hipMemcpyAsync(ctx->nq_rows.p, rows, rows_b, hipMemcpyHostToDevice, ctx->stream));
-    LS_HIP(ctx, hipMemcpyAsync(ctx->nq_cur.p, cur_scores, cur_b, hipMemcpyHostToDevice, ctx->stream));
-    if (cols_b) LS_HIP(ctx, hipMemcpyAsync(ctx->nq_cols.p, cols, cols_b, hipMemcpyHostToDevice, ctx->stream));
-    LS_HIP(ctx, hipMemcpyAsync(ctx->nq_ncols.p, n_cols, nc_b, hipMemcpyHostToDevice, ctx->stream));
-    rc = nq_eval_batch_dev(ctx, n_restarts, n, ctx->nq_rows.as<int>(), ctx->nq_cur.as<long long>(),
-                           ctx->nq_cols.as<int>(), ctx->nq_ncols.as<int>(), max_cols,
-                           nq_clamp_window(window, max_cols, n), ctx->nq_results.as<ls_nq_result>(),
-                           sc_b ? ctx->nq_scores.as<long long>() : nullptr, nullptr);
+    Staging &si = ctx->stage_in, &so = ctx->stage_out;
+    memcpy(si.h<char>(o_cur), cur_scores, cur_b);
+    memcpy(si.h<char>(o_rows), rows, rows_b);
+    if (cols_b) memcpy(si.h<char>(o_cols), cols, cols_b);
+    memcpy(si.h<char>(o_nc), n_cols, nc_b);
+    LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = nq_eval_batch_dev(ctx, n_restarts, n, si.d<int>(o_rows), si.d<long long>(o_cur), si.d<int>(o_cols), si.d<int>(o_nc),
+                           max_cols, nq_clamp_window(window, max_cols, n), so.d<ls_nq_result>(o_res),
+                           sc_b ? ctx->nq_scores.as<long long>() : nullptr, cs_b ? ctx->nq_next_rows.as<int>() : nullptr);
     if (rc != LS_OK) return rc;
-    LS_HIP(ctx, hipMemcpyAsync(results, ctx->nq_results.p, res_b, hipMemcpyDeviceToHost, ctx->stream));
+    if (cs_b) {
+        rc = nq_col_scores_dev(ctx, n_restarts, n, ctx->nq_next_rows.as<int>(), so.d<long long>(o_cs), nullptr);
+        if (rc != LS_OK) return rc;
+    }
+    LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
     if (sc_b) LS_HIP(ctx, hipMemcpyAsync(scores_out, ctx->nq_scores.p, sc_b, hipMemcpyDeviceToHost, ctx->stream));
     LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(results, so.h<char>(o_res), res_b);
+    if (cs_b) memcpy(next_col_scores, so.h<char>(o_cs), cs_b);
     return LS_OK;
+}
+
+int ls_nqueens_eval_batch(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows,
+                          const int64_t *cur_scores, const int32_t *cols, const int32_t *n_cols, int32_t max_cols,
+                          int64_t window, ls_nq_result *results, int64_t *scores_out)
+{
+    return nq_host_call(ctx, n_restarts, n, rows, cur_scores, cols, n_cols, max_cols, window, results, scores_out, nullptr);
 }
 
 int ls_nqueens_eval_batch_next_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows_d,
@@ -270,49 +292,9 @@ int ls_nqueens_eval_batch_next(ls_ctx *ctx, int32_t n_restarts, int32_t n, const
                                const int64_t *cur_scores, const int32_t *cols, const int32_t *n_cols, int32_t max_cols,
                                int64_t window, ls_nq_result *results, int64_t *next_col_scores)
 {
-    LS_BIND(ctx);
-    int rc = nq_check_dims(ctx, n_restarts, n, max_cols, window);
-    if (rc != LS_OK) return rc;
-    LS_REQUIRE(ctx, rows && cur_scores && n_cols && results && next_col_scores && (cols || max_cols == 0), "null pointer");
-    for (long long i = 0; i < (long long)n_restarts * n; i++)
-        LS_REQUIRE(ctx, rows[i] >= 0 && rows[i] < n, "rows[%lld] = %d outside [0, %d)", i, rows[i], n);
-    for (int r = 0; r < n_restarts; r++) {
-        LS_REQUIRE(ctx, n_cols[r] >= 0 && n_cols[r] <= max_cols, "n_cols[%d] = %d outside [0, max_cols = %d]", r,
-                   n_cols[r], max_cols);
-        for (int s = 0; s < n_cols[r]; s++) {
-            const int c = cols[(long long)r * max_cols + s];
-            LS_REQUIRE(ctx, c >= 0 && c < n, "cols[%d][%d] = %d outside [0, %d)", r, s, c, n);
-        }
-    }
-    const size_t rows_b = (size_t)n_restarts * n * 4, cur_b = (size_t)n_restarts * 8,
-                 cols_b = (size_t)n_restarts * max_cols * 4, nc_b = (size_t)n_restarts * 4,
-                 res_b = (size_t)n_restarts * sizeof(ls_nq_result), cs_b = (size_t)n_restarts * n * 8;
-    // inputs: cur | rows | cols | n_cols  ->  one pinned block, one copy
-    const size_t o_cur = 0, o_rows = align256(o_cur + cur_b), o_cols = align256(o_rows + rows_b),
-                 o_nc = align256(o_cols + cols_b), in_b = align256(o_nc + nc_b);
-    // outputs: results | next_col_scores  <-  one copy
-    const size_t o_res = 0, o_cs = align256(o_res + res_b), out_b = align256(o_cs + cs_b);
-    {
-        hipError_t e = ctx->stage_in.reserve(in_b);
-        if (e == hipSuccess) e = ctx->stage_out.reserve(out_b);
-        if (e != hipSuccess) return set_err(ctx, LS_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
-    }
-    LS_RESERVE(ctx, ctx->nq_next_rows, rows_b);
-    Staging &si = ctx->stage_in, &so = ctx->stage_out;
-    memcpy(si.h<char>(o_cur), cur_scores, cur_b);
-    memcpy(si.h<char>(o_rows), rows, rows_b);
-    if (cols_b) memcpy(si.h<char>(o_cols), cols, cols_b);
-    memcpy(si.h<char>(o_nc), n_cols, nc_b);
-    LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
-    rc = ls_nqueens_eval_batch_next_dev(ctx, n_restarts, n, si.d<int>(o_rows), si.d<int64_t>(o_cur), si.d<int>(o_cols),
-                                        si.d<int>(o_nc), max_cols, window, so.d<ls_nq_result>(o_res),
-                                        ctx->nq_next_rows.as<int>(), so.d<int64_t>(o_cs), nullptr);
-    if (rc != LS_OK) return rc;
-    LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
-    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(results, so.h<char>(o_res), res_b);
-    memcpy(next_col_scores, so.h<char>(o_cs), cs_b);
-    return LS_OK;
+    if (ctx && !next_col_scores) return set_err(ctx, LS_ERR_INVALID, "next_col_scores is NULL");
+    return nq_host_call(ctx, n_restarts, n, rows, cur_scores, cols, n_cols, max_cols, window, results, nullptr,
+                        next_col_scores);
 }
 
 int ls_nqueens_eval(ls_ctx *ctx, int32_t n, const int32_t *rows, int64_t cur_score, const int32_t *cols,

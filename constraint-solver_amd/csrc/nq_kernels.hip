@@ -570,8 +570,8 @@ __global__ __launch_bounds__(256) void nq_table_eval_kernel(NqArgs a)
             const long long left = k1 - k;
             const int ve = (left < (long long)(n - v0)) ? (int)(v0 + left) : n;
             const int c = cols[slot];
-            if ((unsigned)c < (unsigned)n) {
-                const int rc = rows[c];
+            const int rc = (unsigned)c < (unsigned)n ? rows[c] : -1;
+            if ((unsigned)rc < (unsigned)n) { // device-pointer callers are not validated: never index a table out of range
                 const long long base = (long long)slot * (n - 1);
                 const NqRanges rg = nq_ranges(v0, ve, rc, base, a.window);
                 const int conf_old = tR[rc] + tA[rc - c + n] + tB[rc + c] - 3;
