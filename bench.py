@@ -62,6 +62,20 @@ def cpu_baseline(n: int, board: np.ndarray, target_seconds: float):
     return out, ns, best
 
 
+def host_core_share() -> int:
+    """Cores this process may really use: the cgroup CPU quota when there is one, else the affinity mask,
+    never more than 16 (the per-GPU CPU share of the benchmark boxes)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cores, 16))
+
+
 def cpu_other_lines(n, board, single_rate):
     """(2) one independent restart per host core, same per-candidate work as the
     reference; (5) the oracle's O(n) delta and O(1) count-table scorers on one core — NOT the reference
@@ -71,7 +85,7 @@ def cpu_other_lines(n, board, single_rate):
 
     import oracle as orc
     lines = {}
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_core_share()
     sample = max(64, int(single_rate * 4.0))            # about 4 s per core
     cols = np.arange(n)
 
