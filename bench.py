@@ -327,6 +327,20 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np):
                                                      ncols_ref.data_ptr(), mc, w, res_d.data_ptr()), 200)
         out[f"{algo}_reference_shaped_window_5n"] = {"neighbours_per_s": R * min(w, mc * (n - 1)) / s,
                                                      "us_per_launch": s * 1e6, "candidates_per_launch": R * min(w, mc * (n - 1))}
+    # the same full-neighbourhood workload through the HOST-pointer entry (inputs cross PCIe every call,
+    # one pinned H2D + one D2H, stream sync): never `value`, recorded for DESIGN.md section 6
+    ctx.set_algo("scan")
+    cols_np = np.tile(np.arange(n, dtype=np.int32), (R, 1))
+    ncols_np = np.full(R, n, dtype=np.int32)
+    ctx.nqueens_eval_batch(boards, cur_np, cols_np, ncols_np, n * (n - 1))
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        ctx.nqueens_eval_batch(boards, cur_np, cols_np, ncols_np, n * (n - 1))
+    s = (time.perf_counter() - t0) / reps
+    out["scan_full_neighbourhood_host_pointer_api_pcie_inclusive"] = {
+        "neighbours_per_s": R * n * (n - 1) / s, "ms_per_call": s * 1e3,
+        "host_bytes_per_call": int(boards.nbytes + cur_np.nbytes + cols_np.nbytes + ncols_np.nbytes + 32 * R)}
     out.update(sched_measurements(ctx, torch, dev, timed))
     return out
 
