@@ -156,26 +156,6 @@ __device__ __forceinline__ int wave_sum_i32(int x)
     return __builtin_amdgcn_readlane(x, 63);
 }
 
-__device__ __forceinline__ int wave_max_i32(int x)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        int o = __shfl_xor(x, m, 64);
-        x = o > x ? o : x;
-    }
-    return x;
-}
-
-__device__ __forceinline__ int wave_min_i32(int x)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        int o = __shfl_xor(x, m, 64);
-        x = o < x ? o : x;
-    }
-    return x;
-}
-
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x)
 {
 #pragma unroll

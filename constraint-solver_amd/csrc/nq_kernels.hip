@@ -9,24 +9,25 @@
 // O(n^2) restatement in the oracle tests):
 //   score(board with rows[c] = v) = score(board) - 2*conf(c, rows[c]) + 2*conf(c, v)
 //   conf(c, r) = #{ j != c : rows[j] == r  or  |rows[j] - r| == |j - c| }
-// and the pair test splits into three mutually exclusive equalities
+// The pair test splits into three mutually exclusive equalities
 //   rows[j] == r,   rows[j] - j == r - c,   rows[j] + j == r + c
-// so with R[j] = rows[j], A[j] = rows[j] - j, B[j] = rows[j] + j (independent of
-// the candidate) a candidate (c, v) is three equality scans of the same state.
+// (used by the packed-u16 board and the count tables) or, with d = |rows[j] - r| and
+// e = |j - c|, into the single product test  d * (d - e) == 0  (used by the fp32 boards).
 //
 // Winner selection: minimum by (score, board vector) (local_search.rs:29-37).
 // All candidates of one launch are single-position edits of one board, so the
 // vector order has a closed form: edits that lower rows[c] ("down") sort before
 // all others by (c asc, v asc); edits that raise it ("up") sort after, by
 // (c desc, v asc).  A 64-bit key (delta | up | colkey | v) makes the argmin an
-// integer min.  delta = conf(c,v) - conf(c,rows[c]) orders like the score.
+// integer min (slot = position of the column in the proposer's list, last, so that the earlier of two
+// identical candidates wins).  delta = conf(c,v) - conf(c,rows[c]) orders like the score.
 //
 // Kernel families
-//   SCAN  (default, north-star shape): one wavefront per candidate; the packed
-//         state lives in the wavefront's registers (n <= 4096) or in LDS
-//         (n <= 32768); per-lane match counts are reduced with DPP adds or a wave-private LDS transpose; each
-//         wavefront keeps a running key minimum, blocks combine through LDS and
-//         publish with one 64-bit atomicMin.
+//   SCAN  (default, north-star shape): one wavefront per candidate; the packed state lives in
+//         the wavefront's registers (n <= 4096) or in LDS (n <= 32768) and is scanned in full
+//         for every candidate; per-lane counts are combined through a wave-private LDS tile
+//         (register path: lane q then owns candidate q) or DPP adds (LDS path); wavefronts
+//         keep running key minima, blocks combine through LDS, one 64-bit atomicMin per block.
 //   TABLE occupancy histograms (rows / two diagonals) built once per board;
 //         a candidate is three table reads.  One lane per candidate.
 #include "ls_common.hpp"
