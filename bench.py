@@ -274,6 +274,12 @@ def main():
                                 "neighbours_per_s_at_bound": 4 * info["n_cus"] / (4 * n / 64 * 0.92e-9),
                                 "frac_of_issue_bound": (value / world) / (4 * info["n_cus"] / (4 * n / 64 * 0.92e-9))},
             },
+            # SURVEY 8(d) secondary metric.  Each neighbour tests its new placement against the n - 1 other
+            # columns; the old placement's n - 1 tests are done once per column and shared by its n - 1
+            # neighbours, so the kernel performs (n - 1) + 1 pair checks per neighbour (the survey's 2(n - 1)
+            # figure counts the shared half once per neighbour).
+            "secondary": {"pair_constraint_checks_per_s": value * n,
+                          "pair_constraint_checks_per_s_survey_convention_2x": value * 2 * (n - 1)},
             "global_best": {"score": best[0][0], "restart": best[2]},
         }
         if not args.no_cpu_baseline and world == 1:
