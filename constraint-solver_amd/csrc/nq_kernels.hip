@@ -604,6 +604,91 @@ __global__ __launch_bounds__(256) void nq_table_eval_kernel(NqArgs a)
     }
 }
 
+// TABLE with the histograms in LDS (n <= NQ_TABLE_LDS_MAX_N): every block builds its restart's three
+// tables itself (3n LDS atomics on packed u16 counters - counts are <= n < 65536), then evaluates its
+// share of the candidates from LDS.  One launch instead of clear + build + eval, and the 10n bytes of
+// tables never leave the CU.
+constexpr int NQ_TABLE_LDS_MAX_N = 12288; // 5n u16 = 120 KB
+
+__device__ __forceinline__ void tab16_inc(unsigned *t, int idx) { atomicAdd(&t[idx >> 1], 1u << (16 * (idx & 1))); }
+__device__ __forceinline__ int tab16_get(const unsigned *t, int idx)
+{
+    return (int)reinterpret_cast<const unsigned short *>(t)[idx];
+}
+
+__global__ __launch_bounds__(256) void nq_table_lds_kernel(NqArgs a)
+{
+    extern __shared__ unsigned s_t16[]; // packed u16: cntR[0..n) | cntA[0..2n) | cntB[0..2n)
+    __shared__ unsigned long long s_best[4];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int restart = blockIdx.x % a.n_restarts;
+    const int chunk = blockIdx.x / a.n_restarts;
+    const int n_chunks = gridDim.x / a.n_restarts;
+    const int n = a.n;
+    const int *__restrict__ rows = a.rows + (long long)restart * n;
+    const int *__restrict__ cols = a.cols + (long long)restart * a.max_cols;
+    int ncols = a.n_cols[restart];
+    ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
+    const long long K = nq_k_limit((long long)ncols * n, n, a.window);
+    const long long k0 = K * chunk / n_chunks;
+    const long long k1 = K * (chunk + 1) / n_chunks;
+    unsigned long long best = NQ_KEY_EMPTY;
+    if (k0 < k1) { // block-uniform
+        const int words = (5 * n + 1) >> 1;
+        for (int i = threadIdx.x; i < words; i += 256) s_t16[i] = 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += 256) {
+            const int q = rows[j];
+            if ((unsigned)q < (unsigned)n) {
+                tab16_inc(s_t16, q);
+                tab16_inc(s_t16, n + (q - j + n));
+                tab16_inc(s_t16, 3 * n + (q + j));
+            }
+        }
+        __syncthreads();
+        const int oA = n, oB = 3 * n;
+        const long long cur = a.cur_scores[restart];
+        int slot = (int)(k0 / n);
+        int v0 = (int)(k0 - (long long)slot * n);
+        long long k = k0;
+        while (k < k1) {
+            const long long left = k1 - k;
+            const int ve = (left < (long long)(n - v0)) ? (int)(v0 + left) : n;
+            const int c = cols[slot];
+            const int rc = (unsigned)c < (unsigned)n ? rows[c] : -1;
+            if ((unsigned)rc < (unsigned)n) {
+                const long long base = (long long)slot * (n - 1);
+                const NqRanges rg = nq_ranges(v0, ve, rc, base, a.window);
+                const int conf_old = tab16_get(s_t16, rc) + tab16_get(s_t16, oA + rc - c + n) + tab16_get(s_t16, oB + rc + c) - 3;
+                long long *srow =
+                    a.scores_out ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
+                const unsigned long long khd = nq_key_hi(0, c, n, slot), khu = nq_key_hi(1, c, n, slot);
+                for (int v = rg.d0 + (int)threadIdx.x; v < rg.d1; v += 256) {
+                    const int delta = tab16_get(s_t16, v) + tab16_get(s_t16, oA + v - c + n) + tab16_get(s_t16, oB + v + c) - conf_old;
+                    best = u64min(best, nq_key(delta, khd, v));
+                    if (srow) srow[v] = cur + 2ll * delta;
+                }
+                for (int v = rg.u0 + (int)threadIdx.x; v < rg.u1; v += 256) {
+                    const int delta = tab16_get(s_t16, v) + tab16_get(s_t16, oA + v - c + n) + tab16_get(s_t16, oB + v + c) - conf_old;
+                    best = u64min(best, nq_key(delta, khu, v));
+                    if (srow) srow[v] = cur + 2ll * delta;
+                }
+            }
+            k += ve - v0;
+            slot++;
+            v0 = 0;
+        }
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) s_best[wib] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = u64min(u64min(s_best[0], s_best[1]), u64min(s_best[2], s_best[3]));
+        if (b != NQ_KEY_EMPTY) atomicMin(&a.best_keys[restart], b);
+    }
+}
+
 // get_col_scores + sum by tables (examples/nqueens/src/lib.rs:74-87,130-139).
 __global__ __launch_bounds__(256) void nq_col_scores_kernel(const int *rows_all, int n, const int *tabs,
                                                             int tab_stride, long long *col_scores,
@@ -867,7 +952,25 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
         }
     }
     if (max_cols > 0) {
-        if (ctx->nq_algo == LS_NQ_ALGO_TABLE) {
+        if (ctx->nq_algo == LS_NQ_ALGO_TABLE && n <= NQ_TABLE_LDS_MAX_N) {
+            const size_t lds = (size_t)((5 * n + 1) / 2) * 4 + 16;
+            static bool attr_done_dev[64] = {false};
+            if (!attr_done_dev[ctx->device & 63]) {
+                LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_table_lds_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (5 * NQ_TABLE_LDS_MAX_N + 1) / 2 * 4 + 16));
+                attr_done_dev[ctx->device & 63] = true;
+            }
+            long long per_cu = (160 * 1024) / (long long)(lds + 64);
+            per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+            long long want_blocks = (k_max + 4095) / 4096; // >= 16 candidates per lane: amortises the table build
+            long long bpr = ((long long)ctx->n_cus * per_cu) / n_restarts;
+            if (bpr < 1) bpr = 1;
+            if (bpr > want_blocks) bpr = want_blocks;
+            if (bpr < 1) bpr = 1;
+            hipLaunchKernelGGL(nq_table_lds_kernel, dim3((unsigned)(bpr * n_restarts)), dim3(256), lds, ctx->stream, a);
+            LS_HIP(ctx, hipGetLastError());
+        } else if (ctx->nq_algo == LS_NQ_ALGO_TABLE) {
             int *tabs = nullptr; int stride = 0;
             int rc = build_tables(ctx, n_restarts, n, rows_d, &tabs, &stride);
             if (rc != LS_OK) return rc;
