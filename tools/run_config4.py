@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--rounds", type=int, default=10_000)
     ap.add_argument("--algo", default="scan")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on real multi-GPU nodes; gloo to rehearse ranks on one GPU")
+    ap.add_argument("--all-on-device", type=int, default=None, help="rehearsal only: every rank uses this device")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -32,9 +34,15 @@ def main():
     from ls_amd import sharding
 
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    if args.all_on_device is not None:
+        local_rank = args.all_on_device
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
     ids = sharding.shard_restarts(args.restarts_per_gpu * world, world, rank)
     seeds = [str(42 + r) for r in ids]
     params = dict(local_search_max_iterations=10_000, window_size=5 * args.n, best_solutions_capacity=32,
@@ -51,8 +59,8 @@ def main():
         recs = [sharding.record(rid, m.best(i)[0], m.best(i)[1]) for i, rid in enumerate(ids) if m.best(i) is not None]
         m.close()
     best, allr = sharding.gather_best(recs)
-    tot = torch.tensor([st["neighbours_scored"], st["ls_iterations"], st["gpu_launches"]], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([st["neighbours_scored"], st["ls_iterations"], st["gpu_launches"]], dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tot)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
