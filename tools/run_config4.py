@@ -4,7 +4,7 @@
 restart r on rank r mod N, host-side gather of the per-restart bests and a global minimum in
 ScoredSolution order.  One process per GPU:
 
-    python tools/run_config4.py [--n 4096] [--restarts-per-gpu 8] [--seconds 60]
+    python tools/run_config4.py [--board-size 4096] [--restarts-per-gpu 8] [--seconds 60]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/run_config4.py ...
 """
 import argparse
@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "constraint-solver_amd"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--board-size", "--n", dest="n", type=int, default=4096)
     ap.add_argument("--restarts-per-gpu", type=int, default=8)
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--rounds", type=int, default=10_000)
