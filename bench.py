@@ -121,7 +121,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--board-size", "--n", dest="n", type=int, default=4096,
+                    help="(under torch.distributed.run use --board-size: its parser treats --n as ambiguous)")
     ap.add_argument("--restarts-per-gpu", type=int, default=8)
     ap.add_argument("--algo", choices=["scan", "table"], default="scan")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline leg")
