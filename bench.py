@@ -116,6 +116,25 @@ def cpu_other_lines(n, board, single_rate):
     return lines
 
 
+def ensure_built():
+    """The shared library is a git-ignored build artefact: build it (hipcc, gfx950) when a clean checkout
+    has none.  Only local rank 0 builds; the other ranks wait for the file."""
+    so = os.path.join(ROOT, "constraint-solver_amd", "lib", "libls_amd.so")
+    if os.path.exists(so):
+        return
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ls_amd_build", os.path.join(ROOT, "constraint-solver_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build(verbose=False)
+    else:
+        t0 = time.time()
+        while not os.path.exists(so) and time.time() - t0 < 600:
+            time.sleep(1.0)
+        time.sleep(2.0)  # let the linker finish writing
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +155,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    ensure_built()
     import ls_amd
     from ls_amd import sharding
 
