@@ -53,10 +53,12 @@ def build(force: bool = False, keep_temps: bool = False, verbose: bool = True) -
     for p, cmd in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", SO] + objs
+    tmp = SO + ".tmp"
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link, cwd=LIBDIR)
+    os.replace(tmp, SO)  # atomic: concurrent ranks never see a half-written library
     return SO
 
 
