@@ -962,7 +962,7 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
                 attr_done_dev[ctx->device & 63] = true;
             }
             long long per_cu = (160 * 1024) / (long long)(lds + 64);
-            per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+            per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu); // LDS-latency bound: residency beats wave-count parity here (measured)
             long long want_blocks = (k_max + 4095) / 4096; // >= 16 candidates per lane: amortises the table build
             long long bpr = ((long long)ctx->n_cus * per_cu) / n_restarts;
             if (bpr < 1) bpr = 1;
