@@ -314,22 +314,21 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, co
     if (amount == 0) return {};
     if (amount > length) throw std::runtime_error("`amount` of samples must be less than or equal to `length`");
     struct El { double key; uint32_t index; };
-    std::vector<El> heap;
-    heap.reserve(length);
-    auto less = [](const El &a, const El &b) { return a.key < b.key; }; // max-heap on key
+    std::vector<El> keyed;
+    keyed.reserve(length);
     for (uint32_t i = 0; i < length; i++) {
         if (!(weights[i] >= 0.0)) throw std::runtime_error("invalid weight");
-        const double key = std::pow(rng.gen_f64(), 1.0 / weights[i]);
-        heap.push_back(El{key, i});
-        std::push_heap(heap.begin(), heap.end(), less);
+        keyed.push_back(El{std::pow(rng.gen_f64(), 1.0 / weights[i]), i});
     }
+    // The reference pushes every key into a BinaryHeap and pops `amount` times: the `amount` largest keys in
+    // descending order.  Same result by selection + a small sort (ties between equal 53-bit random keys have
+    // probability ~0; they are broken by index here).
+    auto greater = [](const El &a, const El &b) { return a.key > b.key || (a.key == b.key && a.index < b.index); };
+    if (amount < length) std::nth_element(keyed.begin(), keyed.begin() + amount, keyed.end(), greater);
+    std::sort(keyed.begin(), keyed.begin() + amount, greater);
     std::vector<uint32_t> out;
     out.reserve(amount);
-    while (out.size() < amount) {
-        std::pop_heap(heap.begin(), heap.end(), less);
-        out.push_back(heap.back().index);
-        heap.pop_back();
-    }
+    for (uint32_t i = 0; i < amount; i++) out.push_back(keyed[i].index);
     return out;
 }
 
