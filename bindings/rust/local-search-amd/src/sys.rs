@@ -9,6 +9,7 @@ use std::os::raw::{c_char, c_double, c_int, c_void};
 pub const LS_OK: c_int = 0;
 pub const LS_NQ_ALGO_SCAN: c_int = 0;
 pub const LS_NQ_ALGO_TABLE: c_int = 1;
+pub const LS_NQ_ALGO_AUTO: c_int = 2;
 
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct ls_nq_result { pub n_scored: i64, pub best_index: i64, pub best_score: i64, pub best_col: i32, pub best_value: i32 }

@@ -164,6 +164,8 @@ struct NQueensProblem {
     NqBatcher *batcher = nullptr; // set when this restart is one of a lockstep batch
     // statistics
     uint64_t neighbours_scored = 0, gpu_evals = 0, gpu_col_score_calls = 0;
+    double t_prop = 0, t_gpu = 0;
+    ~NQueensProblem() { if (getenv("LS_AMD_TRACE")) fprintf(stderr, "nq: evals %llu prop %.3f s gpu %.3f s\n", (unsigned long long)gpu_evals, t_prop, t_gpu); }
     // column scores of the board the loop will expand next, delivered by the previous neighbourhood's
     // round trip (or by score()): saves one GPU round trip per LS iteration
     mutable Solution cached_board;
@@ -248,9 +250,12 @@ struct NQueensProblem {
     // local_search.rs:315-325 for this plug-in: one GPU launch
     template <class R> bool best_of_neighbourhood(const SS &current, R &rng, size_t window, SS &out)
     {
+        const auto T0 = std::chrono::steady_clock::now();
         const std::vector<int32_t> cols = propose_columns(current.solution, rng);
         if (cols.empty()) return false;
         const std::vector<int32_t> rows = pack(current.solution);
+        const auto T1 = std::chrono::steady_clock::now();
+        t_prop += std::chrono::duration<double>(T1 - T0).count();
         ls_nq_result res;
         std::vector<int64_t> next_cs(rows.size());
         if (batcher) {
@@ -265,6 +270,7 @@ struct NQueensProblem {
                                                      &nc, nc, (int64_t)window, &res, next_cs.data()),
                      "ls_nqueens_eval_batch_next");
         }
+        t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - T1).count();
         gpu_evals++;
         neighbours_scored += (uint64_t)res.n_scored;
         if (res.best_index < 0) return false;

@@ -32,6 +32,10 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
                       ls_nq_result *results_d, long long *scores_out_d, int *next_rows_d);
 int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, long long *col_scores_d,
                       long long *scores_d);
+bool nq_step_eligible(const ls_ctx *ctx, int n, int max_cols, long long window);
+int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long long *cur, const int *cols,
+                const int *n_cols, int max_cols, long long window, ls_nq_result *results, int *next_rows,
+                long long *next_col_scores, long long *next_totals);
 // sched_kernels.hip
 int sched_score_dev(ls_ctx *ctx, int n_states, const int *states_d, long long *hard_d, long long *soft_d,
                     long long *terms_d);
@@ -96,6 +100,7 @@ int ls_ctx_create(int device_id, ls_ctx **out)
     }
     ctx->stream = ctx->own_stream;
     if (const char *v = getenv("LS_NQ_SCAN_VARIANT")) ctx->nq_scan_variant = atoi(v);
+    if (const char *v = getenv("LS_NQ_STEP")) ctx->nq_step_mode = atoi(v);
     ctx->sched_force_64 = getenv("LS_SCHED_FORCE_64") != nullptr;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->wave_size = prop.warpSize;
@@ -149,7 +154,8 @@ int ls_ctx_synchronize(ls_ctx *ctx)
 int ls_ctx_set_nq_algo(ls_ctx *ctx, int algo)
 {
     if (!ctx) return LS_ERR_INVALID;
-    LS_REQUIRE(ctx, algo == LS_NQ_ALGO_SCAN || algo == LS_NQ_ALGO_TABLE, "unknown N-queens algo %d", algo);
+    LS_REQUIRE(ctx, algo == LS_NQ_ALGO_SCAN || algo == LS_NQ_ALGO_TABLE || algo == LS_NQ_ALGO_AUTO,
+               "unknown N-queens algo %d", algo);
     ctx->nq_algo = algo;
     return LS_OK;
 }
@@ -247,9 +253,26 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
     memcpy(si.h<char>(o_rows), rows, rows_b);
     if (cols_b) memcpy(si.h<char>(o_cols), cols, cols_b);
     memcpy(si.h<char>(o_nc), n_cols, nc_b);
+    const long long win = nq_clamp_window(window, max_cols, n);
+    if (cs_b && !sc_b && ctx->nq_step_mode > 0 && nq_step_eligible(ctx, n, max_cols, win)) {
+        // One LS step per restart in one launch.  Mode 2: the kernel reads the pinned staging block and writes
+        // the pinned result block directly (each byte crosses PCIe once, no copy dispatches in the chain).
+        const bool zc = ctx->nq_step_mode >= 2;
+        if (!zc) LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
+        char *ib = static_cast<char *>(zc ? si.host : si.dev), *ob = static_cast<char *>(zc ? so.host : so.dev);
+        rc = nq_step_dev(ctx, n_restarts, n, reinterpret_cast<int *>(ib + o_rows), reinterpret_cast<long long *>(ib + o_cur),
+                         reinterpret_cast<int *>(ib + o_cols), reinterpret_cast<int *>(ib + o_nc), max_cols, win,
+                         reinterpret_cast<ls_nq_result *>(ob + o_res), nullptr, reinterpret_cast<long long *>(ob + o_cs), nullptr);
+        if (rc != LS_OK) return rc;
+        if (!zc) LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
+        LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(results, so.h<char>(o_res), res_b);
+        memcpy(next_col_scores, so.h<char>(o_cs), cs_b);
+        return LS_OK;
+    }
     LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
     rc = nq_eval_batch_dev(ctx, n_restarts, n, si.d<int>(o_rows), si.d<long long>(o_cur), si.d<int>(o_cols), si.d<int>(o_nc),
-                           max_cols, nq_clamp_window(window, max_cols, n), so.d<ls_nq_result>(o_res),
+                           max_cols, win, so.d<ls_nq_result>(o_res),
                            sc_b ? ctx->nq_scores.as<long long>() : nullptr, cs_b ? ctx->nq_next_rows.as<int>() : nullptr);
     if (rc != LS_OK) return rc;
     if (cs_b) {
@@ -281,8 +304,13 @@ int ls_nqueens_eval_batch_next_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, c
     if (rc != LS_OK) return rc;
     LS_REQUIRE(ctx, rows_d && cur_scores_d && n_cols_d && results_d && (cols_d || max_cols == 0) && next_rows_d &&
                         next_col_scores_d, "null device pointer");
+    const long long win = nq_clamp_window(window, max_cols, n);
+    if (ctx->nq_step_mode > 0 && nq_step_eligible(ctx, n, max_cols, win))
+        return nq_step_dev(ctx, n_restarts, n, rows_d, reinterpret_cast<const long long *>(cur_scores_d), cols_d, n_cols_d,
+                           max_cols, win, results_d, next_rows_d, reinterpret_cast<long long *>(next_col_scores_d),
+                           reinterpret_cast<long long *>(next_scores_d));
     rc = nq_eval_batch_dev(ctx, n_restarts, n, rows_d, reinterpret_cast<const long long *>(cur_scores_d), cols_d, n_cols_d,
-                           max_cols, nq_clamp_window(window, max_cols, n), results_d, nullptr, next_rows_d);
+                           max_cols, win, results_d, nullptr, next_rows_d);
     if (rc != LS_OK) return rc;
     return nq_col_scores_dev(ctx, n_restarts, n, next_rows_d, reinterpret_cast<long long *>(next_col_scores_d),
                              reinterpret_cast<long long *>(next_scores_d));

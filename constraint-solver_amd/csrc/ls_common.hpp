@@ -79,7 +79,8 @@ struct ls_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    int nq_algo = LS_NQ_ALGO_SCAN;
+    int nq_algo = LS_NQ_ALGO_AUTO;
+    int nq_step_mode = 2; // fused LS-step kernel: 0 off, 1 through device staging copies, 2 zero-copy on pinned host memory (LS_NQ_STEP)
     long long nq_keys_ready = 0; // leading argmin keys known to hold NQ_KEY_EMPTY (the finalize kernel resets what it reads)
     bool sched_force_64 = false; // LS_SCHED_FORCE_64: use the full-wavefront scheduling kernel even for <= 32 days
     int nq_scan_variant = 0; // register-scan formulation: 0 auto (fp32), 1 packed u16 (LS_NQ_SCAN_VARIANT)

@@ -805,6 +805,127 @@ __global__ __launch_bounds__(1024) void nq_col_scores_lds_kernel(const int *rows
     }
 }
 
+// ============================================================= fused LS step
+// One LS iteration of one restart in ONE launch, one 1024-thread block per restart (the solver's
+// per-iteration shape: window = 5n => ~5 columns, ~20k candidates, where launch latency, not
+// throughput, is the cost).  The block reads rows / cols ONCE into LDS (so the inputs may live in
+// pinned host memory), builds the three packed-u16 occupancy tables, scores the candidates that
+// take(window) can reach, picks the (score, solution) minimum, applies the move to its LDS board and
+// tables, and emits the winner's column scores (the next iteration's proposer input, lib.rs:182) --
+// what the multi-launch path does with table_lds + finalize + col_scores_lds.
+constexpr int NQ_STEP_MAX_N = 8192;         // 10n (tables) + 4n (rows) bytes of LDS
+constexpr long long NQ_STEP_MAX_K = 65536;  // unfiltered positions per restart one block is asked to walk
+constexpr int NQ_STEP_MAX_SLOTS = 1024;
+
+__device__ __forceinline__ void tab16_dec(unsigned *t, int idx) { atomicSub(&t[idx >> 1], 1u << (16 * (idx & 1))); }
+
+__global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *results, int *next_rows,
+                                                       long long *next_col_scores, long long *next_totals)
+{
+    extern __shared__ unsigned s_dyn[]; // tables (packed u16: R[n] | A[2n] | B[2n]) | rows[n] | cols[n_slots]
+    __shared__ unsigned long long s_best[16];
+    __shared__ int s_sum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    const int r = blockIdx.x, n = a.n;
+    const int words = (5 * n + 1) >> 1;
+    unsigned *s_t16 = s_dyn;
+    int *s_rows = reinterpret_cast<int *>(s_dyn + words);
+    int *s_cols = s_rows + n;
+    const int *__restrict__ rows = a.rows + (long long)r * n;
+    const int *__restrict__ cols = a.cols + (long long)r * a.max_cols;
+    int ncols = a.n_cols[r];
+    ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
+    const long long K = nq_k_limit((long long)ncols * n, n, a.window);
+    const int n_slots = (int)((K + n - 1) / n);
+    for (int i = tid; i < words; i += 1024) s_t16[i] = 0;
+    for (int j = tid; j < n; j += 1024) s_rows[j] = rows[j];
+    for (int s = tid; s < n_slots; s += 1024) s_cols[s] = cols[s];
+    __syncthreads();
+    for (int j = tid; j < n; j += 1024) {
+        const int q = s_rows[j];
+        if ((unsigned)q < (unsigned)n) {
+            tab16_inc(s_t16, q);
+            tab16_inc(s_t16, n + (q - j + n));
+            tab16_inc(s_t16, 3 * n + (q + j));
+        }
+    }
+    __syncthreads();
+    const int oA = n, oB = 3 * n;
+    unsigned long long best = NQ_KEY_EMPTY;
+    for (int slot = 0; slot < n_slots; slot++) {
+        const long long left = K - (long long)slot * n;
+        const int ve = left < n ? (int)left : n;
+        const int c = s_cols[slot];
+        const int rc = (unsigned)c < (unsigned)n ? s_rows[c] : -1;
+        if ((unsigned)rc >= (unsigned)n) continue;
+        const NqRanges rg = nq_ranges(0, ve, rc, (long long)slot * (n - 1), a.window);
+        const int conf_old = tab16_get(s_t16, rc) + tab16_get(s_t16, oA + rc - c + n) + tab16_get(s_t16, oB + rc + c) - 3;
+        const unsigned long long khd = nq_key_hi(0, c, n, slot), khu = nq_key_hi(1, c, n, slot);
+        // one strided walk over [d0, u1); v == rc is the no-op, everything else in range is a candidate
+        for (int v = rg.d0 + tid; v < rg.u1; v += 1024) {
+            const bool down = v < rg.d1, up = v >= rg.u0;
+            if (down || up) {
+                const int delta = tab16_get(s_t16, v) + tab16_get(s_t16, oA + v - c + n) + tab16_get(s_t16, oB + v + c) - conf_old;
+                best = u64min(best, nq_key(delta, down ? khd : khu, v));
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) s_best[wib] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long key = s_best[0];
+        for (int i = 1; i < 16; i++) key = u64min(key, s_best[i]);
+        const long long total = (long long)ncols * (n - 1);
+        ls_nq_result out;
+        out.n_scored = a.window < total ? (a.window < 0 ? 0 : a.window) : total;
+        if (key == NQ_KEY_EMPTY || out.n_scored == 0) {
+            out.n_scored = key == NQ_KEY_EMPTY ? 0 : out.n_scored;
+            out.best_index = -1;
+            out.best_score = 0;
+            out.best_col = -1;
+            out.best_value = -1;
+        } else {
+            const int slot = (int)(key & 0x7fffu);
+            const int v = (int)((key >> 15) & 0x7fffu);
+            const int colkey = (int)((key >> 30) & 0x7fffu);
+            const int is_up = (int)((key >> 45) & 1u);
+            const int c = is_up ? n - 1 - colkey : colkey;
+            const int delta = (int)(key >> 46) - NQ_DELTA_BIAS;
+            out.best_index = (long long)slot * n + v;
+            out.best_score = a.cur_scores[r] + 2ll * delta;
+            out.best_col = c;
+            out.best_value = v;
+            // the move (MoveIterator, lib.rs:226-228) on the LDS board and its tables
+            const int q = s_rows[c];
+            tab16_dec(s_t16, q); tab16_dec(s_t16, oA + q - c + n); tab16_dec(s_t16, oB + q + c);
+            tab16_inc(s_t16, v); tab16_inc(s_t16, oA + v - c + n); tab16_inc(s_t16, oB + v + c);
+            s_rows[c] = v;
+        }
+        results[r] = out;
+    }
+    __syncthreads();
+    int local = 0;
+    for (int j = tid; j < n; j += 1024) {
+        const int q = s_rows[j];
+        int sc = 0;
+        if ((unsigned)q < (unsigned)n) sc = tab16_get(s_t16, q) + tab16_get(s_t16, oA + q - j + n) + tab16_get(s_t16, oB + q + j) - 3;
+        if (next_col_scores) next_col_scores[(long long)r * n + j] = sc;
+        if (next_rows) next_rows[(long long)r * n + j] = q;
+        local += sc;
+    }
+    if (next_totals) { // block-uniform
+        const int ws = wave_sum_i32(local);
+        if (lane == 0) s_sum[wib] = ws;
+        __syncthreads();
+        if (tid == 0) {
+            long long t = 0;
+            for (int i = 0; i < 16; i++) t += s_sum[i];
+            next_totals[r] = t;
+        }
+    }
+}
+
 // ================================================================ launchers
 static int nq_blocks_per_cu(const void *fn, size_t dyn_lds)
 {
@@ -952,7 +1073,7 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
         }
     }
     if (max_cols > 0) {
-        if (ctx->nq_algo == LS_NQ_ALGO_TABLE && n <= NQ_TABLE_LDS_MAX_N) {
+        if (ctx->nq_algo != LS_NQ_ALGO_SCAN && n <= NQ_TABLE_LDS_MAX_N) {
             const size_t lds = (size_t)((5 * n + 1) / 2) * 4 + 16;
             static bool attr_done_dev[64] = {false};
             if (!attr_done_dev[ctx->device & 63]) {
@@ -970,7 +1091,7 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
             if (bpr < 1) bpr = 1;
             hipLaunchKernelGGL(nq_table_lds_kernel, dim3((unsigned)(bpr * n_restarts)), dim3(256), lds, ctx->stream, a);
             LS_HIP(ctx, hipGetLastError());
-        } else if (ctx->nq_algo == LS_NQ_ALGO_TABLE) {
+        } else if (ctx->nq_algo != LS_NQ_ALGO_SCAN) {
             int *tabs = nullptr; int stride = 0;
             int rc = build_tables(ctx, n_restarts, n, rows_d, &tabs, &stride);
             if (rc != LS_OK) return rc;
@@ -1023,6 +1144,38 @@ int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, lon
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(nq_col_scores_kernel, dim3(gx, n_restarts), dim3(256), 0, ctx->stream, rows_d, n, tabs,
                        stride, col_scores_d, scores_d);
+    LS_HIP(ctx, hipGetLastError());
+    return LS_OK;
+}
+
+bool nq_step_eligible(const ls_ctx *ctx, int n, int max_cols, long long window)
+{
+    if (ctx->nq_algo == LS_NQ_ALGO_SCAN || n < 2 || n > NQ_STEP_MAX_N || max_cols < 1) return false;
+    long long k_max = (long long)max_cols * n;
+    if (window / (n - 1) < max_cols) k_max = (window / (n - 1) + 1) * n;
+    return k_max <= NQ_STEP_MAX_K && (k_max + n - 1) / n <= NQ_STEP_MAX_SLOTS;
+}
+
+// Pointers may be device memory or pinned host memory (each input is read once, each output written once).
+int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long long *cur, const int *cols,
+                const int *n_cols, int max_cols, long long window, ls_nq_result *results, int *next_rows,
+                long long *next_col_scores, long long *next_totals)
+{
+    NqArgs a;
+    a.rows = rows; a.cur_scores = cur; a.cols = cols; a.n_cols = n_cols;
+    a.n = n; a.n_restarts = n_restarts; a.max_cols = max_cols; a.window = window;
+    a.best_keys = nullptr; a.scores_out = nullptr; a.tabs = nullptr; a.tab_stride = 0;
+    static bool attr_done_dev[64] = {false};
+    if (!attr_done_dev[ctx->device & 63]) {
+        LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        ((5 * NQ_STEP_MAX_N + 1) / 2 + NQ_STEP_MAX_N + NQ_STEP_MAX_SLOTS) * 4));
+        attr_done_dev[ctx->device & 63] = true;
+    }
+    long long slots = (long long)max_cols;
+    if (window / (n - 1) < max_cols) slots = window / (n - 1) + 1;
+    const size_t lds = ((size_t)(5 * n + 1) / 2 + (size_t)n + (size_t)slots) * 4;
+    hipLaunchKernelGGL(nq_step_kernel, dim3(n_restarts), dim3(1024), lds, ctx->stream, a, results, next_rows, next_col_scores,
+                       next_totals);
     LS_HIP(ctx, hipGetLastError());
     return LS_OK;
 }

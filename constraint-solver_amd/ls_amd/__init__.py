@@ -12,10 +12,10 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (INT64_MIN, LS_NQ_ALGO_SCAN, LS_NQ_ALGO_TABLE, LS_NQ_MAX_N, LS_SCHED_MAX_DAYS,  # noqa: F401
+from ._lib import (INT64_MIN, LS_NQ_ALGO_AUTO, LS_NQ_ALGO_SCAN, LS_NQ_ALGO_TABLE, LS_NQ_MAX_N, LS_SCHED_MAX_DAYS,  # noqa: F401
                    LsError, NqResult, SchedMove, SchedResult, SolverParams)
 
-ALGOS = {"scan": LS_NQ_ALGO_SCAN, "table": LS_NQ_ALGO_TABLE}
+ALGOS = {"scan": LS_NQ_ALGO_SCAN, "table": LS_NQ_ALGO_TABLE, "auto": LS_NQ_ALGO_AUTO}
 
 
 def device_count() -> int:
@@ -33,7 +33,7 @@ def _vp(a):
 class Context:
     """One GPU's context (ls_ctx).  Not thread-safe; one per device."""
 
-    def __init__(self, device: int = 0, algo: str = "scan"):
+    def __init__(self, device: int = 0, algo: str = "auto"):
         self._l = _lib.load()
         h = C.c_void_p()
         rc = self._l.ls_ctx_create(int(device), C.byref(h))
@@ -129,6 +129,14 @@ class Context:
             self._h, int(n_restarts), int(n), C.c_void_p(rows_d), C.c_void_p(cur_scores_d), C.c_void_p(cols_d),
             C.c_void_p(n_cols_d), int(max_cols), int(window), C.c_void_p(results_d),
             C.c_void_p(scores_out_d or 0)))
+
+    def nqueens_eval_batch_next_dev(self, n_restarts, n, rows_d, cur_scores_d, cols_d, n_cols_d, max_cols, window,
+                                    results_d, next_rows_d, next_col_scores_d, next_scores_d=None):
+        """Device-pointer LS step: result + winner board + its column scores (+ its score); asynchronous."""
+        self._check(self._l.ls_nqueens_eval_batch_next_dev(
+            self._h, int(n_restarts), int(n), C.c_void_p(rows_d), C.c_void_p(cur_scores_d), C.c_void_p(cols_d),
+            C.c_void_p(n_cols_d), int(max_cols), int(window), C.c_void_p(results_d), C.c_void_p(next_rows_d),
+            C.c_void_p(next_col_scores_d), C.c_void_p(next_scores_d or 0)))
 
     def nqueens_col_scores(self, rows):
         """rows [R, n] -> (col_scores [R, n] int64, scores [R] int64)."""

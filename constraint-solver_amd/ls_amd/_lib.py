@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "ls_amd.h")
 
 LS_OK = 0
 LS_ERR_INVALID, LS_ERR_NO_DEVICE, LS_ERR_HIP, LS_ERR_UNSUPPORTED, LS_ERR_NOMEM, LS_ERR_STATE = 1, 2, 3, 4, 5, 6
-LS_NQ_ALGO_SCAN, LS_NQ_ALGO_TABLE = 0, 1
+LS_NQ_ALGO_SCAN, LS_NQ_ALGO_TABLE, LS_NQ_ALGO_AUTO = 0, 1, 2
 LS_NQ_MAX_N = 32768
 LS_SCHED_MAX_DAYS = 64
 INT64_MIN = -(2 ** 63)

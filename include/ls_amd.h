@@ -58,8 +58,9 @@ extern "C" {
 #define LS_ERR_STATE        6   /* call order (e.g. schedule eval before instance upload) */
 
 /* N-queens kernel families (ls_ctx_set_nq_algo) */
-#define LS_NQ_ALGO_SCAN   0  /* one wavefront per candidate scans the packed state (default) */
+#define LS_NQ_ALGO_SCAN   0  /* one wavefront per candidate scans the packed state: the reference's O(n) pair checks */
 #define LS_NQ_ALGO_TABLE  1  /* occupancy count tables, O(1) per candidate */
+#define LS_NQ_ALGO_AUTO   2  /* default: the fastest family for the launch (today: TABLE, fused LS step when it fits) */
 
 /* limits */
 #define LS_NQ_MAX_N        32768

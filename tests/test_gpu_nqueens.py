@@ -11,7 +11,7 @@ import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = ["scan", "table"]
+ALGOS = ["scan", "table"]   # "auto" (the default) resolves to the TABLE family
 
 
 @pytest.fixture(scope="module")
@@ -318,3 +318,77 @@ def test_eval_next_returns_winner_column_scores(ctx):
             if out[r]["best_index"] >= 0:
                 assert exp.sum() == out[r]["best_score"]
     ctx.set_algo("scan")
+
+
+def _expect_step(rows, cols, n_cols, window):
+    """Oracle view of one LS step of every restart: neighbourhood result, winner board, its column scores."""
+    out = []
+    for r in range(len(rows)):
+        c = cols[r][:n_cols[r]]
+        exp = orc.nq_neighbourhood(rows[r], c, window, "table", want_scores=False) if len(c) else \
+            dict(n_scored=0, best_index=-1, best_score=0)
+        b = np.array(rows[r]).copy()
+        if exp["best_index"] >= 0:
+            b[c[exp["best_index"] // len(b)]] = exp["best_index"] % len(b)
+        out.append((exp, b, orc.nq_col_scores(b)))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["2", "1", "0"])
+def test_fused_step_kernel_matches_oracle(monkeypatch, mode):
+    # the solver's per-iteration launch: one block per restart does tables + argmin + move + column scores.
+    # LS_NQ_STEP: 2 = zero-copy on pinned host memory (default), 1 = through staging copies, 0 = multi-launch path
+    import ls_amd
+    monkeypatch.setenv("LS_NQ_STEP", mode)
+    rng = np.random.default_rng(100 + int(mode))
+    with ls_amd.Context(0) as c:                      # default algo: auto
+        for n, R, mc, window in ((2, 3, 2, 10), (3, 2, 3, 4), (8, 4, 1, 40), (64, 5, 3, 64), (300, 6, 9, 1500),
+                                 (1024, 8, 51, 5120), (4096, 8, 204, 20480), (4096, 2, 3, 10 ** 9), (8192, 2, 12, 40960),
+                                 (8192, 1, 9, 65535), (500, 3, 4, 1)):
+            kind = "uniform" if n % 2 == 0 else "perm"
+            rows = np.stack([_board(rng, n, kind) for _ in range(R)])
+            cols = np.stack([rng.permutation(n)[:mc] if mc <= n else rng.integers(0, n, size=mc) for _ in range(R)])
+            if mc >= 3:
+                cols[0, 2] = cols[0, 0]               # a duplicated column: the earlier slot must win ties
+            n_cols = np.full(R, mc)
+            if R >= 3:
+                n_cols[1], n_cols[2] = 0, 1           # ragged: an empty and a one-column restart
+            cur = [orc.nq_score(rows[r]) for r in range(R)]
+            out, nxt = c.nqueens_eval_batch_next(rows, cur, cols, n_cols, window)
+            for r, (exp, board, cs) in enumerate(_expect_step(rows, cols, n_cols, window)):
+                assert out[r]["n_scored"] == exp["n_scored"], (n, r)
+                assert out[r]["best_index"] == exp["best_index"], (n, r)
+                if exp["best_index"] >= 0:
+                    assert out[r]["best_score"] == exp["best_score"] == cs.sum()
+                    assert out[r]["best_col"] == cols[r][exp["best_index"] // n]
+                    assert out[r]["best_value"] == exp["best_index"] % n
+                assert np.array_equal(nxt[r], cs), (n, r)
+
+
+def test_fused_step_device_entry(ctx):
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(77)
+    dev = torch.device("cuda:0")
+    ctx.set_algo("auto")
+    for n, R, mc, window in ((1024, 4, 51, 5120), (4096, 3, 204, 20480), (200, 2, 200, 10 ** 9)):
+        rows = np.stack([_board(rng, n, "uniform") for _ in range(R)]).astype(np.int32)
+        cols = np.stack([rng.permutation(n)[:mc] for _ in range(R)]).astype(np.int32)
+        n_cols = np.full(R, mc, dtype=np.int32)
+        cur = np.array([orc.nq_score(rows[r]) for r in range(R)], dtype=np.int64)
+        t = [torch.from_numpy(x).to(dev) for x in (rows, cur, cols, n_cols)]
+        res = torch.zeros((R, 4), dtype=torch.int64, device=dev)
+        nrows = torch.zeros((R, n), dtype=torch.int32, device=dev)
+        ncs = torch.zeros((R, n), dtype=torch.int64, device=dev)
+        ntot = torch.zeros(R, dtype=torch.int64, device=dev)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        try:
+            ctx.nqueens_eval_batch_next_dev(R, n, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), mc,
+                                            window, res.data_ptr(), nrows.data_ptr(), ncs.data_ptr(), ntot.data_ptr())
+            torch.cuda.synchronize()
+        finally:
+            ctx.set_stream(None)
+        raw, nrows, ncs, ntot = res.cpu().numpy(), nrows.cpu().numpy(), ncs.cpu().numpy(), ntot.cpu().numpy()
+        for r, (exp, board, cs) in enumerate(_expect_step(rows, cols, n_cols, window)):
+            assert (raw[r, 0], raw[r, 1]) == (exp["n_scored"], exp["best_index"])
+            assert raw[r, 2] == exp["best_score"]
+            assert np.array_equal(nrows[r], board) and np.array_equal(ncs[r], cs) and ntot[r] == cs.sum()
