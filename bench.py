@@ -368,6 +368,22 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np):
     out["scan_full_neighbourhood_host_pointer_api_pcie_inclusive"] = {
         "neighbours_per_s": R * n * (n - 1) / s, "ms_per_call": s * 1e3,
         "host_bytes_per_call": int(boards.nbytes + cur_np.nbytes + cols_np.nbytes + ncols_np.nbytes + 32 * R)}
+    # the solver's per-iteration call (config 4 shape): fused LS step -- neighbourhood argmin + move + winner's column
+    # scores -- through the HOST-pointer entry, i.e. a complete round trip incl. PCIe and the stream sync
+    ctx.set_algo("auto")
+    cols_h, ncols_h = cols_ref.cpu().numpy(), ncols_ref.cpu().numpy()
+    for RR in (1, R):
+        args_h = (boards[:RR], cur_np[:RR], cols_h[:RR], ncols_h[:RR], 5 * n)
+        for _ in range(200):     # also lets the clocks settle after the heavy launches above
+            ctx.nqueens_eval_batch_next(*args_h)
+        reps = 1000
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.nqueens_eval_batch_next(*args_h)
+        s = (time.perf_counter() - t0) / reps
+        out[f"fused_ls_step_host_round_trip_{RR}_restarts"] = {"us_per_call": s * 1e6, "candidates_per_call": RR * min(5 * n, mc * (n - 1)),
+                                                               "note": "includes ctypes/numpy marshalling of the Python wrapper"}
+    ctx.set_algo("scan")
     out.update(sched_measurements(ctx, torch, dev, timed))
     return out
 

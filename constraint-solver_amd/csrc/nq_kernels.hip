@@ -834,6 +834,7 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
     const int *__restrict__ rows = a.rows + (long long)r * n;
     const int *__restrict__ cols = a.cols + (long long)r * a.max_cols;
     int ncols = a.n_cols[r];
+    const long long cur = tid == 0 ? a.cur_scores[r] : 0; // issued with the other input loads, not on the serial path below
     ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
     const long long K = nq_k_limit((long long)ncols * n, n, a.window);
     const int n_slots = (int)((K + n - 1) / n);
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
             const int c = is_up ? n - 1 - colkey : colkey;
             const int delta = (int)(key >> 46) - NQ_DELTA_BIAS;
             out.best_index = (long long)slot * n + v;
-            out.best_score = a.cur_scores[r] + 2ll * delta;
+            out.best_score = cur + 2ll * delta;
             out.best_col = c;
             out.best_value = v;
             // the move (MoveIterator, lib.rs:226-228) on the LDS board and its tables
