@@ -3,7 +3,7 @@
 (examples/nqueens/src/main.rs:95-150): same flags (--seed/-s string, --board-size/-b), same
 hard-coded hyper-parameters (:129-135), same output shape (board drawing + score).
 
-    python examples/nqueens.py --board-size 8 --seed 42 [--algo scan|table]
+    python examples/nqueens.py --board-size 8 --seed 42 [--algo auto|scan|table]
 """
 import argparse
 import os
@@ -32,7 +32,7 @@ def main():
     ap = argparse.ArgumentParser(description="Local Search N-Queens Example (MI355X)")
     ap.add_argument("-s", "--seed", default="42", help="Random seed, any string")
     ap.add_argument("-b", "--board-size", type=int, default=8)
-    ap.add_argument("--algo", choices=["scan", "table"], default="scan")
+    ap.add_argument("--algo", choices=["auto", "scan", "table"], default="auto")
     ap.add_argument("--device", type=int, default=0)
     args = ap.parse_args()
     n = args.board_size

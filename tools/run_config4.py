@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--restarts-per-gpu", type=int, default=8)
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--rounds", type=int, default=10_000)
-    ap.add_argument("--algo", default="scan")
+    ap.add_argument("--algo", default="auto", choices=["auto", "table", "scan"])
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on real multi-GPU nodes; gloo to rehearse ranks on one GPU")
     ap.add_argument("--all-on-device", type=int, default=None, help="rehearsal only: every rank uses this device")
     args = ap.parse_args()
