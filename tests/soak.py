@@ -57,6 +57,30 @@ def nq_case(ctx):
             fail(f"nqueens {algo}: debug and production paths differ", n=n, rows=rows, cols=cols, window=window)
     stats["nq"] += 1
     stats["nq_candidates"] += exp["n_scored"]
+    # the solver's per-iteration call: result + winner board's column scores (fused step kernel under "auto"
+    # whenever the launch fits it, multi-launch otherwise), here as a ragged 3-restart batch
+    if n >= 2:
+        R = 3
+        brows = np.stack([rows, rng.integers(0, n, size=n), rng.permutation(n)])
+        mc = max(1, n_cols)
+        bcols = np.stack([np.resize(cols, mc) if n_cols else np.zeros(mc, dtype=np.int64), rng.integers(0, n, size=mc),
+                          rng.permutation(n)[:mc] if mc <= n else rng.integers(0, n, size=mc)])
+        bn = np.array([n_cols, mc, int(rng.integers(0, mc + 1))])
+        bcur = [orc.nq_score(b) for b in brows]
+        for algo in ("auto", "scan"):
+            ctx.set_algo(algo)
+            out, nxt = ctx.nqueens_eval_batch_next(brows, bcur, bcols, bn, window)
+            for r in range(R):
+                c = bcols[r][:bn[r]]
+                e = orc.nq_neighbourhood(brows[r], c, window, "table", want_scores=False) if len(c) else dict(n_scored=0, best_index=-1)
+                b = brows[r].copy()
+                if e["best_index"] >= 0:
+                    b[c[e["best_index"] // n]] = e["best_index"] % n
+                if (out[r]["n_scored"], out[r]["best_index"]) != (e["n_scored"], e["best_index"]) or \
+                        (e["best_index"] >= 0 and out[r]["best_score"] != e["best_score"]) or \
+                        not np.array_equal(nxt[r], orc.nq_col_scores(b)):
+                    fail(f"nqueens step {algo}", n=n, rows=brows[r], cols=c, window=window, got=out[r])
+        stats["nq_steps"] = stats.get("nq_steps", 0) + 2 * R
 
 
 def sched_case(ctx):
