@@ -101,6 +101,8 @@ int ls_ctx_create(int device_id, ls_ctx **out)
     ctx->stream = ctx->own_stream;
     if (const char *v = getenv("LS_NQ_SCAN_VARIANT")) ctx->nq_scan_variant = atoi(v);
     if (const char *v = getenv("LS_NQ_STEP")) ctx->nq_step_mode = atoi(v);
+    if (const char *v = getenv("LS_SCHED_ZEROCOPY")) ctx->sched_zero_copy = atoi(v) != 0;
+    if (const char *v = getenv("LS_SCHED_FUSED")) ctx->sched_fused = atoi(v) != 0;
     ctx->sched_force_64 = getenv("LS_SCHED_FORCE_64") != nullptr;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->wave_size = prop.warpSize;
@@ -559,11 +561,15 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
     Staging &si = ctx->stage_in, &so = ctx->stage_out;
     *si.h<long long>(o_nm) = n_moves;
     memcpy(si.h<char>(o_st), state, (size_t)S * 4);
-    LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
-    rc = sched_eval_batch_dev(ctx, 1, si.d<int>(o_st), ctx->sc_resident_moves.as<ls_sched_move>(), si.d<long long>(o_nm),
-                              n_moves, window, so.d<ls_sched_result>(0), nullptr, nullptr);
+    // The per-iteration inputs are 136 bytes and the output 32: the kernels read / write the pinned blocks directly
+    // (LS_SCHED_ZEROCOPY=0 restores the two staging copies), so the chain is kernels only.
+    const bool zc = ctx->sched_zero_copy && n_moves <= 4096; // many blocks re-reading the state over PCIe cost more than the copies
+    if (!zc) LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = sched_eval_batch_dev(ctx, 1, zc ? si.h<int>(o_st) : si.d<int>(o_st), ctx->sc_resident_moves.as<ls_sched_move>(),
+                              zc ? si.h<long long>(o_nm) : si.d<long long>(o_nm), n_moves, window,
+                              zc ? so.h<ls_sched_result>(0) : so.d<ls_sched_result>(0), nullptr, nullptr);
     if (rc != LS_OK) return rc;
-    LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    if (!zc) LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
     LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = *so.h<ls_sched_result>(0);
     return LS_OK;

@@ -47,7 +47,9 @@ struct Staging {
         if (bytes <= cap) return hipSuccess;
         release();
         size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
-        hipError_t e = hipHostMalloc(&host, want, hipHostMallocDefault);
+        // coherent (fine-grained) whatever HIP_HOST_COHERENT says: kernels read and write this block in place
+        hipError_t e = hipHostMalloc(&host, want, hipHostMallocCoherent);
+        if (e != hipSuccess) e = hipHostMalloc(&host, want, hipHostMallocDefault);
         if (e != hipSuccess) { host = nullptr; return e; }
         e = hipMalloc(&dev, want);
         if (e != hipSuccess) { (void)hipHostFree(host); host = nullptr; dev = nullptr; return e; }
@@ -82,6 +84,8 @@ struct ls_ctx {
     int nq_algo = LS_NQ_ALGO_AUTO;
     int nq_step_mode = 2; // fused LS-step kernel: 0 off, 1 through device staging copies, 2 zero-copy on pinned host memory (LS_NQ_STEP)
     long long nq_keys_ready = 0; // leading argmin keys known to hold NQ_KEY_EMPTY (the finalize kernel resets what it reads)
+    bool sched_zero_copy = true; // ls_sched_eval_resident: kernels work on the pinned staging blocks directly (LS_SCHED_ZEROCOPY)
+    bool sched_fused = true;     // small scheduling launches: locate + eval + reduce in one kernel (LS_SCHED_FUSED)
     bool sched_force_64 = false; // LS_SCHED_FORCE_64: use the full-wavefront scheduling kernel even for <= 32 days
     int nq_scan_variant = 0; // register-scan formulation: 0 auto (fp32), 1 packed u16 (LS_NQ_SCAN_VARIANT)
     int n_cus = 0;

@@ -46,6 +46,7 @@ typedef unsigned long long u64;
 constexpr u64 SC_KEY_EMPTY = ~0ull;
 constexpr int SC_BIG = 1 << 20;
 constexpr int SC_COUNT_CHUNK = 1024; // moves per block in the window-count pass
+constexpr int SC_FUSED_WAVES = 16;   // wavefronts of the fused small-launch block (one block per restart)
 
 struct SchedInst {
     int D;             // scored days
@@ -334,10 +335,10 @@ __device__ __forceinline__ u64 sc_edit_key(int pos, int newv, int basev)
     return ((u64)cls << 21) | ((u64)poskey << 15) | (unsigned)newv;
 }
 
-__device__ __forceinline__ void sched_write_result(const SchedEvalArgs &a, int r, u64 bk, long long bi)
+__device__ __forceinline__ void sched_write_result_n(const SchedEvalArgs &a, int r, u64 bk, long long bi, long long n_scored)
 {
     ls_sched_result out;
-    out.n_scored = a.n_scored[r];
+    out.n_scored = n_scored;
     if (bk == SC_KEY_EMPTY) { out.best_index = -1; out.best_hard = 0; out.best_soft = 0; out.n_scored = 0; }
     else {
         out.best_index = bi;
@@ -347,24 +348,78 @@ __device__ __forceinline__ void sched_write_result(const SchedEvalArgs &a, int r
     a.results[r] = out;
 }
 
+__device__ __forceinline__ void sched_write_result(const SchedEvalArgs &a, int r, u64 bk, long long bi)
+{
+    sched_write_result_n(a, r, bk, bi, a.n_scored[r]);
+}
+
+// Fused small launch (one block of NW wavefronts per restart, max_moves <= SC_COUNT_CHUNK): the block first finds
+// where take(window) stops (pass 1b's in-chunk ballots, on the whole move list), then scores, then writes the
+// result itself -- locate + eval + reduce in ONE launch.  The state is read once into LDS, so it may live in pinned
+// host memory.
+struct SchedFusedShared {
+    int state[64];
+    int wcnt[16];
+    long long found;
+};
+
+template <int NW>
+__device__ __forceinline__ void sched_locate_in_block(const SchedEvalArgs &a, int r, SchedFusedShared &sh, long long &k_end,
+                                                      long long &n_scored)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x < 64) sh.state[threadIdx.x] = (int)threadIdx.x < a.in.S ? a.states[(long long)r * a.in.S + threadIdx.x] : -1;
+    if (threadIdx.x == 0) sh.found = -1;
+    __syncthreads();
+    const long long nm = sched_nm(a, r);
+    const ls_sched_move *mv = a.moves + (long long)r * a.max_moves;
+    long long run = 0;
+    k_end = nm;
+    if (a.window <= 0) { k_end = 0; n_scored = 0; return; }
+    for (int t = 0; t < SC_COUNT_CHUNK && t < nm; t += 64 * NW) { // block-uniform trip count
+        const long long k = t + threadIdx.x;
+        const bool flag = sched_counts(a, mv, k, nm, sh.state);
+        const u64 bal = __ballot(flag);
+        __syncthreads(); // wcnt is reused
+        if (lane == 0) sh.wcnt[w] = __popcll(bal);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int i = 0; i < NW; i++) {
+            if (i < w) before += sh.wcnt[i];
+            total += sh.wcnt[i];
+        }
+        const int incl = before + __popcll(bal & ((2ull << lane) - 1));
+        if (flag && run + incl == a.window) sh.found = k + 1;
+        __syncthreads();
+        if (sh.found >= 0) break;
+        run += total;
+    }
+    if (sh.found >= 0) { k_end = sh.found; run = a.window; }
+    n_scored = run;
+}
+
 // Pass 2: score every non-tabu candidate k < k_end.
-__global__ __launch_bounds__(256) void sched_eval_kernel(SchedEvalArgs a)
+template <int NW, bool FUSED>
+__global__ __launch_bounds__(64 * NW) void sched_eval_kernel(SchedEvalArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = blockIdx.x % a.n_restarts;
-    const int wave = (blockIdx.x / a.n_restarts) * 4 + wib;
-    const int n_waves = (gridDim.x / a.n_restarts) * 4;
+    const int r = FUSED ? (int)blockIdx.x : (int)(blockIdx.x % a.n_restarts);
+    const int wave = FUSED ? wib : (int)(blockIdx.x / a.n_restarts) * NW + wib;
+    const int n_waves = FUSED ? NW : (int)(gridDim.x / a.n_restarts) * NW;
     const int S = a.in.S, D = a.in.D, E = a.in.n_employees;
-    const long long k_end = a.k_end[r];
+    __shared__ SchedFusedShared s_fused;
+    long long k_end, n_scored_f = 0;
+    if (FUSED) sched_locate_in_block<NW>(a, r, s_fused, k_end, n_scored_f);
+    else k_end = a.k_end[r];
     const long long n_batches = ((k_end + 63) >> 6) * a.split; // work units: (batch, part)
-    __shared__ u64 s_key[4];
-    __shared__ long long s_idx[4];
+    __shared__ u64 s_key[NW];
+    __shared__ long long s_idx[NW];
     u64 best_key = SC_KEY_EMPTY; // this lane's running minimum (key, index)
     long long best_idx = -1;
     if (wave < n_batches) {
     const SchedLaneConst L = a.in.lane_tab[lane];
-    const int base = lane < S ? a.states[(long long)r * S + lane] : -1 - lane;
+    const int base = lane < S ? (FUSED ? s_fused.state[lane] : a.states[(long long)r * S + lane]) : -1 - lane;
     const u64 eq_base = sched_build_eq(D, base) & L.scored_mask;
     const int hb_base = sched_holiday_bit(a.in, base, lane);
     const ls_sched_move *mv = a.moves + (long long)r * a.max_moves;
@@ -446,11 +501,13 @@ __global__ __launch_bounds__(256) void sched_eval_kernel(SchedEvalArgs a)
     if (lane == 0) { s_key[wib] = best_key; s_idx[wib] = best_idx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < 4; i++)
+        for (int i = 1; i < NW; i++)
             if (s_key[i] < best_key || (s_key[i] == best_key && best_key != SC_KEY_EMPTY && s_idx[i] < best_idx)) {
                 best_key = s_key[i]; best_idx = s_idx[i];
             }
-        if (a.blocks_per_restart == 1) {
+        if (FUSED) {
+            sched_write_result_n(a, r, best_key, best_idx, n_scored_f);
+        } else if (a.blocks_per_restart == 1) {
             sched_write_result(a, r, best_key, best_idx);
         } else {
             const long long slot = (long long)r * a.blocks_per_restart + blockIdx.x / a.n_restarts;
@@ -546,20 +603,24 @@ __device__ __forceinline__ SchedPartial32 sched_terms32(int D, const SchedLane32
     return r;
 }
 
-__global__ __launch_bounds__(256) void sched_eval32_kernel(SchedEvalArgs a)
+template <int NW, bool FUSED>
+__global__ __launch_bounds__(64 * NW) void sched_eval32_kernel(SchedEvalArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int li = lane & 31;      // day
     const bool upper = lane >= 32; // which of the two candidates of a pass this lane works for
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = blockIdx.x % a.n_restarts;
-    const int wave = (blockIdx.x / a.n_restarts) * 4 + wib;
-    const int n_waves = (gridDim.x / a.n_restarts) * 4;
+    const int r = FUSED ? (int)blockIdx.x : (int)(blockIdx.x % a.n_restarts);
+    const int wave = FUSED ? wib : (int)(blockIdx.x / a.n_restarts) * NW + wib;
+    const int n_waves = FUSED ? NW : (int)(gridDim.x / a.n_restarts) * NW;
     const int S = a.in.S, D = a.in.D, E = a.in.n_employees;
-    const long long k_end = a.k_end[r];
+    __shared__ SchedFusedShared s_fused;
+    long long k_end, n_scored_f = 0;
+    if (FUSED) sched_locate_in_block<NW>(a, r, s_fused, k_end, n_scored_f);
+    else k_end = a.k_end[r];
     const long long n_units = ((k_end + 63) >> 6) * a.split; // work units: (batch, part)
-    __shared__ u64 s_key[4];
-    __shared__ long long s_idx[4];
+    __shared__ u64 s_key[NW];
+    __shared__ long long s_idx[NW];
     u64 best_key = SC_KEY_EMPTY;
     long long best_idx = -1;
     if (wave < n_units) {
@@ -568,7 +629,7 @@ __global__ __launch_bounds__(256) void sched_eval32_kernel(SchedEvalArgs a)
         L.scored_mask = (unsigned)L64.scored_mask; L.weekend_mask = (unsigned)L64.weekend_mask;
         L.mask2 = (unsigned)L64.mask2; L.h3mask = (unsigned)L64.h3mask; L.wdmask = (unsigned)L64.wdmask;
         L.gsize = L64.gsize; L.flags = L64.flags;
-        const int base = li < S ? a.states[(long long)r * S + li] : -1 - li; // both halves hold the base vector
+        const int base = li < S ? (FUSED ? s_fused.state[li] : a.states[(long long)r * S + li]) : -1 - li; // both halves hold the base vector
         unsigned eq_base = 0;
 #pragma unroll
         for (int q = 0; q < 32; q++)
@@ -672,11 +733,13 @@ __global__ __launch_bounds__(256) void sched_eval32_kernel(SchedEvalArgs a)
     if (lane == 0) { s_key[wib] = best_key; s_idx[wib] = best_idx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < 4; i++)
+        for (int i = 1; i < NW; i++)
             if (s_key[i] < best_key || (s_key[i] == best_key && best_key != SC_KEY_EMPTY && s_idx[i] < best_idx)) {
                 best_key = s_key[i]; best_idx = s_idx[i];
             }
-        if (a.blocks_per_restart == 1) {
+        if (FUSED) {
+            sched_write_result_n(a, r, best_key, best_idx, n_scored_f);
+        } else if (a.blocks_per_restart == 1) {
             sched_write_result(a, r, best_key, best_idx);
         } else {
             const long long slot = (long long)r * a.blocks_per_restart + blockIdx.x / a.n_restarts;
@@ -788,6 +851,17 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
         hipLaunchKernelGGL(fill_i64_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream, soft_out_d, (long long)INT64_MIN, total);
         LS_HIP(ctx, hipGetLastError());
     }
+    if (n_chunks == 1 && batches * 4 <= 2 * SC_FUSED_WAVES && ctx->sched_fused) {
+        // small launch (the reference's example: window 100): locate + eval + reduce in one block per restart
+        a.split = 4;
+        a.blocks_per_restart = 1;
+        if (ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64)
+            hipLaunchKernelGGL((sched_eval32_kernel<SC_FUSED_WAVES, true>), dim3(n_restarts), dim3(64 * SC_FUSED_WAVES), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((sched_eval_kernel<SC_FUSED_WAVES, true>), dim3(n_restarts), dim3(64 * SC_FUSED_WAVES), 0, ctx->stream, a);
+        LS_HIP(ctx, hipGetLastError());
+        return LS_OK;
+    }
     if (n_chunks > 1) { // a single chunk is counted by the locate pass itself
         hipLaunchKernelGGL(sched_count_kernel, dim3((unsigned)n_chunks, (unsigned)n_restarts), dim3(256), 0, ctx->stream, a);
         LS_HIP(ctx, hipGetLastError());
@@ -795,9 +869,9 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
     hipLaunchKernelGGL(sched_locate_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a);
     LS_HIP(ctx, hipGetLastError());
     if (ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64)
-        hipLaunchKernelGGL(sched_eval32_kernel, dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL((sched_eval32_kernel<4, false>), dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL(sched_eval_kernel, dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL((sched_eval_kernel<4, false>), dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
     LS_HIP(ctx, hipGetLastError());
     if (bpr > 1) { // with one block per restart pass 2 has already written the result
         hipLaunchKernelGGL(sched_reduce_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a);

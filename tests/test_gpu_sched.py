@@ -183,3 +183,40 @@ def test_resident_move_list_matches_host_list(ctx):
     import ls_amd
     with pytest.raises(ls_amd.LsError):
         ctx.sched_eval_resident(state, 901, 10)
+
+
+@pytest.mark.parametrize("fused,zero_copy", [("1", "1"), ("1", "0"), ("0", "1")])
+def test_small_launch_fused_kernel(monkeypatch, fused, zero_copy):
+    # move lists of <= 512 entries run locate + eval + reduce as ONE block per restart (LS_SCHED_FUSED, default on);
+    # the resident entry hands the kernels the pinned staging blocks directly (LS_SCHED_ZEROCOPY, default on)
+    import ls_amd
+    monkeypatch.setenv("LS_SCHED_FUSED", fused)
+    monkeypatch.setenv("LS_SCHED_ZEROCOPY", zero_copy)
+    rng = np.random.default_rng(40 + int(fused) * 2 + int(zero_copy))
+    with ls_amd.Context(0) as c:
+        for start, end, n_emp in (((2022, 5, 9), (2022, 6, 8), 7),      # half-wavefront kernel (32 stored days)
+                                  ((2024, 1, 3), (2024, 1, 10), 3),     # 8 days
+                                  ((2023, 12, 30), (2024, 2, 29), 5)):  # 63 stored days: full-wavefront kernel
+            hol = {0: [0, 1], 2: [3]}
+            inst, D, S = _upload(c, start, end, n_emp, hol)
+            for n_moves, window in ((150, 100), (512, 100), (512, 10 ** 9), (64, 64), (65, 1), (7, 0), (300, 299), (513, 100)):
+                state = rng.integers(0, n_emp, size=S)
+                moves = _random_moves(rng, n_moves, D, n_emp, state)
+                exp = inst.neighbourhood(state, moves, window)
+                got, hard, soft = c.sched_eval(state, moves, window, want_scores=True)
+                assert (got["n_scored"], got["best_index"]) == (exp["n_scored"], exp["best_index"]), (n_moves, window)
+                if exp["best_index"] >= 0:
+                    assert (got["best_hard"], got["best_soft"]) == (exp["best_hard"], exp["best_soft"])
+                assert np.array_equal(hard, exp["hard"]) and np.array_equal(soft, exp["soft"])
+                c.sched_moves_upload(moves)
+                res = c.sched_eval_resident(state, n_moves, window)
+                assert res == {k: got[k] for k in res}
+            # batched, ragged
+            R, mm = 5, 200
+            states = rng.integers(0, n_emp, size=(R, S))
+            moves = np.stack([_random_moves(rng, mm, D, n_emp, states[r]) for r in range(R)])
+            n_moves = np.array([0, 1, 200, 63, 129])
+            out, _, _ = c.sched_eval_batch(states, moves, n_moves, 50)
+            for r in range(R):
+                exp = inst.neighbourhood(states[r], moves[r, :n_moves[r]], 50)
+                assert (out[r]["n_scored"], out[r]["best_index"]) == (exp["n_scored"], exp["best_index"])
