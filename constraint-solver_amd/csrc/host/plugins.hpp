@@ -164,8 +164,9 @@ struct NQueensProblem {
     NqBatcher *batcher = nullptr; // set when this restart is one of a lockstep batch
     // statistics
     uint64_t neighbours_scored = 0, gpu_evals = 0, gpu_col_score_calls = 0;
-    double t_prop = 0, t_gpu = 0;
-    ~NQueensProblem() { if (getenv("LS_AMD_TRACE")) fprintf(stderr, "nq: evals %llu prop %.3f s gpu %.3f s\n", (unsigned long long)gpu_evals, t_prop, t_gpu); }
+    double t_prop = 0, t_gpu = 0, t_samp = 0;
+    uint64_t n_conf = 0;
+    ~NQueensProblem() { if (getenv("LS_AMD_TRACE")) fprintf(stderr, "nq: evals %llu prop %.3f s (weighted sample %.3f s, %.1f conflict cols/iter) gpu %.3f s\n", (unsigned long long)gpu_evals, t_prop, t_samp, (double)n_conf / (gpu_evals ? gpu_evals : 1), t_gpu); }
     // column scores of the board the loop will expand next, delivered by the previous neighbourhood's
     // round trip (or by score()): saves one GPU round trip per LS iteration
     mutable Solution cached_board;
@@ -237,7 +238,10 @@ struct NQueensProblem {
         size_t amount = start.size() / 20;
         if (amount < 1) amount = 1;
         if (amount > conflict_cols.size()) amount = conflict_cols.size();
+        const auto TA = std::chrono::steady_clock::now();
+        const_cast<NQueensProblem *>(this)->n_conf += conflict_cols.size();
         const std::vector<uint32_t> picked = index_sample_weighted(rng, weights, (uint32_t)amount);
+        const_cast<NQueensProblem *>(this)->t_samp += std::chrono::duration<double>(std::chrono::steady_clock::now() - TA).count();
         std::vector<uint32_t> cols;
         for (uint32_t i : picked) cols.push_back(conflict_cols[i]);
         const uint64_t num_cols = gen_range_u64_incl(rng, 1, cols.size());

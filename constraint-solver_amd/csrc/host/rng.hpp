@@ -152,12 +152,39 @@ public:
     uint64_t words_drawn() const { return counter_ * 16 - (64 - (index_ > 64 ? 64 : index_)); }
 
 private:
+    // The four blocks of one refill in parallel, one 32-bit lane per block (compiler vector extension: SSE2/AVX on
+    // the host).  Same words as four chacha20_block calls (tests/test_host_rng.py compares the two).
     void generate_and_set(size_t idx)
     {
+        typedef uint32_t v4 __attribute__((vector_size(16)));
+        auto splat = [](uint32_t w) { return v4{w, w, w, w}; };
+        auto rotl = [](v4 v, int n) { return (v << n) | (v >> (32 - n)); };
+        v4 s[16];
+        s[0] = splat(0x61707865u); s[1] = splat(0x3320646eu); s[2] = splat(0x79622d32u); s[3] = splat(0x6b206574u);
+        for (int i = 0; i < 8; i++) s[4 + i] = splat(key_[i]);
         for (int b = 0; b < 4; b++) {
-            chacha20_block(key_, (uint32_t)counter_, (uint32_t)(counter_ >> 32), 0, 0, buf_ + 16 * b);
-            counter_++;
+            const uint64_t c = counter_ + (uint64_t)b;
+            s[12][b] = (uint32_t)c;
+            s[13][b] = (uint32_t)(c >> 32);
         }
+        s[14] = splat(0); s[15] = splat(0);
+        v4 x[16];
+        for (int i = 0; i < 16; i++) x[i] = s[i];
+#define LS_QR(a, b, c, d)                                   \
+        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);         \
+        x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);         \
+        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);          \
+        x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+        for (int r = 0; r < 10; r++) {
+            LS_QR(0, 4, 8, 12) LS_QR(1, 5, 9, 13) LS_QR(2, 6, 10, 14) LS_QR(3, 7, 11, 15)
+            LS_QR(0, 5, 10, 15) LS_QR(1, 6, 11, 12) LS_QR(2, 7, 8, 13) LS_QR(3, 4, 9, 14)
+        }
+#undef LS_QR
+        for (int i = 0; i < 16; i++) {
+            const v4 o = x[i] + s[i];
+            for (int b = 0; b < 4; b++) buf_[16 * b + i] = o[b];
+        }
+        counter_ += 4;
         index_ = idx;
     }
     uint32_t key_[8];

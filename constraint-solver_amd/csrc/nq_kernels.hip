@@ -822,53 +822,74 @@ __device__ __forceinline__ void tab16_dec(unsigned *t, int idx) { atomicSub(&t[i
 __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *results, int *next_rows,
                                                        long long *next_col_scores, long long *next_totals)
 {
-    extern __shared__ unsigned s_dyn[]; // tables (packed u16: R[n] | A[2n] | B[2n]) | rows[n] | cols[n_slots]
+    extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[]; // tables (packed u16: R[n] | A[2n] | B[2n]) | rows[n] | slot records[n_slots]
     __shared__ unsigned long long s_best[16];
     __shared__ int s_sum[16];
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
     const int r = blockIdx.x, n = a.n;
-    const int words = (5 * n + 1) >> 1;
+    const int words = (((5 * n + 1) >> 1) + 3) & ~3; // keeps the slot records 16-byte aligned
     unsigned *s_t16 = s_dyn;
     int *s_rows = reinterpret_cast<int *>(s_dyn + words);
-    int *s_cols = s_rows + n;
+    int4 *s_slot = reinterpret_cast<int4 *>(s_rows + ((n + 3) & ~3)); // {column, its row, conf(column, row), -}
     const int *__restrict__ rows = a.rows + (long long)r * n;
     const int *__restrict__ cols = a.cols + (long long)r * a.max_cols;
+    // every global (possibly PCIe) read of the kernel is issued here, back to back: one latency, not three
+    int rv[NQ_STEP_MAX_N / 1024];
+#pragma unroll
+    for (int i = 0; i < NQ_STEP_MAX_N / 1024; i++) {
+        const int j = tid + 1024 * i;
+        rv[i] = j < n ? rows[j] : -1;
+    }
+    const int cv = tid < a.max_cols ? cols[tid] : -1; // the launcher guarantees n_slots <= 1024
     int ncols = a.n_cols[r];
-    const long long cur = tid == 0 ? a.cur_scores[r] : 0; // issued with the other input loads, not on the serial path below
+    const long long cur = tid == 0 ? a.cur_scores[r] : 0;
+    for (int i = tid; i < words; i += 1024) s_t16[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NQ_STEP_MAX_N / 1024; i++) {
+        const int j = tid + 1024 * i;
+        if (j < n) s_rows[j] = rv[i];
+    }
     ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
     const long long K = nq_k_limit((long long)ncols * n, n, a.window);
     const int n_slots = (int)((K + n - 1) / n);
-    for (int i = tid; i < words; i += 1024) s_t16[i] = 0;
-    for (int j = tid; j < n; j += 1024) s_rows[j] = rows[j];
-    for (int s = tid; s < n_slots; s += 1024) s_cols[s] = cols[s];
     __syncthreads();
-    for (int j = tid; j < n; j += 1024) {
-        const int q = s_rows[j];
-        if ((unsigned)q < (unsigned)n) {
+    const int oA = n, oB = 3 * n;
+#pragma unroll
+    for (int i = 0; i < NQ_STEP_MAX_N / 1024; i++) {
+        const int j = tid + 1024 * i, q = rv[i];
+        if (j < n && (unsigned)q < (unsigned)n) {
             tab16_inc(s_t16, q);
-            tab16_inc(s_t16, n + (q - j + n));
-            tab16_inc(s_t16, 3 * n + (q + j));
+            tab16_inc(s_t16, oA + (q - j + n));
+            tab16_inc(s_t16, oB + (q + j));
         }
     }
     __syncthreads();
-    const int oA = n, oB = 3 * n;
-    unsigned long long best = NQ_KEY_EMPTY;
-    for (int slot = 0; slot < n_slots; slot++) {
-        const long long left = K - (long long)slot * n;
-        const int ve = left < n ? (int)left : n;
-        const int c = s_cols[slot];
+    if (tid < n_slots) {
+        const int c = cv;
         const int rc = (unsigned)c < (unsigned)n ? s_rows[c] : -1;
-        if ((unsigned)rc >= (unsigned)n) continue;
-        const NqRanges rg = nq_ranges(0, ve, rc, (long long)slot * (n - 1), a.window);
-        const int conf_old = tab16_get(s_t16, rc) + tab16_get(s_t16, oA + rc - c + n) + tab16_get(s_t16, oB + rc + c) - 3;
-        const unsigned long long khd = nq_key_hi(0, c, n, slot), khu = nq_key_hi(1, c, n, slot);
-        // one strided walk over [d0, u1); v == rc is the no-op, everything else in range is a candidate
-        for (int v = rg.d0 + tid; v < rg.u1; v += 1024) {
-            const bool down = v < rg.d1, up = v >= rg.u0;
-            if (down || up) {
-                const int delta = tab16_get(s_t16, v) + tab16_get(s_t16, oA + v - c + n) + tab16_get(s_t16, oB + v + c) - conf_old;
-                best = u64min(best, nq_key(delta, down ? khd : khu, v));
-            }
+        int conf_old = 0;
+        if ((unsigned)rc < (unsigned)n)
+            conf_old = tab16_get(s_t16, rc) + tab16_get(s_t16, oA + rc - c + n) + tab16_get(s_t16, oB + rc + c) - 3;
+        s_slot[tid] = make_int4(c, (unsigned)rc < (unsigned)n ? rc : -1, conf_old, 0);
+    }
+    __syncthreads();
+    // Flat walk over the unfiltered positions k = slot * n + v that take(window) can reach; iterations are
+    // independent, so the LDS look-ups of several candidates are in flight together.  k / n by an exact
+    // multiply-high (k < 2^17, n < 2^14).
+    unsigned long long best = NQ_KEY_EMPTY;
+    const unsigned magic = (unsigned)(0x100000000ull / (unsigned)n) + 1u;
+    const int kmax = (int)K;
+#pragma unroll 4
+    for (int k = tid; k < kmax; k += 1024) {
+        const int slot = (int)__umulhi((unsigned)k, magic);
+        const int v = k - slot * n;
+        const int4 si = s_slot[slot];
+        const int c = si.x, rc = si.y;
+        const bool up = v > rc;
+        const long long rank = (long long)slot * (n - 1) + v - (up ? 1 : 0); // tabu candidates do not consume window
+        if (rc >= 0 && v != rc && rank < a.window) {
+            const int delta = tab16_get(s_t16, v) + tab16_get(s_t16, oA + v - c + n) + tab16_get(s_t16, oB + v + c) - si.z;
+            best = u64min(best, nq_key(delta, nq_key_hi(up ? 1 : 0, c, n, slot), v));
         }
     }
     best = wave_min_u64(best);
@@ -1169,12 +1190,12 @@ int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long 
     static bool attr_done_dev[64] = {false};
     if (!attr_done_dev[ctx->device & 63]) {
         LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        ((5 * NQ_STEP_MAX_N + 1) / 2 + NQ_STEP_MAX_N + NQ_STEP_MAX_SLOTS) * 4));
+                                        ((5 * NQ_STEP_MAX_N + 1) / 2 + 4 + NQ_STEP_MAX_N + 4 * NQ_STEP_MAX_SLOTS) * 4));
         attr_done_dev[ctx->device & 63] = true;
     }
     long long slots = (long long)max_cols;
     if (window / (n - 1) < max_cols) slots = window / (n - 1) + 1;
-    const size_t lds = ((size_t)(5 * n + 1) / 2 + (size_t)n + (size_t)slots) * 4;
+    const size_t lds = ((((size_t)(5 * n + 1) / 2 + 3) & ~(size_t)3) + (((size_t)n + 3) & ~(size_t)3) + 4 * (size_t)slots) * 4;
     hipLaunchKernelGGL(nq_step_kernel, dim3(n_restarts), dim3(1024), lds, ctx->stream, a, results, next_rows, next_col_scores,
                        next_totals);
     LS_HIP(ctx, hipGetLastError());
