@@ -306,37 +306,51 @@ constexpr int NQ_TILE_STRIDE = 68;
 constexpr int NQ_TILE_DWORDS = 16 * NQ_TILE_STRIDE;
 
 template <bool WANT_SCORES, class Board>
-__device__ __forceinline__ void nq_scan_range_regs(const Board &bd, unsigned *tile, int vbeg, int vend, int c,
-                                                   int conf_old, unsigned long long khi, unsigned long long &best,
-                                                   long long *scores_row, long long cur, int lane)
+__device__ __forceinline__ void nq_scan_column_regs(const Board &bd, unsigned *tile, const NqRanges &rg, int rc, int c, int n,
+                                                    int slot, unsigned long long &best, long long *scores_row, long long cur,
+                                                    int lane)
 {
+    // Three segments through ONE copy of the (fully unrolled, ~8 KB) column scan: the column's own square
+    // (conf_old = conf(c, rows[c]): candidate rc in lane 0, own queen's matches dropped), then the "down" and the
+    // "up" moves.  One copy instead of three keeps the cold instruction-cache fill of a small launch short.
+    int conf_old = 0;
 #pragma unroll 1
-    for (int vb = vbeg; vb < vend; vb += 64) {
-        const int left = vend - vb;
-        const int steps = left >= 64 ? 16 : (left + 3) >> 2;
-        __builtin_amdgcn_wave_barrier(); // the previous pass's reads are program-ordered before these writes
+    for (int seg = 0; seg < 3; seg++) {
+        const int vbeg = seg == 0 ? rc : (seg == 1 ? rg.d0 : rg.u0);
+        const int vend = seg == 0 ? rc + 1 : (seg == 1 ? rg.d1 : rg.u1);
+        const unsigned long long khi = nq_key_hi(seg == 2 ? 1 : 0, c, n, slot);
+#pragma unroll 1
+        for (int vb = vbeg; vb < vend; vb += 64) {
+            const int left = vend - vb;
+            const int steps = left >= 64 ? 16 : (left + 3) >> 2;
+            __builtin_amdgcn_wave_barrier(); // the previous pass's reads are program-ordered before these writes
 #pragma unroll 1 // one copy of the (fully unrolled) column scan; unrolling this loop spills the board
-        for (int st = 0; st < steps; st++) tile[st * NQ_TILE_STRIDE + lane] = bd.lanes4(vb + 4 * st, c);
-        // The tile is private to this wavefront and LDS operations of one wavefront complete in order, so no
-        // s_barrier is needed; the fences only stop the compiler from moving the reads above other lanes' writes.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const unsigned *row = tile + (lane >> 2) * NQ_TILE_STRIDE;
-        const int sh = (lane & 3) * 8;
-        int sum = 0;
+            for (int st = 0; st < steps; st++) tile[st * NQ_TILE_STRIDE + lane] = bd.lanes4(vb + 4 * st, c);
+            // The tile is private to this wavefront and LDS operations of one wavefront complete in order, so no
+            // s_barrier is needed; the fences only stop the compiler from moving the reads above other lanes' writes.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned *row = tile + (lane >> 2) * NQ_TILE_STRIDE;
+            const int sh = (lane & 3) * 8;
+            int sum = 0;
 #pragma clang loop unroll_count(Board::READ_UNROLL) // b128 reads in flight; more would spill the register-resident board
-        for (int l4 = 0; l4 < 16; l4++) {
-            const uint4 x = *reinterpret_cast<const uint4 *>(row + 4 * l4);
-            sum += (int)((x.x >> sh) & 0xffu) + (int)((x.y >> sh) & 0xffu) + (int)((x.z >> sh) & 0xffu) +
-                   (int)((x.w >> sh) & 0xffu);
-        }
-        const int v = vb + lane;
-        if (v < vend) {
+            for (int l4 = 0; l4 < 16; l4++) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(row + 4 * l4);
+                sum += (int)((x.x >> sh) & 0xffu) + (int)((x.y >> sh) & 0xffu) + (int)((x.z >> sh) & 0xffu) +
+                       (int)((x.w >> sh) & 0xffu);
+            }
             const int cnt = Board::MISMATCH ? 64 * Board::LANE_TOTAL - sum : sum;
-            const int delta = cnt - conf_old;
-            best = u64min(best, nq_key(delta, khi, v));
-            if (WANT_SCORES) scores_row[v] = cur + 2ll * delta;
+            if (seg == 0) {
+                conf_old = __builtin_amdgcn_readfirstlane(cnt) - Board::SELF;
+            } else {
+                const int v = vb + lane;
+                if (v < vend) {
+                    const int delta = cnt - conf_old;
+                    best = u64min(best, nq_key(delta, khi, v));
+                    if (WANT_SCORES) scores_row[v] = cur + 2ll * delta;
+                }
+            }
         }
     }
 }
@@ -379,13 +393,8 @@ __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs 
                 const NqRanges rg = nq_ranges(v0, ve, rc, base, a.window);
                 if (rg.d1 > rg.d0 || rg.u1 > rg.u0) {
                     bd.prepare(c, lane);
-                    // conf(c, rows[c]): scan the own square, drop the own queen's matches
-                    const int conf_old = nq_count_first<Board>(bd.lanes4(rc, c)) - Board::SELF;
                     long long *srow = WANT_SCORES ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
-                    nq_scan_range_regs<WANT_SCORES>(bd, tile, rg.d0, rg.d1, c, conf_old, nq_key_hi(0, c, n, slot), best, srow,
-                                                    cur, lane);
-                    nq_scan_range_regs<WANT_SCORES>(bd, tile, rg.u0, rg.u1, c, conf_old, nq_key_hi(1, c, n, slot), best, srow,
-                                                    cur, lane);
+                    nq_scan_column_regs<WANT_SCORES>(bd, tile, rg, rc, c, n, slot, best, srow, cur, lane);
                 }
             }
             k += ve - v0;
