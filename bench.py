@@ -422,10 +422,7 @@ def sched_measurements(ctx, torch, dev, timed):
     ctx.sched_instance_upload(D, S, 0, E, bits)
     state_np = rng.integers(0, E, size=(1, S)).astype(np.int32)
     states = torch.from_numpy(state_np).to(dev)
-    ex = np.zeros((S * E, 3), dtype=np.int32)          # exhaustive ScheduleMoveProposer order (lib.rs:526-550)
-    for day in range(S):
-        ex[day * E:(day + 1) * E, 1] = day
-        ex[day * E:(day + 1) * E, 2] = (state_np[0, day] + 1 + np.arange(E)) % E
+    ex = ctx.sched_exhaustive_moves(state_np)[0]       # exhaustive ScheduleMoveProposer order (lib.rs:493-559), built on the device
     res = torch.zeros((1, 4), dtype=torch.int64, device=dev)
     for name, moves, window in (("sched10k_exhaustive_320k", ex, 10 ** 9),
                                 ("sched10k_random_stream_window_65536", random_moves(70_000, D, E), 65_536)):
@@ -437,6 +434,16 @@ def sched_measurements(ctx, torch, dev, timed):
         n_scored = int(res.cpu().numpy()[0, 0])
         out[name] = {"neighbours_per_s": n_scored / s, "us_per_launch": s * 1e6, "candidates_per_launch": n_scored,
                      "effective_GBps_at_144B": n_scored * 144 / s / 1e9}
+    # the same exhaustive neighbourhood through the host entry that generates the move list on the device:
+    # only the 128-byte state and the 32-byte result cross PCIe (round trip incl. sync and the Python wrapper)
+    ctx.sched_eval_exhaustive(state_np, 10 ** 9)
+    t0 = time.perf_counter()
+    reps = 100
+    for _ in range(reps):
+        r0 = ctx.sched_eval_exhaustive(state_np, 10 ** 9)[0]
+    s = (time.perf_counter() - t0) / reps
+    out["sched10k_exhaustive_320k_host_round_trip_generated_on_device"] = {
+        "neighbours_per_s": r0["n_scored"] / s, "us_per_call": s * 1e6, "candidates_per_call": r0["n_scored"]}
     return out
 
 

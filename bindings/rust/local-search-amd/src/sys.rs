@@ -66,6 +66,12 @@ extern "C" {
     pub fn ls_sched_eval(ctx: *mut ls_ctx, state: *const i32, moves: *const ls_sched_move, n_moves: i64, window: i64,
                          out: *mut ls_sched_result, hard_out: *mut i64, soft_out: *mut i64) -> c_int;
     pub fn ls_sched_moves_upload(ctx: *mut ls_ctx, moves: *const ls_sched_move, n_moves: i64) -> c_int;
+    pub fn ls_sched_exhaustive_moves(ctx: *mut ls_ctx, n_restarts: i32, states: *const i32,
+                                     moves_out: *mut ls_sched_move) -> c_int;
+    pub fn ls_sched_exhaustive_moves_dev(ctx: *mut ls_ctx, n_restarts: i32, states_d: *const i32,
+                                         moves_d: *mut ls_sched_move) -> c_int;
+    pub fn ls_sched_eval_exhaustive(ctx: *mut ls_ctx, n_restarts: i32, states: *const i32, window: i64,
+                                    results: *mut ls_sched_result) -> c_int;
     pub fn ls_sched_eval_resident(ctx: *mut ls_ctx, state: *const i32, n_moves: i64, window: i64,
                                   out: *mut ls_sched_result) -> c_int;
     pub fn ls_sched_eval_batch(ctx: *mut ls_ctx, n_restarts: i32, states: *const i32, moves: *const ls_sched_move,

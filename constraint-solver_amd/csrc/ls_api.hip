@@ -42,6 +42,7 @@ int sched_score_dev(ls_ctx *ctx, int n_states, const int *states_d, long long *h
 int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const ls_sched_move *moves_d,
                          const long long *n_moves_d, long long max_moves, long long window,
                          ls_sched_result *results_d, long long *hard_out_d, long long *soft_out_d);
+int sched_exhaustive_moves_dev(ls_ctx *ctx, int n_restarts, const int *states_d, ls_sched_move *moves_d, long long *n_moves_d);
 
 static int bind(ls_ctx *ctx)
 {
@@ -572,6 +573,61 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
     if (!zc) LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
     LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = *so.h<ls_sched_result>(0);
+    return LS_OK;
+}
+
+int ls_sched_exhaustive_moves_dev(ls_ctx *ctx, int32_t n_restarts, const int32_t *states_d, ls_sched_move *moves_d)
+{
+    LS_BIND(ctx);
+    if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
+    LS_REQUIRE(ctx, n_restarts >= 1 && states_d && moves_d, "bad arguments");
+    return sched_exhaustive_moves_dev(ctx, n_restarts, states_d, moves_d, nullptr);
+}
+
+int ls_sched_exhaustive_moves(ls_ctx *ctx, int32_t n_restarts, const int32_t *states, ls_sched_move *moves_out)
+{
+    LS_BIND(ctx);
+    if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
+    LS_REQUIRE(ctx, n_restarts >= 1 && states && moves_out, "bad arguments");
+    const int S = ctx->sched.n_days_stored;
+    int rc = sched_check_state(ctx, states, (long long)n_restarts * S);
+    if (rc != LS_OK) return rc;
+    const size_t st_b = (size_t)n_restarts * S * 4, mv_b = (size_t)n_restarts * S * ctx->sched.n_employees * sizeof(ls_sched_move);
+    LS_RESERVE(ctx, ctx->sc_states, st_b);
+    LS_RESERVE(ctx, ctx->sc_moves, mv_b);
+    LS_HIP(ctx, hipMemcpyAsync(ctx->sc_states.p, states, st_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = sched_exhaustive_moves_dev(ctx, n_restarts, ctx->sc_states.as<int>(), ctx->sc_moves.as<ls_sched_move>(), nullptr);
+    if (rc != LS_OK) return rc;
+    LS_HIP(ctx, hipMemcpyAsync(moves_out, ctx->sc_moves.p, mv_b, hipMemcpyDeviceToHost, ctx->stream));
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LS_OK;
+}
+
+int ls_sched_eval_exhaustive(ls_ctx *ctx, int32_t n_restarts, const int32_t *states, int64_t window, ls_sched_result *results)
+{
+    LS_BIND(ctx);
+    if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
+    LS_REQUIRE(ctx, n_restarts >= 1 && states && results && window >= 0, "bad arguments");
+    const int S = ctx->sched.n_days_stored;
+    int rc = sched_check_state(ctx, states, (long long)n_restarts * S);
+    if (rc != LS_OK) return rc;
+    const long long per = (long long)S * ctx->sched.n_employees;
+    const size_t st_b = (size_t)n_restarts * S * 4, mv_b = (size_t)n_restarts * per * sizeof(ls_sched_move),
+                 nm_b = (size_t)n_restarts * 8, res_b = (size_t)n_restarts * sizeof(ls_sched_result);
+    LS_RESERVE(ctx, ctx->sc_states, st_b);
+    LS_RESERVE(ctx, ctx->sc_moves, mv_b);
+    LS_RESERVE(ctx, ctx->sc_nmoves, nm_b);
+    LS_RESERVE(ctx, ctx->sc_results, res_b);
+    LS_HIP(ctx, hipMemcpyAsync(ctx->sc_states.p, states, st_b, hipMemcpyHostToDevice, ctx->stream));
+    // the move list is generated on the device from the state: nothing but the states crosses PCIe
+    rc = sched_exhaustive_moves_dev(ctx, n_restarts, ctx->sc_states.as<int>(), ctx->sc_moves.as<ls_sched_move>(),
+                                    ctx->sc_nmoves.as<long long>());
+    if (rc != LS_OK) return rc;
+    rc = sched_eval_batch_dev(ctx, n_restarts, ctx->sc_states.as<int>(), ctx->sc_moves.as<ls_sched_move>(),
+                              ctx->sc_nmoves.as<long long>(), per, window, ctx->sc_results.as<ls_sched_result>(), nullptr, nullptr);
+    if (rc != LS_OK) return rc;
+    LS_HIP(ctx, hipMemcpyAsync(results, ctx->sc_results.p, res_b, hipMemcpyDeviceToHost, ctx->stream));
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LS_OK;
 }
 

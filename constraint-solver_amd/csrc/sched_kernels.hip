@@ -781,6 +781,26 @@ __global__ __launch_bounds__(256) void sched_reduce_kernel(SchedEvalArgs a)
     }
 }
 
+// ScheduleMoveProposer::iter_local_moves (examples/employee-scheduling/src/lib.rs:493-559) as a move list: for every
+// STORED day d, ChangeDay(d, e) for e = next(cur), next(next(cur)), ... in id order with wrap-around, the day's
+// current employee last (:541-543; a no-op the tabu filter drops).  Employees are the indices 0..E-1 (sorted ids,
+// BTreeSet :83), so next(e) = (e + 1) mod E.   moves[r][d * E + i] = ChangeDay(d, (state[r][d] + 1 + i) mod E).
+__global__ __launch_bounds__(256) void sched_exhaustive_moves_kernel(const int *states, int S, int E, int n_restarts,
+                                                                     ls_sched_move *moves, long long *n_moves)
+{
+    const long long per = (long long)S * E, total = per * n_restarts;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int r = (int)(t / per);
+        const long long k = t - (long long)r * per;
+        const int d = (int)(k / E), i = (int)(k - (long long)d * E);
+        const int cur = states[(long long)r * S + d];
+        ls_sched_move m;
+        m.type = 0; m.a = d; m.b = (int)(((long long)cur + 1 + i) % E);
+        moves[t] = m;
+        if (k == 0 && n_moves) n_moves[r] = per;
+    }
+}
+
 // ------------------------------------------------------------------ launchers
 static SchedInst make_inst(const ls_ctx *ctx)
 {
@@ -802,6 +822,19 @@ int sched_score_dev(ls_ctx *ctx, int n_states, const int *states_d, long long *h
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(sched_score_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, make_inst(ctx),
                        n_states, states_d, hard_d, soft_d, terms_d);
+    LS_HIP(ctx, hipGetLastError());
+    return LS_OK;
+}
+
+int sched_exhaustive_moves_dev(ls_ctx *ctx, int n_restarts, const int *states_d, ls_sched_move *moves_d, long long *n_moves_d)
+{
+    const long long total = (long long)n_restarts * ctx->sched.n_days_stored * ctx->sched.n_employees;
+    long long g = (total + 255) / 256;
+    const long long cap = (long long)ctx->n_cus * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(sched_exhaustive_moves_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, states_d,
+                       ctx->sched.n_days_stored, ctx->sched.n_employees, n_restarts, moves_d, n_moves_d);
     LS_HIP(ctx, hipGetLastError());
     return LS_OK;
 }

@@ -203,6 +203,27 @@ class Context:
         mv = _c(moves, np.int32).reshape(-1, 3)
         self._check(self._l.ls_sched_moves_upload(self._h, _vp(mv), len(mv)))
 
+    def sched_exhaustive_moves(self, states):
+        """ScheduleMoveProposer order (lib.rs:493-559) for states [R, S] -> moves [R, S * E, 3] (type, a, b)."""
+        st = _c(states, np.int32)
+        if st.ndim == 1:
+            st = st.reshape(1, -1)
+        R, S = st.shape
+        E = self._sched_dims[2]
+        mv = np.empty((R, S * E, 3), dtype=np.int32)
+        self._check(self._l.ls_sched_exhaustive_moves(self._h, R, _vp(st), _vp(mv)))
+        return mv
+
+    def sched_eval_exhaustive(self, states, window):
+        """Exhaustive neighbourhood of every state, generated and scored on the device."""
+        st = _c(states, np.int32)
+        if st.ndim == 1:
+            st = st.reshape(1, -1)
+        R = st.shape[0]
+        res = (SchedResult * R)()
+        self._check(self._l.ls_sched_eval_exhaustive(self._h, R, _vp(st), int(window), C.cast(res, C.c_void_p)))
+        return [dict(n_scored=r.n_scored, best_index=r.best_index, best_hard=r.best_hard, best_soft=r.best_soft) for r in res]
+
     def sched_eval_resident(self, state, n_moves, window):
         st = _c(state, np.int32)
         res = SchedResult()

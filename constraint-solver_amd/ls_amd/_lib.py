@@ -79,6 +79,9 @@ SIGNATURES = {
     "ls_sched_score": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "ls_sched_eval": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "ls_sched_moves_upload": (C.c_int, [_vp, _vp, _i64]),
+    "ls_sched_exhaustive_moves": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "ls_sched_exhaustive_moves_dev": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "ls_sched_eval_exhaustive": (C.c_int, [_vp, _i32, _vp, _i64, _vp]),
     "ls_sched_eval_resident": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "ls_sched_eval_batch": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "ls_sched_eval_batch_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),

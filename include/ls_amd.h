@@ -227,6 +227,21 @@ int ls_sched_eval(ls_ctx *ctx, const int32_t *state, const ls_sched_move *moves,
  * ls_sched_moves_upload replaces the context's resident list; ls_sched_eval_resident evaluates its
  * first n_moves entries against `state` exactly like ls_sched_eval. */
 int ls_sched_moves_upload(ls_ctx *ctx, const ls_sched_move *moves, int64_t n_moves);
+
+/* ScheduleMoveProposer::iter_local_moves (examples/employee-scheduling/src/lib.rs:493-559), the exhaustive
+ * proposer (constructed nowhere in the reference, :59), as a move list in its order: for every STORED day d
+ * (:530), ChangeDay(d, e) for e = next(current), next(next(current)), ... in id order with wrap-around
+ * (next_employees, :499-508), the day's current employee last (:541-543: a no-op, dropped by the tabu filter).
+ * moves: [n_restarts][n_days_stored * n_employees], generated on the device from the states.
+ *   ls_sched_exhaustive_moves      host states in, host moves out (synchronous)
+ *   ls_sched_exhaustive_moves_dev  device pointers, asynchronous on the context's stream
+ *   ls_sched_eval_exhaustive       lines :315-325 over that neighbourhood: generate + score + argmin on the device,
+ *                                  only the states (in) and the result records (out) cross the boundary;
+ *                                  best_index is the position in the list above */
+int ls_sched_exhaustive_moves(ls_ctx *ctx, int32_t n_restarts, const int32_t *states, ls_sched_move *moves_out);
+int ls_sched_exhaustive_moves_dev(ls_ctx *ctx, int32_t n_restarts, const int32_t *states_d, ls_sched_move *moves_d);
+int ls_sched_eval_exhaustive(ls_ctx *ctx, int32_t n_restarts, const int32_t *states, int64_t window,
+                             ls_sched_result *results);
 int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, int64_t window, ls_sched_result *out);
 
 /* Batched over restarts: states[n_restarts][n_days_stored],

@@ -46,11 +46,18 @@ def test_raw_calls_return_codes_not_crashes():
     st = np.zeros(32, dtype=np.int32)
     assert lib.ls_sched_eval_resident(hh, _vp(st), 0, 10, C.byref(sres)) == _lib.LS_ERR_STATE
     assert lib.ls_sched_moves_upload(hh, None, 0) == _lib.LS_ERR_STATE
+    assert lib.ls_sched_eval_exhaustive(hh, 1, _vp(st), 10, C.byref(sres)) == _lib.LS_ERR_STATE
+    assert lib.ls_sched_exhaustive_moves(hh, 1, _vp(st), _vp(np.zeros(32 * 7 * 3, np.int32))) == _lib.LS_ERR_STATE
     assert lib.ls_sched_instance_upload(hh, 31, 32, 9, 7, _vp(np.zeros(7, np.uint64))) == _lib.LS_ERR_INVALID   # weekday 9
     assert lib.ls_sched_instance_upload(hh, 31, 30, 0, 7, _vp(np.zeros(7, np.uint64))) == _lib.LS_ERR_INVALID   # stored < scored
     assert lib.ls_sched_instance_upload(hh, 31, 32, 0, 7, None) == _lib.LS_ERR_INVALID
     assert lib.ls_sched_instance_upload(hh, 31, 32, 0, 7, _vp(np.zeros(7, np.uint64))) == _lib.LS_OK
     assert lib.ls_sched_eval(hh, _vp(st), None, 5, 10, C.byref(sres), None, None) == _lib.LS_ERR_INVALID
+    assert lib.ls_sched_eval_exhaustive(hh, 1, None, 10, C.byref(sres)) == _lib.LS_ERR_INVALID
+    assert lib.ls_sched_eval_exhaustive(hh, 1, _vp(st), -1, C.byref(sres)) == _lib.LS_ERR_INVALID
+    assert lib.ls_sched_eval_exhaustive(hh, 0, _vp(st), 10, C.byref(sres)) == _lib.LS_ERR_INVALID
+    assert lib.ls_sched_exhaustive_moves(hh, 1, _vp(st), None) == _lib.LS_ERR_INVALID
+    assert lib.ls_sched_eval_exhaustive(hh, 1, _vp(np.full(32, 7, np.int32)), 10, C.byref(sres)) == _lib.LS_ERR_INVALID  # employee 7 of 0..6
     assert lib.ls_sched_eval(hh, _vp(st), None, 0, 10, C.byref(sres), None, None) == _lib.LS_OK       # empty move list is fine
     assert sres.n_scored == 0 and sres.best_index == -1
     assert lib.ls_sched_eval_resident(hh, _vp(st), 5, 10, C.byref(sres)) == _lib.LS_ERR_INVALID       # nothing resident yet

@@ -220,3 +220,29 @@ def test_small_launch_fused_kernel(monkeypatch, fused, zero_copy):
             for r in range(R):
                 exp = inst.neighbourhood(states[r], moves[r, :n_moves[r]], 50)
                 assert (out[r]["n_scored"], out[r]["best_index"]) == (exp["n_scored"], exp["best_index"])
+
+
+def test_exhaustive_proposer_entries(ctx):
+    # ScheduleMoveProposer (lib.rs:493-559) generated on the device: same list as the oracle's restatement,
+    # and the generate + score + argmin entry agrees with evaluating that list
+    rng = np.random.default_rng(91)
+    for start, end, n_emp, hol in (((2022, 5, 9), (2022, 6, 8), 7, {0: [0, 1], 3: [3]}),
+                                   ((2022, 5, 9), (2022, 6, 8), 1, {}),           # one employee: every move is a no-op
+                                   ((2024, 1, 3), (2024, 1, 10), 40, {1: [4]}),
+                                   ((2023, 12, 30), (2024, 2, 29), 300, {})):
+        inst, D, S = _upload(ctx, start, end, n_emp, hol)
+        R = 3
+        states = rng.integers(0, n_emp, size=(R, S))
+        mv = ctx.sched_exhaustive_moves(states)
+        assert mv.shape == (R, S * n_emp, 3)
+        for window in (10 ** 9, 37, 0):
+            got = ctx.sched_eval_exhaustive(states, window)
+            for r in range(R):
+                exp_moves = orc.Sched.exhaustive_moves(states[r], range(n_emp))
+                assert np.array_equal(mv[r], exp_moves)
+                exp = inst.neighbourhood(states[r], exp_moves, window)
+                assert (got[r]["n_scored"], got[r]["best_index"]) == (exp["n_scored"], exp["best_index"]), (n_emp, window, r)
+                if exp["best_index"] >= 0:
+                    assert (got[r]["best_hard"], got[r]["best_soft"]) == (exp["best_hard"], exp["best_soft"])
+                if window == 10 ** 9:
+                    assert exp["n_scored"] == S * (n_emp - 1)

@@ -80,13 +80,7 @@ def main():
         ctx.sched_instance_upload(D, S, 0, E, bits)
         state = rng.integers(0, E, size=S)
         # (a) exhaustive ScheduleMoveProposer order: 32 x 10 000 candidates (32 of them no-ops)
-        moves = np.zeros((S * E, 3), dtype=np.int32)
-        k = 0
-        for day in range(S):
-            ring = (state[day] + 1 + np.arange(E)) % E
-            moves[k:k + E, 1] = day
-            moves[k:k + E, 2] = ring
-            k += E
+        moves = ctx.sched_exhaustive_moves(state)[0]                # generated on the device (lib.rs:493-559 order)
         for name, mv, window in (("exhaustive_320k", moves, 10 ** 9),):
             ctx.sched_eval(state, mv, window)                       # warm-up (allocations)
             t0 = time.perf_counter()
@@ -97,6 +91,17 @@ def main():
             out[f"sched10k_{name}_host_api"] = dict(n_scored=res["n_scored"], ms_per_call=dt * 1e3,
                                                    neighbours_per_s=res["n_scored"] / dt,
                                                    note="host-pointer entry: includes the 3.8 MB move upload per call")
+        # (b) the same neighbourhood generated on the device: only the state and the result cross PCIe
+        ref = ctx.sched_eval(state, moves, 10 ** 9)[0]
+        got = ctx.sched_eval_exhaustive(state, 10 ** 9)[0]
+        assert got == ref, (got, ref)
+        t0 = time.perf_counter()
+        reps = 50
+        for _ in range(reps):
+            ctx.sched_eval_exhaustive(state, 10 ** 9)
+        dt = (time.perf_counter() - t0) / reps
+        out["sched10k_exhaustive_320k_generated_on_device"] = dict(n_scored=got["n_scored"], us_per_call=dt * 1e6,
+                                                                   neighbours_per_s=got["n_scored"] / dt)
     print(json.dumps(out, indent=1))
 
 
