@@ -80,10 +80,15 @@ public:
         cv_.notify_all();
     }
     uint64_t launches = 0;
+    double t_flush = 0, t_call = 0;
+    uint64_t n_flush = 0, sum_R = 0;
+    ~NqBatcher() { if (getenv("LS_AMD_TRACE")) fprintf(stderr, "batcher: %llu flushes %.3f s (ABI calls %.3f s), mean restarts per launch %.2f\n", (unsigned long long)n_flush, t_flush, t_call, (double)sum_R / (launches ? launches : 1)); }
 
 private:
     void flush_locked()
     {
+        const auto TF0 = std::chrono::steady_clock::now();
+        struct Tm { NqBatcher *b; std::chrono::steady_clock::time_point t0; ~Tm() { b->t_flush += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); b->n_flush++; } } tm{this, TF0};
         try {
             if (!error_.empty()) throw std::runtime_error(error_); // a restart failed: release everyone
             std::vector<NqRequest *> cs, ev;
@@ -120,10 +125,13 @@ private:
                     cur_[i] = ev[i]->cur_score;
                     if (ev[i]->window != ev[0]->window) throw std::runtime_error("restarts of one batch must share the window size");
                 }
+                const auto TC0 = std::chrono::steady_clock::now();
                 check_rc(ctx_, ls_nqueens_eval_batch_next(ctx_, (int32_t)R, n_, rows_.data(), cur_.data(), cols_.data(),
                                                           ncols_.data(), max_cols, ev[0]->window, results_.data(),
                                                           colscores_.data()),
                          "ls_nqueens_eval_batch_next");
+                t_call += std::chrono::duration<double>(std::chrono::steady_clock::now() - TC0).count();
+                sum_R += R;
                 launches++;
                 for (size_t i = 0; i < R; i++) {
                     *ev[i]->result_out = results_[i];

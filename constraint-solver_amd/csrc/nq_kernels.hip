@@ -289,13 +289,6 @@ struct BoardF32 {
     }
 };
 
-// Attack count of one square from the per-lane packed counts (used once per column, for conf_old).
-template <class Board> __device__ __forceinline__ int nq_count_first(unsigned packed)
-{
-    const int s = wave_sum_i32((int)(packed & 0xffu));
-    return Board::MISMATCH ? 64 * Board::LANE_TOTAL - s : s;
-}
-
 // 64 candidates per pass.  Sixteen steps of four candidates each leave per-lane counts (one byte
 // per candidate) in a wave-private LDS tile, row = step, column = lane; then lane q OWNS candidate q:
 // it sums byte (q & 3) of row (q >> 2) over the 64 lanes, forms delta and key, and keeps its own
