@@ -66,6 +66,16 @@ __device__ __forceinline__ unsigned long long nq_key(int delta, unsigned long lo
     return ((unsigned long long)(unsigned)(delta + NQ_DELTA_BIAS) << 46) | hi | ((unsigned long long)(unsigned)v << 15);
 }
 
+// Within one (column, direction) range only delta and v vary: a 32-bit running minimum of
+// (delta + 2^16) << 15 | v  (|delta| <= n + 2 <= 32770, v < 2^15) orders exactly like the full key and is
+// widened once per range instead of once per candidate.
+constexpr unsigned NQ_KEY32_EMPTY = 0xffffffffu;
+__device__ __forceinline__ unsigned nq_key32(int delta, int v) { return ((unsigned)(delta + 65536) << 15) | (unsigned)v; }
+__device__ __forceinline__ unsigned long long nq_key_from32(unsigned k32, unsigned long long hi)
+{
+    return nq_key((int)(k32 >> 15) - 65536, hi, (int)(k32 & 0x7fffu));
+}
+
 // Unfiltered positions [0, nq_k_limit) are the only ones take(window) can reach: each column
 // holds n - 1 real candidates and one no-op.
 __device__ __forceinline__ long long nq_k_limit(long long K, int n, long long window)
@@ -581,16 +591,21 @@ __global__ __launch_bounds__(256) void nq_table_eval_kernel(NqArgs a)
                 long long *srow =
                     a.scores_out ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
                 const unsigned long long khd = nq_key_hi(0, c, n, slot), khu = nq_key_hi(1, c, n, slot);
+                unsigned md = NQ_KEY32_EMPTY, mu = NQ_KEY32_EMPTY;
                 for (int v = rg.d0 + (int)threadIdx.x; v < rg.d1; v += 256) {
                     const int delta = tR[v] + tA[v - c + n] + tB[v + c] - conf_old;
-                    best = u64min(best, nq_key(delta, khd, v));
+                    const unsigned k32 = nq_key32(delta, v);
+                    md = k32 < md ? k32 : md;
                     if (srow) srow[v] = cur + 2ll * delta;
                 }
                 for (int v = rg.u0 + (int)threadIdx.x; v < rg.u1; v += 256) {
                     const int delta = tR[v] + tA[v - c + n] + tB[v + c] - conf_old;
-                    best = u64min(best, nq_key(delta, khu, v));
+                    const unsigned k32 = nq_key32(delta, v);
+                    mu = k32 < mu ? k32 : mu;
                     if (srow) srow[v] = cur + 2ll * delta;
                 }
+                if (md != NQ_KEY32_EMPTY) best = u64min(best, nq_key_from32(md, khd));
+                if (mu != NQ_KEY32_EMPTY) best = u64min(best, nq_key_from32(mu, khu));
             }
             k += ve - v0;
             slot++;
@@ -666,16 +681,21 @@ __global__ __launch_bounds__(256) void nq_table_lds_kernel(NqArgs a)
                 long long *srow =
                     a.scores_out ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
                 const unsigned long long khd = nq_key_hi(0, c, n, slot), khu = nq_key_hi(1, c, n, slot);
+                unsigned md = NQ_KEY32_EMPTY, mu = NQ_KEY32_EMPTY;
                 for (int v = rg.d0 + (int)threadIdx.x; v < rg.d1; v += 256) {
                     const int delta = tab16_get(s_t16, v) + tab16_get(s_t16, oA + v - c + n) + tab16_get(s_t16, oB + v + c) - conf_old;
-                    best = u64min(best, nq_key(delta, khd, v));
+                    const unsigned k32 = nq_key32(delta, v);
+                    md = k32 < md ? k32 : md;
                     if (srow) srow[v] = cur + 2ll * delta;
                 }
                 for (int v = rg.u0 + (int)threadIdx.x; v < rg.u1; v += 256) {
                     const int delta = tab16_get(s_t16, v) + tab16_get(s_t16, oA + v - c + n) + tab16_get(s_t16, oB + v + c) - conf_old;
-                    best = u64min(best, nq_key(delta, khu, v));
+                    const unsigned k32 = nq_key32(delta, v);
+                    mu = k32 < mu ? k32 : mu;
                     if (srow) srow[v] = cur + 2ll * delta;
                 }
+                if (md != NQ_KEY32_EMPTY) best = u64min(best, nq_key_from32(md, khd));
+                if (mu != NQ_KEY32_EMPTY) best = u64min(best, nq_key_from32(mu, khu));
             }
             k += ve - v0;
             slot++;
