@@ -313,15 +313,22 @@ __device__ __forceinline__ void nq_scan_column_regs(const Board &bd, unsigned *t
                                                     int slot, unsigned long long &best, long long *scores_row, long long cur,
                                                     int lane)
 {
-    // Three segments through ONE copy of the (fully unrolled, ~8 KB) column scan: the column's own square
-    // (conf_old = conf(c, rows[c]): candidate rc in lane 0, own queen's matches dropped), then the "down" and the
-    // "up" moves.  One copy instead of three keeps the cold instruction-cache fill of a small launch short.
-    int conf_old = 0;
+    // ONE range [lo, hi) per column through ONE copy of the (fully unrolled, ~8 KB) column scan: the "down" moves, the
+    // column's own square and the "up" moves in a single sequence of 64-candidate passes.  The own square is not a
+    // candidate (tabu) but its count is conf_old + SELF, so when it lies inside the range it costs nothing extra;
+    // otherwise (the range was cut by the window or by the wavefront's share) a one-step pass fetches it first.
+    // Inside the column only the count and v vary, so each lane keeps two 32-bit minima of (count << 15 | v)
+    // (down / up) and widens them to 64-bit keys once, when conf_old is known.
+    const int lo = rg.d1 > rg.d0 ? rg.d0 : rg.u0;
+    const int hi = rg.u1 > rg.u0 ? rg.u1 : rg.d1;
+    const bool own_inside = rc >= lo && rc < hi;
+    const bool conf_first = WANT_SCORES || !own_inside; // the parity-mode score store needs conf_old up front
+    int conf_old = 0, own_cnt = 0;
+    unsigned md = NQ_KEY32_EMPTY, mu = NQ_KEY32_EMPTY;
 #pragma unroll 1
-    for (int seg = 0; seg < 3; seg++) {
-        const int vbeg = seg == 0 ? rc : (seg == 1 ? rg.d0 : rg.u0);
-        const int vend = seg == 0 ? rc + 1 : (seg == 1 ? rg.d1 : rg.u1);
-        const unsigned long long khi = nq_key_hi(seg == 2 ? 1 : 0, c, n, slot);
+    for (int seg = conf_first ? 0 : 1; seg < 2; seg++) {
+        const int vbeg = seg == 0 ? rc : lo;
+        const int vend = seg == 0 ? rc + 1 : hi;
 #pragma unroll 1
         for (int vb = vbeg; vb < vend; vb += 64) {
             const int left = vend - vb;
@@ -348,14 +355,19 @@ __device__ __forceinline__ void nq_scan_column_regs(const Board &bd, unsigned *t
                 conf_old = __builtin_amdgcn_readfirstlane(cnt) - Board::SELF;
             } else {
                 const int v = vb + lane;
-                if (v < vend) {
-                    const int delta = cnt - conf_old;
-                    best = u64min(best, nq_key(delta, khi, v));
-                    if (WANT_SCORES) scores_row[v] = cur + 2ll * delta;
-                }
+                const unsigned k32 = ((unsigned)cnt << 15) | (unsigned)v;
+                if (v < rg.d1) md = k32 < md ? k32 : md;                    // v in [d0, d1): lo == d0 whenever this is non-empty
+                else if (v >= rg.u0 && v < rg.u1) mu = k32 < mu ? k32 : mu;
+                else if (v == rc) own_cnt = cnt;
+                if (WANT_SCORES && (v < rg.d1 || (v >= rg.u0 && v < rg.u1))) scores_row[v] = cur + 2ll * (cnt - conf_old);
             }
         }
     }
+    if (!conf_first) conf_old = __builtin_amdgcn_readlane(own_cnt, (rc - lo) & 63) - Board::SELF;
+    if (md != NQ_KEY32_EMPTY)
+        best = u64min(best, nq_key((int)(md >> 15) - conf_old, nq_key_hi(0, c, n, slot), (int)(md & 0x7fffu)));
+    if (mu != NQ_KEY32_EMPTY)
+        best = u64min(best, nq_key((int)(mu >> 15) - conf_old, nq_key_hi(1, c, n, slot), (int)(mu & 0x7fffu)));
 }
 
 template <class Board, bool WANT_SCORES>
