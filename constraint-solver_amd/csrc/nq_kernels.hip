@@ -445,15 +445,23 @@ __device__ __forceinline__ void nq_count4_lds(const float *sR, int n_pad, int la
 {
     const float f0 = (float)v, f1 = (float)(v + 1), f2 = (float)(v + 2), f3 = (float)(v + 3);
     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
-    float jc = (float)(lane - c); // j - c for this lane's column of the current visit
-    for (int j = lane; j < n_pad; j += 64) {
-        const float r = sR[j];
+    // one ds_read_b128 per visit: the lane owns four CONSECUTIVE columns 4*lane + 256*i .. +3
+    float jc0 = (float)(4 * lane - c), jc1 = jc0 + 1.0f, jc2 = jc0 + 2.0f, jc3 = jc0 + 3.0f; // j - c per owned column
+    const float4 *p4 = reinterpret_cast<const float4 *>(sR) + lane;
+    const int visits8 = n_pad >> 9; // wave-uniform trip count, two b128 reads in flight per trip (n_pad % 512 == 0)
+    for (int i = 0; i < visits8; i++) {
+        const float4 r = p4[128 * i], t = p4[128 * i + 64];
         float d0, d1, d2, d3, u0, u1, u2, u3;
-        asm(LS_F32_LDS_STEP
-            : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(u0), "=&v"(u1),
-              "=&v"(u2), "=&v"(u3)
-            : "v"(r), "v"(jc), "v"(f0), "v"(f1), "v"(f2), "v"(f3));
-        jc += 64.0f;
+#define LS_LDS_COL(R, JC)                                                                                             \
+        asm(LS_F32_LDS_STEP                                                                                           \
+            : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(u0), "=&v"(u1), \
+              "=&v"(u2), "=&v"(u3)                                                                                    \
+            : "v"(R), "v"(JC), "v"(f0), "v"(f1), "v"(f2), "v"(f3));
+        LS_LDS_COL(r.x, jc0) LS_LDS_COL(r.y, jc1) LS_LDS_COL(r.z, jc2) LS_LDS_COL(r.w, jc3)
+        jc0 += 256.0f; jc1 += 256.0f; jc2 += 256.0f; jc3 += 256.0f;
+        LS_LDS_COL(t.x, jc0) LS_LDS_COL(t.y, jc1) LS_LDS_COL(t.z, jc2) LS_LDS_COL(t.w, jc3)
+        jc0 += 256.0f; jc1 += 256.0f; jc2 += 256.0f; jc3 += 256.0f;
+#undef LS_LDS_COL
     }
     // per-lane mismatches <= n_pad/64 <= 512; wave totals of matches <= n + 2 < 2^16: two per register
     const int visits = n_pad >> 6;
@@ -486,7 +494,7 @@ constexpr int NQ_LDS_BLOCK = 1024;
 
 __global__ __launch_bounds__(NQ_LDS_BLOCK) void nq_scan_lds_kernel(NqArgs a)
 {
-    extern __shared__ float s_dynf[]; // [n_pad] state as floats, then 16 x u64 best (8-byte aligned: n_pad % 64 == 0)
+    extern __shared__ __attribute__((aligned(16))) float s_dynf[]; // [n_pad] state as floats, then 16 x u64 best (n_pad % 512 == 0)
     constexpr int WPB = NQ_LDS_BLOCK / 64;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(NQ_LDS_BLOCK) void nq_scan_lds_kernel(NqArgs a)
     const int wchunk = (blockIdx.x / a.n_restarts) * WPB + wib;
     const int n_wchunks = (gridDim.x / a.n_restarts) * WPB;
     const int n = a.n;
-    const int n_pad = (n + 63) & ~63;
+    const int n_pad = (n + 511) & ~511;
     float *sR = s_dynf;
     unsigned long long *s_best = reinterpret_cast<unsigned long long *>(s_dynf + n_pad);
     const int *__restrict__ rows = a.rows + (long long)restart * n;
@@ -1053,7 +1061,7 @@ static int launch_scan(ls_ctx *ctx, const NqArgs &a, long long k_max)
     const int variant = ctx->nq_scan_variant;
     if (n <= 4096 && variant != 1) return launch_scan_f32(ctx, a, bpr_cap);
     if (n <= 8192 && variant == 1) return launch_scan_pk16(ctx, a, bpr_cap);
-    const int n_pad = (n + 63) & ~63;
+    const int n_pad = (n + 511) & ~511;
     const size_t lds = (size_t)n_pad * 4 + 16 * 8;
     LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_scan_lds_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
