@@ -271,6 +271,9 @@ def main():
                             f"uniform-random boards seeded by restart id, algo={args.algo}",
                 "n": n, "restarts_per_gpu": R, "neighbours_per_step_per_gpu": neighbours_per_step,
                 "algo": args.algo, "device": info["name"], "n_cus": info["n_cus"],
+                "algo_note": "scan = the reference's O(n) pair checks per candidate, the kernel the metric and SURVEY 8(d)'s byte "
+                             "accounting are defined on; the library default (auto) resolves to the count-table family, "
+                             "reported under extra.table_*",
                 "arithmetic": "state int32, scores int64; the scan kernel tests attacks with exact integer-valued fp32 "
                               "arithmetic (|values| < 2^24), see DESIGN.md 3.1",
             },
