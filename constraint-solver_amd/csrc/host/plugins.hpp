@@ -203,7 +203,8 @@ struct NQueensProblem {
     }
 
     // get_col_scores (lib.rs:74-87) on the GPU; also returns the sum (lib.rs:130-139)
-    std::vector<int64_t> col_scores(const Solution &s, int64_t *total) const
+    // (returns a reference to the cache: valid until the next call)
+    const std::vector<int64_t> &col_scores(const Solution &s, int64_t *total) const
     {
         if (cache_valid && s == cached_board) {
             if (total) *total = cached_total;
@@ -221,8 +222,8 @@ struct NQueensProblem {
         } else
             check_rc(ctx, ls_nqueens_col_scores(ctx, 1, (int32_t)s.size(), rows.data(), cs.data(), &tot), "ls_nqueens_col_scores");
         if (total) *total = tot;
-        cached_board = s; cached_cs = cs; cached_total = tot; cache_valid = true;
-        return cs;
+        cached_board = s; cached_cs.swap(cs); cached_total = tot; cache_valid = true;
+        return cached_cs;
     }
     Score score(const Solution &s) const
     {
@@ -236,7 +237,7 @@ struct NQueensProblem {
     // number of them in choose_multiple order.  Empty result <=> `random_cols == None`.
     template <class R> std::vector<int32_t> propose_columns(const Solution &start, R &rng) const
     {
-        const std::vector<int64_t> cs = col_scores(start, nullptr);
+        const std::vector<int64_t> &cs = col_scores(start, nullptr);
         std::vector<uint32_t> conflict_cols;
         std::vector<double> weights;
         for (size_t c = 0; c < cs.size(); c++)

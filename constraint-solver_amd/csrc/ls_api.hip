@@ -195,6 +195,15 @@ static int nq_check_dims(ls_ctx *ctx, int32_t n_restarts, int32_t n, int32_t max
     return LS_OK;
 }
 
+// Range check of a large int32 array on the per-iteration path: one branch-free (vectorisable) pass for the common
+// all-valid case; the element-by-element walk that names the offender only runs when it found something.
+static bool all_in_range(const int32_t *p, long long count, int32_t hi_excl)
+{
+    uint32_t worst = 0; // (uint32_t)x < hi_excl  <=>  0 <= x < hi_excl
+    for (long long i = 0; i < count; i++) worst = (uint32_t)p[i] > worst ? (uint32_t)p[i] : worst;
+    return count == 0 || worst < (uint32_t)hi_excl;
+}
+
 static long long nq_clamp_window(int64_t window, int32_t max_cols, int32_t n)
 {
     const long long cap = (long long)max_cols * n + 1;
@@ -226,8 +235,9 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
     int rc = nq_check_dims(ctx, n_restarts, n, max_cols, window);
     if (rc != LS_OK) return rc;
     LS_REQUIRE(ctx, rows && cur_scores && n_cols && results && (cols || max_cols == 0), "null pointer");
-    for (long long i = 0; i < (long long)n_restarts * n; i++)
-        LS_REQUIRE(ctx, rows[i] >= 0 && rows[i] < n, "rows[%lld] = %d outside [0, %d)", i, rows[i], n);
+    if (!all_in_range(rows, (long long)n_restarts * n, n))
+        for (long long i = 0; i < (long long)n_restarts * n; i++)
+            LS_REQUIRE(ctx, rows[i] >= 0 && rows[i] < n, "rows[%lld] = %d outside [0, %d)", i, rows[i], n);
     for (int r = 0; r < n_restarts; r++) {
         LS_REQUIRE(ctx, n_cols[r] >= 0 && n_cols[r] <= max_cols, "n_cols[%d] = %d outside [0, max_cols = %d]", r,
                    n_cols[r], max_cols);
@@ -352,8 +362,9 @@ int ls_nqueens_col_scores(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int3
     int rc = nq_check_dims(ctx, n_restarts, n, 0, 0);
     if (rc != LS_OK) return rc;
     LS_REQUIRE(ctx, rows != nullptr, "null pointer");
-    for (long long i = 0; i < (long long)n_restarts * n; i++)
-        LS_REQUIRE(ctx, rows[i] >= 0 && rows[i] < n, "rows[%lld] = %d outside [0, %d)", i, rows[i], n);
+    if (!all_in_range(rows, (long long)n_restarts * n, n))
+        for (long long i = 0; i < (long long)n_restarts * n; i++)
+            LS_REQUIRE(ctx, rows[i] >= 0 && rows[i] < n, "rows[%lld] = %d outside [0, %d)", i, rows[i], n);
     const size_t rows_b = (size_t)n_restarts * n * 4, cs_b = (size_t)n_restarts * n * 8, t_b = (size_t)n_restarts * 8;
     LS_RESERVE(ctx, ctx->nq_rows, rows_b);
     LS_RESERVE(ctx, ctx->nq_colscores, cs_b);
@@ -409,6 +420,7 @@ int ls_sched_instance_upload(ls_ctx *ctx, int32_t n_days_scored, int32_t n_days_
 
 static int sched_check_state(ls_ctx *ctx, const int32_t *states, long long count)
 {
+    if (all_in_range(states, count, ctx->sched.n_employees)) return LS_OK;
     for (long long i = 0; i < count; i++)
         LS_REQUIRE(ctx, states[i] >= 0 && states[i] < ctx->sched.n_employees,
                    "state entry %lld = %d is not an employee index in [0, %d)", i, states[i], ctx->sched.n_employees);
