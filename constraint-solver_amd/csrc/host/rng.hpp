@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -152,44 +153,71 @@ public:
     uint64_t words_drawn() const { return counter_ * 16 - (64 - (index_ > 64 ? 64 : index_)); }
 
 private:
-    // The four blocks of one refill in parallel, one 32-bit lane per block (compiler vector extension: SSE2/AVX on
-    // the host).  Same words as four chacha20_block calls (tests/test_host_rng.py compares the two).
+    // One 32-bit lane per block (compiler vector extension).  A refill consumes four blocks (BlockRng's 64-word
+    // buffer); where the host has AVX2, eight blocks are produced at once and the second four wait in ahead_ --
+    // the word sequence is that of chacha20_block called block by block (tests/test_host_rng.py compares them).
+#define LS_CHACHA_LANES(L, OUT)                                                                      \
+    typedef uint32_t vL __attribute__((vector_size(4 * L)));                                        \
+    vL s[16], x[16];                                                                                 \
+    const uint32_t sigma[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};                  \
+    for (int i = 0; i < 4; i++) s[i] = vL{} + sigma[i];                                              \
+    for (int i = 0; i < 8; i++) s[4 + i] = vL{} + key_[i];                                           \
+    s[12] = vL{}; s[13] = vL{}; s[14] = vL{}; s[15] = vL{};                                          \
+    for (int b = 0; b < L; b++) {                                                                    \
+        const uint64_t c = counter_ + (uint64_t)b;                                                   \
+        s[12][b] = (uint32_t)c;                                                                      \
+        s[13][b] = (uint32_t)(c >> 32);                                                              \
+    }                                                                                                \
+    for (int i = 0; i < 16; i++) x[i] = s[i];                                                        \
+    for (int r = 0; r < 10; r++) {                                                                   \
+        LS_QR(0, 4, 8, 12) LS_QR(1, 5, 9, 13) LS_QR(2, 6, 10, 14) LS_QR(3, 7, 11, 15)                \
+        LS_QR(0, 5, 10, 15) LS_QR(1, 6, 11, 12) LS_QR(2, 7, 8, 13) LS_QR(3, 4, 9, 14)                \
+    }                                                                                                \
+    for (int i = 0; i < 16; i++) {                                                                   \
+        const vL o = x[i] + s[i];                                                                    \
+        for (int b = 0; b < L; b++) (OUT)[16 * b + i] = o[b];                                        \
+    }
+#define LS_QR(a, b, c, d)                                                            \
+    x[a] += x[b]; x[d] = ((x[d] ^ x[a]) << 16) | ((x[d] ^ x[a]) >> 16);              \
+    x[c] += x[d]; x[b] = ((x[b] ^ x[c]) << 12) | ((x[b] ^ x[c]) >> 20);              \
+    x[a] += x[b]; x[d] = ((x[d] ^ x[a]) << 8) | ((x[d] ^ x[a]) >> 24);               \
+    x[c] += x[d]; x[b] = ((x[b] ^ x[c]) << 7) | ((x[b] ^ x[c]) >> 25);
+    void blocks4(uint32_t *out) { LS_CHACHA_LANES(4, out) }
+#if defined(__x86_64__)
+    __attribute__((target("avx2"))) void blocks8(uint32_t *out) { LS_CHACHA_LANES(8, out) }
+    static bool have_avx2() // LS_HOST_NO_AVX2=1 forces the four-lane path (tests run both)
+    {
+        static const bool v = __builtin_cpu_supports("avx2") && std::getenv("LS_HOST_NO_AVX2") == nullptr;
+        return v;
+    }
+#endif
+#undef LS_QR
+#undef LS_CHACHA_LANES
     void generate_and_set(size_t idx)
     {
-        typedef uint32_t v4 __attribute__((vector_size(16)));
-        auto splat = [](uint32_t w) { return v4{w, w, w, w}; };
-        auto rotl = [](v4 v, int n) { return (v << n) | (v >> (32 - n)); };
-        v4 s[16];
-        s[0] = splat(0x61707865u); s[1] = splat(0x3320646eu); s[2] = splat(0x79622d32u); s[3] = splat(0x6b206574u);
-        for (int i = 0; i < 8; i++) s[4 + i] = splat(key_[i]);
-        for (int b = 0; b < 4; b++) {
-            const uint64_t c = counter_ + (uint64_t)b;
-            s[12][b] = (uint32_t)c;
-            s[13][b] = (uint32_t)(c >> 32);
+        if (have_ahead_) {
+            std::memcpy(buf_, ahead_, sizeof buf_);
+            have_ahead_ = false;
+        } else {
+#if defined(__x86_64__)
+            if (have_avx2()) {
+                uint32_t tmp[128];
+                blocks8(tmp);
+                std::memcpy(buf_, tmp, sizeof buf_);
+                std::memcpy(ahead_, tmp + 64, sizeof ahead_);
+                have_ahead_ = true;
+            } else
+#endif
+                blocks4(buf_);
         }
-        s[14] = splat(0); s[15] = splat(0);
-        v4 x[16];
-        for (int i = 0; i < 16; i++) x[i] = s[i];
-#define LS_QR(a, b, c, d)                                   \
-        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);         \
-        x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);         \
-        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);          \
-        x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
-        for (int r = 0; r < 10; r++) {
-            LS_QR(0, 4, 8, 12) LS_QR(1, 5, 9, 13) LS_QR(2, 6, 10, 14) LS_QR(3, 7, 11, 15)
-            LS_QR(0, 5, 10, 15) LS_QR(1, 6, 11, 12) LS_QR(2, 7, 8, 13) LS_QR(3, 4, 9, 14)
-        }
-#undef LS_QR
-        for (int i = 0; i < 16; i++) {
-            const v4 o = x[i] + s[i];
-            for (int b = 0; b < 4; b++) buf_[16 * b + i] = o[b];
-        }
-        counter_ += 4;
+        counter_ += 4; // blocks handed to buf_ so far (ahead_ holds blocks counter_ .. counter_ + 3 when have_ahead_)
         index_ = idx;
     }
     uint32_t key_[8];
     uint64_t counter_ = 0;
     uint32_t buf_[64];
+    uint32_t ahead_[64];
+    bool have_ahead_ = false;
     size_t index_ = 64;
 };
 

@@ -7,6 +7,7 @@
 The rand / rand_chacha crates are not in /root/reference: PARITY UNPINNED against the Rust
 binaries' streams."""
 import hashlib
+import os
 import random
 import struct
 
@@ -118,3 +119,18 @@ def test_gen_range_is_in_range_and_covers():
     assert min(vals) == 3 and max(vals) == 9
     vals = ls_amd.host_rng_script(seed, [(7, 10, 10)])
     assert sorted(vals) == list(range(10))
+
+
+def test_rng_stream_without_avx2_lookahead():
+    # the refill has two code paths (AVX2: eight blocks at once with a look-ahead buffer; otherwise four): same words
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import hashlib, ls_amd;"
+            "seed = hashlib.blake2b(b'42', digest_size=32).digest();"
+            "print(ls_amd.host_rng_script(seed, [(0, 0, 0)] * 300 + [(1, 0, 0)] * 100))") % os.path.dirname(ls_amd.__path__[0])
+    outs = []
+    for extra in ({}, {"LS_HOST_NO_AVX2": "1"}):
+        env = dict(os.environ, **extra)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True, text=True,
+                                   timeout=120).stdout)
+    assert outs[0] == outs[1] and len(outs[0]) > 1000
