@@ -164,3 +164,24 @@ def test_multi_restart_lockstep_equals_single_runs(ctx):
         if b is not None and b[0] == 0:
             break
     assert o.get_best_solution() == singles[1]
+
+
+def test_c_example_program_matches_python_solver(ctx, tmp_path):
+    # examples/nqueens_c.c: the reference's nqueens binary in plain C on the C ABI (no Python, no torch in the process)
+    import subprocess
+    import ls_amd
+    from test_abi import _build_c_example
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe, "8", "42"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rows = [int(x) for x in r.stdout.split("[")[1].split("]")[0].split(",")]
+    assert "result.score: 0" in r.stdout
+    ctx.set_algo("auto")
+    s = ls_amd.Solver.nqueens(ctx, 8, "42", _nq_params(8))
+    while not s.is_finished():
+        s.execute_round()
+        b = s.best()
+        if b is not None and b[0] == 0:
+            break
+    assert list(s.best()[1]) == rows
+    s.close()
