@@ -68,13 +68,13 @@ def test_rust_sys_bindings_cover_the_header():
     assert sorted(set(re.findall(r"pub fn (ls_[a-z0-9_]+)\(", rs))) == _declared_functions()
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="nqueens_c"):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(_lib.HEADER_PATH)))
-    exe = str(tmp_path / "nqueens_c")
+    exe = str(tmp_path / name)
     libdir = os.path.dirname(_lib.SO_PATH)
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-O2", "-I", os.path.dirname(_lib.HEADER_PATH),
-                    os.path.join(root, "examples", "nqueens_c.c"), "-o", exe, "-L", libdir, "-lls_amd",
+                    os.path.join(root, "examples", name + ".c"), "-o", exe, "-L", libdir, "-lls_amd",
                     f"-Wl,-rpath,{libdir}"], check=True, capture_output=True, text=True, timeout=120)
     return exe
 
@@ -86,6 +86,7 @@ def test_header_is_plain_c_and_c_example_links(tmp_path):
     src.write_text('#include "ls_amd.h"\nint main(void) { return (int)sizeof(ls_nq_result) - 32; }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.dirname(_lib.HEADER_PATH),
                     "-c", str(src), "-o", str(tmp_path / "hdr.o")], check=True, capture_output=True, timeout=60)
+    _build_c_example(tmp_path, "employee_scheduling_c")
     exe = _build_c_example(tmp_path)
     if ls_amd.device_count() == 0:                 # and, like every entry point, it fails loudly without a GPU
         r = subprocess.run([exe, "8", "42"], capture_output=True, text=True, timeout=60)

@@ -185,3 +185,20 @@ def test_c_example_program_matches_python_solver(ctx, tmp_path):
             break
     assert list(s.best()[1]) == rows
     s.close()
+
+
+def test_c_scheduling_example_matches_python_solver(ctx, tmp_path):
+    import subprocess
+    import ls_amd
+    from test_abi import _build_c_example
+    exe = _build_c_example(tmp_path, "employee_scheduling_c")
+    r = subprocess.run([exe, "42"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    sol = [int(x) for x in r.stdout.split("[")[1].split("]")[0].split(",")]
+    s = ls_amd.Solver.scheduling(ctx, 31, 0, 7, "42", dict(lo.SCHED_MAIN_PARAMS))
+    while not s.is_finished():
+        s.execute_round()
+    score, best = s.best()
+    s.close()
+    assert list(best) == sol
+    assert f"result.score: hard {score[0]}, soft {score[1]}" in r.stdout
