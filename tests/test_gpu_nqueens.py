@@ -392,3 +392,48 @@ def test_fused_step_device_entry(ctx):
             assert (raw[r, 0], raw[r, 1]) == (exp["n_scored"], exp["best_index"])
             assert raw[r, 2] == exp["best_score"]
             assert np.array_equal(nrows[r], board) and np.array_equal(ncs[r], cs) and ntot[r] == cs.sum()
+
+
+def test_fused_step_device_entry_is_graph_capturable(ctx):
+    # a whole LS step (argmin + move + next board + its column scores) is one kernel with no allocation or
+    # synchronisation once warmed up: captured into a hipGraph, replayed as a chain board -> next board -> ...
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(88)
+    n, R, mc = 1024, 3, 51
+    dev = torch.device("cuda:0")
+    rows_np = np.stack([_board(rng, n, "uniform") for _ in range(R)]).astype(np.int32)
+    cols_np = np.stack([rng.permutation(n)[:mc] for _ in range(R)]).astype(np.int32)
+    n_cols = np.full(R, mc, dtype=np.int32)
+    cur_np = np.array([orc.nq_score(rows_np[r]) for r in range(R)], dtype=np.int64)
+    rows, cols = torch.from_numpy(rows_np).to(dev), torch.from_numpy(cols_np).to(dev)
+    cur, ncols = torch.from_numpy(cur_np).to(dev), torch.from_numpy(n_cols).to(dev)
+    res = torch.zeros((R, 4), dtype=torch.int64, device=dev)
+    nrows = torch.zeros((R, n), dtype=torch.int32, device=dev)
+    ncs = torch.zeros((R, n), dtype=torch.int64, device=dev)
+    ntot = torch.zeros(R, dtype=torch.int64, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    ctx.set_algo("auto")
+    ctx.set_stream(stream.cuda_stream)
+    try:
+        def launch():
+            ctx.nqueens_eval_batch_next_dev(R, n, rows.data_ptr(), cur.data_ptr(), cols.data_ptr(), ncols.data_ptr(), mc,
+                                            5 * n, res.data_ptr(), nrows.data_ptr(), ncs.data_ptr(), ntot.data_ptr())
+        with torch.cuda.stream(stream):
+            launch()
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            launch()
+        board, score = rows_np.copy(), cur_np.copy()
+        for step in range(4):                       # feed every step's winner board back in
+            rows.copy_(torch.from_numpy(board)); cur.copy_(torch.from_numpy(score))
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            out, nb, cs, tot = res.cpu().numpy(), nrows.cpu().numpy(), ncs.cpu().numpy(), ntot.cpu().numpy()
+            for r, (exp, b, ecs) in enumerate(_expect_step(board, cols_np, n_cols, 5 * n)):
+                assert (out[r, 0], out[r, 1], out[r, 2]) == (exp["n_scored"], exp["best_index"], exp["best_score"])
+                assert np.array_equal(nb[r], b) and np.array_equal(cs[r], ecs) and tot[r] == ecs.sum() == exp["best_score"]
+            board, score = nb.astype(np.int32).copy(), tot.copy()
+    finally:
+        ctx.set_stream(None)
