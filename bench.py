@@ -388,6 +388,16 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np):
                                                                "note": "includes ctypes/numpy marshalling of the Python wrapper"}
     ctx.set_algo("scan")
     out.update(sched_measurements(ctx, torch, dev, timed))
+    # the HBM figure the rooflines divide by is the vendor's 8 TB/s; this is what a plain device-to-device
+    # copy of 2 GiB reaches on this box (torch's copy kernel; bytes read + bytes written per second)
+    try:
+        src = torch.empty(1 << 29, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        s = timed(lambda: dst.copy_(src), 10)
+        out["hbm_copy_bandwidth"] = {"GBps_read_plus_write": 2 * src.numel() * 4 / s / 1e9, "bytes_copied": int(src.numel() * 4)}
+        del src, dst
+    except Exception as e:  # noqa: BLE001 - a measurement line must not take the bench down
+        out["hbm_copy_bandwidth"] = {"error": repr(e)}
     return out
 
 
