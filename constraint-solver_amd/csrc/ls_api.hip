@@ -267,7 +267,7 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
     if (cols_b) memcpy(si.h<char>(o_cols), cols, cols_b);
     memcpy(si.h<char>(o_nc), n_cols, nc_b);
     const long long win = nq_clamp_window(window, max_cols, n);
-    if (cs_b && !sc_b && ctx->nq_step_mode > 0 && nq_step_eligible(ctx, n, max_cols, win)) {
+    if (!sc_b && ctx->nq_step_mode > 0 && nq_step_eligible(ctx, n, max_cols, win)) {
         // One LS step per restart in one launch.  Mode 2: the kernel reads the pinned staging block and writes
         // the pinned result block directly (each byte crosses PCIe once, no copy dispatches in the chain).
         const bool zc = ctx->nq_step_mode >= 2;
@@ -275,12 +275,13 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
         char *ib = static_cast<char *>(zc ? si.host : si.dev), *ob = static_cast<char *>(zc ? so.host : so.dev);
         rc = nq_step_dev(ctx, n_restarts, n, reinterpret_cast<int *>(ib + o_rows), reinterpret_cast<long long *>(ib + o_cur),
                          reinterpret_cast<int *>(ib + o_cols), reinterpret_cast<int *>(ib + o_nc), max_cols, win,
-                         reinterpret_cast<ls_nq_result *>(ob + o_res), nullptr, reinterpret_cast<long long *>(ob + o_cs), nullptr);
+                         reinterpret_cast<ls_nq_result *>(ob + o_res), nullptr,
+                         cs_b ? reinterpret_cast<long long *>(ob + o_cs) : nullptr, nullptr);
         if (rc != LS_OK) return rc;
         if (!zc) LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
         LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         memcpy(results, so.h<char>(o_res), res_b);
-        memcpy(next_col_scores, so.h<char>(o_cs), cs_b);
+        if (cs_b) memcpy(next_col_scores, so.h<char>(o_cs), cs_b);
         return LS_OK;
     }
     LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
