@@ -498,6 +498,33 @@ int ls_sched_eval_batch(ls_ctx *ctx, int32_t n_restarts, const int32_t *states, 
     const size_t st_b = (size_t)n_restarts * S * 4, mv_b = (size_t)n_restarts * max_moves * sizeof(ls_sched_move),
                  nm_b = (size_t)n_restarts * 8, res_b = (size_t)n_restarts * sizeof(ls_sched_result),
                  out_b = (size_t)n_restarts * max_moves * 8;
+    if (!hard_out && !soft_out && st_b + mv_b + nm_b <= (size_t)4 << 20) {
+        // Production shape (no per-candidate score dump): everything goes through the pinned staging blocks -- one
+        // copy each way, or none at all for the small move lists the fused one-block launch serves (<= 512 moves:
+        // the reference example's window-100 iteration), whose kernel reads its inputs in place.
+        const size_t o_nm = 0, o_st = align256(o_nm + nm_b), o_mv = align256(o_st + st_b), in_b = align256(o_mv + mv_b);
+        const size_t res_pad = align256(res_b);
+        {
+            hipError_t e = ctx->stage_in.reserve(in_b);
+            if (e == hipSuccess) e = ctx->stage_out.reserve(res_pad);
+            if (e != hipSuccess) return set_err(ctx, LS_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
+        }
+        Staging &si = ctx->stage_in, &so = ctx->stage_out;
+        memcpy(si.h<char>(o_nm), n_moves, nm_b);
+        memcpy(si.h<char>(o_st), states, st_b);
+        if (mv_b) memcpy(si.h<char>(o_mv), moves, mv_b);
+        const bool zc = ctx->sched_zero_copy && ctx->sched_fused && max_moves <= 512;
+        if (!zc) LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
+        char *ib = static_cast<char *>(zc ? si.host : si.dev), *ob = static_cast<char *>(zc ? so.host : so.dev);
+        rc = sched_eval_batch_dev(ctx, n_restarts, reinterpret_cast<int *>(ib + o_st), reinterpret_cast<ls_sched_move *>(ib + o_mv),
+                                  reinterpret_cast<long long *>(ib + o_nm), max_moves, window,
+                                  reinterpret_cast<ls_sched_result *>(ob), nullptr, nullptr);
+        if (rc != LS_OK) return rc;
+        if (!zc) LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, res_pad, hipMemcpyDeviceToHost, ctx->stream));
+        LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(results, so.h<char>(0), res_b);
+        return LS_OK;
+    }
     LS_RESERVE(ctx, ctx->sc_states, st_b);
     LS_RESERVE(ctx, ctx->sc_moves, mv_b);
     LS_RESERVE(ctx, ctx->sc_nmoves, nm_b);
