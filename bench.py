@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--board-size", "--n", dest="n", type=int, default=4096,
                     help="(under torch.distributed.run use --board-size: its parser treats --n as ambiguous)")
     ap.add_argument("--restarts-per-gpu", type=int, default=8)
+    ap.add_argument("--total-restarts", type=int, default=None,
+                    help="strong-scaling mode (SURVEY 8(e)): a fixed total, e.g. 64, split evenly over the ranks")
     ap.add_argument("--algo", choices=["scan", "table"], default="scan")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -180,6 +182,10 @@ def main():
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     n, R = args.n, args.restarts_per_gpu
+    if args.total_restarts is not None:
+        if args.total_restarts % world:
+            raise SystemExit(f"--total-restarts {args.total_restarts} is not divisible by the {world} ranks")
+        R = args.total_restarts // world
     # restart r -> rank r mod world; R restarts per GPU
     my_ids = sharding.shard_restarts(R * world, world, rank)
     boards = make_boards(n, my_ids)
@@ -261,7 +267,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.total_restarts is None else "strong",
             "vs_baseline": None,
             "dtype": "f32" if args.algo == "scan" and n <= 4096 else "int32",
             "data": "synthetic",
