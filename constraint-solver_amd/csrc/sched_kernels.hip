@@ -357,30 +357,37 @@ __device__ __forceinline__ void sched_write_result(const SchedEvalArgs &a, int r
 // where take(window) stops (pass 1b's in-chunk ballots, on the whole move list), then scores, then writes the
 // result itself -- locate + eval + reduce in ONE launch.  The state is read once into LDS, so it may live in pinned
 // host memory.
-struct SchedFusedShared {
+template <bool FUSED> struct SchedFusedShared {
     int state[64];
     int wcnt[16];
     long long found;
+    ls_sched_move moves[FUSED ? 64 * SC_FUSED_WAVES : 1]; // the (<= 512-entry) move list, read from memory once
 };
 
 template <int NW>
-__device__ __forceinline__ void sched_locate_in_block(const SchedEvalArgs &a, int r, SchedFusedShared &sh, long long &k_end,
+__device__ __forceinline__ void sched_locate_in_block(const SchedEvalArgs &a, int r, SchedFusedShared<true> &sh, long long &k_end,
                                                       long long &n_scored)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // every global read of this phase is issued before the first wait: the move (device memory, speculative: it does
+    // not depend on the state or on n_moves), the state and n_moves (possibly pinned host memory, one PCIe round trip)
+    const ls_sched_move *mv = a.moves + (long long)r * a.max_moves;
+    ls_sched_move m0;
+    m0.type = -1; m0.a = 0; m0.b = 0;
+    if ((long long)threadIdx.x < a.max_moves) m0 = mv[threadIdx.x];
+    const long long nm = sched_nm(a, r);
     if (threadIdx.x < 64) sh.state[threadIdx.x] = (int)threadIdx.x < a.in.S ? a.states[(long long)r * a.in.S + threadIdx.x] : -1;
     if (threadIdx.x == 0) sh.found = -1;
+    sh.moves[threadIdx.x] = m0;
     __syncthreads();
-    const long long nm = sched_nm(a, r);
-    const ls_sched_move *mv = a.moves + (long long)r * a.max_moves;
     long long run = 0;
     k_end = nm;
     if (a.window <= 0) { k_end = 0; n_scored = 0; return; }
-    for (int t = 0; t < SC_COUNT_CHUNK && t < nm; t += 64 * NW) { // block-uniform trip count
-        const long long k = t + threadIdx.x;
-        const bool flag = sched_counts(a, mv, k, nm, sh.state);
+    {   // the fused launch serves max_moves <= 64 * NW: one pass over the list
+        const long long k = threadIdx.x;
+        const bool flag = k < nm && sched_move_ok(m0.type, m0.a, m0.b, a.in.S, a.in.n_employees) &&
+                          (m0.type == 0 ? (sh.state[m0.a] != m0.b) : (sh.state[m0.a] != sh.state[m0.b]));
         const u64 bal = __ballot(flag);
-        __syncthreads(); // wcnt is reused
         if (lane == 0) sh.wcnt[w] = __popcll(bal);
         __syncthreads();
         int before = 0, total = 0;
@@ -391,8 +398,7 @@ __device__ __forceinline__ void sched_locate_in_block(const SchedEvalArgs &a, in
         const int incl = before + __popcll(bal & ((2ull << lane) - 1));
         if (flag && run + incl == a.window) sh.found = k + 1;
         __syncthreads();
-        if (sh.found >= 0) break;
-        run += total;
+        if (sh.found < 0) run += total;
     }
     if (sh.found >= 0) { k_end = sh.found; run = a.window; }
     n_scored = run;
@@ -408,9 +414,9 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_kernel(SchedEvalArgs a)
     const int wave = FUSED ? wib : (int)(blockIdx.x / a.n_restarts) * NW + wib;
     const int n_waves = FUSED ? NW : (int)(gridDim.x / a.n_restarts) * NW;
     const int S = a.in.S, D = a.in.D, E = a.in.n_employees;
-    __shared__ SchedFusedShared s_fused;
+    __shared__ SchedFusedShared<FUSED> s_fused;
     long long k_end, n_scored_f = 0;
-    if (FUSED) sched_locate_in_block<NW>(a, r, s_fused, k_end, n_scored_f);
+    if constexpr (FUSED) sched_locate_in_block<NW>(a, r, s_fused, k_end, n_scored_f);
     else k_end = a.k_end[r];
     const long long n_batches = ((k_end + 63) >> 6) * a.split; // work units: (batch, part)
     __shared__ u64 s_key[NW];
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_kernel(SchedEvalArgs a)
         const long long k = (batch << 6) + lane;
         // ---- per-lane: this lane's move, its edit, its holiday bits, its half of the key
         int type = -1, ma = 0, mb = 0;
-        if (k < k_end) { const ls_sched_move m = mv[k]; type = m.type; ma = m.a; mb = m.b; }
+        if (k < k_end) { const ls_sched_move m = FUSED ? s_fused.moves[FUSED ? k : 0] : mv[k]; type = m.type; ma = m.a; mb = m.b; }
         const bool ok = sched_move_ok(type, ma, mb, S, E);
         const int ia = ok ? ma : 0, ib = (ok && type == 1) ? mb : ia;
         const int ea = __shfl(base, ia, 64), eb = __shfl(base, ib, 64);
@@ -614,9 +620,9 @@ __global__ __launch_bounds__(64 * NW) void sched_eval32_kernel(SchedEvalArgs a)
     const int wave = FUSED ? wib : (int)(blockIdx.x / a.n_restarts) * NW + wib;
     const int n_waves = FUSED ? NW : (int)(gridDim.x / a.n_restarts) * NW;
     const int S = a.in.S, D = a.in.D, E = a.in.n_employees;
-    __shared__ SchedFusedShared s_fused;
+    __shared__ SchedFusedShared<FUSED> s_fused;
     long long k_end, n_scored_f = 0;
-    if (FUSED) sched_locate_in_block<NW>(a, r, s_fused, k_end, n_scored_f);
+    if constexpr (FUSED) sched_locate_in_block<NW>(a, r, s_fused, k_end, n_scored_f);
     else k_end = a.k_end[r];
     const long long n_units = ((k_end + 63) >> 6) * a.split; // work units: (batch, part)
     __shared__ u64 s_key[NW];
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(64 * NW) void sched_eval32_kernel(SchedEvalArgs a)
             const long long k = (batch << 6) + lane;
             // ---- per-lane: this lane's move, its edit, its holiday bits, its half of the key
             int type = -1, ma = 0, mb = 0;
-            if (k < k_end) { const ls_sched_move m = mv[k]; type = m.type; ma = m.a; mb = m.b; }
+            if (k < k_end) { const ls_sched_move m = FUSED ? s_fused.moves[FUSED ? k : 0] : mv[k]; type = m.type; ma = m.a; mb = m.b; }
             const bool ok = sched_move_ok(type, ma, mb, S, E);
             const int ia = ok ? ma : 0, ib = (ok && type == 1) ? mb : ia;
             const int ea = __shfl(base, ia, 64), eb = __shfl(base, ib, 64);
