@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import hashlib
 import math
+import struct
 from collections import deque
 
 import numpy as np
@@ -327,9 +328,9 @@ class LocalSearch:
 
 
 class IteratedLocalSearch:
-    def __init__(self, problem, params, seed: str):
+    def __init__(self, problem, params, seed):
         self.p = problem
-        seed32 = hash_str(seed)
+        seed32 = seed if isinstance(seed, (bytes, bytearray)) else hash_str(seed)   # 32 raw bytes, or the examples' seed string
         self.local_search = LocalSearch(problem, params["local_search_max_iterations"], params["window_size"],
                                         params["best_solutions_capacity"], params["all_solutions_capacity"],
                                         params["all_solution_iteration_expiry"], ChaCha20Rng(seed32))
@@ -493,6 +494,108 @@ NQUEENS_MAIN_PARAMS = dict(  # examples/nqueens/src/main.rs:129-135 (window = 5 
 SCHED_MAIN_PARAMS = dict(    # examples/employee-scheduling/src/main.rs:24-31
     local_search_max_iterations=1_000, window_size=100, best_solutions_capacity=64, all_solutions_capacity=100_000,
     all_solution_iteration_expiry=1_000, iterated_local_search_max_iterations=250, max_allow_no_improvement_for=20)
+
+
+# ------------------------------------------------------------------ Ackley
+# The reference's OWN tests of the generic loop (local-search/src/local_search.rs:351-440,
+# iterated_local_search.rs:205-321) drive LocalSearch / IteratedLocalSearch with a third plug-in, the f64 Ackley
+# function (local-search/src/ackley.rs, math-util/src/ackley.rs).  It is restated here ONLY so that those tests'
+# assertions can be run against this oracle's History / LocalSearch / IteratedLocalSearch (tests/test_oracle_driver.py);
+# the product does not build it.  The RNG draws (rand_core seed_from_u64, UniformFloat, Normal)
+# follow the published algorithms from memory -- stream equality with the Rust binaries is unverified, and the
+# reference's assertions (improves / does not move / reaches 1e-2) do not depend on it.
+def seed_from_u64(state: int) -> bytes:
+    """rand_core 0.6 SeedableRng::seed_from_u64: PCG32 output words fill the 32-byte seed."""
+    out = b""
+    for _ in range(8):
+        state = (state * 6364136223846793005 + 11634580027462260723) & M64
+        xorshifted = (((state >> 18) ^ state) >> 27) & M32
+        rot = state >> 59
+        x = ((xorshifted >> rot) | (xorshifted << ((32 - rot) & 31))) & M32
+        out += x.to_bytes(4, "little")
+    return out
+
+
+def gen_range_f64(rng, low, high):
+    """rand 0.8.5 UniformFloat<f64>::sample_single for low..high."""
+    scale = high - low
+    while True:
+        bits = (rng.next_u64() >> 12) | (1023 << 52)          # a float in [1, 2)
+        value1_2 = struct.unpack("<d", struct.pack("<Q", bits))[0]
+        res = value1_2 * scale + (low - scale)
+        if res < high:
+            return res
+
+
+def ackley_function(xs, a=20.0, b=0.2, c=2.0 * math.pi):
+    """math-util/src/ackley.rs:19-33."""
+    d = float(len(xs))
+    square_sum = 0.0
+    cosine_sum = 0.0
+    for x in xs:
+        square_sum += x * x
+        cosine_sum += math.cos(c * x)
+    fx = 0.0
+    fx += -a * math.exp(-b * math.sqrt(square_sum / d))
+    fx -= math.exp(cosine_sum / d)
+    fx += a + math.e
+    return fx
+
+
+class Ackley:
+    """AckleySolution / Score / ScoreCalculator / InitialSolutionGenerator / MoveProposer / Perturbation
+    (local-search/src/ackley.rs:21-262) with the LITERAL neighbourhood pipeline of local_search.rs:315-325."""
+    X_MIN, X_MAX = -32.768, 32.768
+
+    def __init__(self, dimensions, min_move_size, max_move_size):
+        self.d, self.lo, self.hi = dimensions, min_move_size, max_move_size
+
+    @staticmethod
+    def is_best(score):                                         # ackley.rs:36-41
+        return abs(score - 0.0) <= 1e-2
+
+    def score(self, sol):
+        return ackley_function(sol)
+
+    def generate_initial_solution(self, rng):                   # :96-105
+        return tuple(gen_range_f64(rng, self.X_MIN, self.X_MAX) for _ in range(self.d))
+
+    def neighbourhood_first(self, current, rng, window, history):
+        dims = list(range(self.d))                              # iter_local_moves, :187-197
+        shuffle(rng, dims)
+        move = gen_range_f64(rng, self.lo, self.hi)
+        scored = []
+        for dim in dims:                                        # MoveIterator::next, :156-178: up, then down
+            for delta in (move, -move):
+                c = list(current[1])
+                c[dim] = c[dim] + delta
+                c = tuple(c)
+                if history.is_solution_tabu(c):                 # local_search.rs:319
+                    continue
+                scored.append((self.score(c), c))               # :320
+                if len(scored) == window:                       # :321
+                    break
+            if len(scored) == window:
+                break
+        if not scored:
+            return None
+        scored.sort()                                           # :323
+        return scored[0]                                        # :325
+
+    def propose_new_starting_solution(self, current, history, rng):   # ackley.rs:231-261
+        strategy = choose_weighted_index(rng, [100, 10], 64)
+        if strategy == 1:
+            return current[1]
+        new = list(current[1])
+        dims = list(range(len(new)))
+        shuffle(rng, dims)
+        k = gen_range_incl(rng, 0, len(dims) - 1, 64)           # gen_range(0..len): may be 0
+        for i in dims[:k]:
+            # rand_distr::Normal (ziggurat) is not restated: Box-Muller on two uniform draws (stream differs)
+            u1, u2 = max(rng.gen_f64(), 1e-300), rng.gen_f64()
+            z = math.sqrt(-2.0 * math.log(u1)) * math.cos(2.0 * math.pi * u2)
+            new[i] = min(max(new[i] + z, self.X_MIN), self.X_MAX)
+        return tuple(new)
 
 
 def run(ils: IteratedLocalSearch, max_rounds=None, trace=None):

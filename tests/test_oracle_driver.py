@@ -1,6 +1,8 @@
 """CPU-only: the oracle's restatement of the reference's host driver reproduces the reference's
 own end-to-end test — examples/nqueens/src/main.rs:156-200 `repeatable`: n = 8, seeds
 "42".."49", identical result on every run and final score 0 (expiry 1000 there)."""
+import pytest
+
 import ls_oracle as lo
 
 
@@ -32,3 +34,51 @@ def test_sched_example_instance_runs_and_improves():
     best = ils.get_best_solution()
     assert best is not None and best[0] < first
     assert len(best[1]) == 32
+
+
+# ---- the reference's own tests of the GENERIC loop (they use a third plug-in, the f64 Ackley function) ----
+
+def test_ackley_function_kats():
+    # math-util/src/ackley.rs:60-104 (values from the published MATLAB implementation, epsilon 1e-12)
+    assert abs(lo.ackley_function([0.0, 0.0]) - 0.0) <= 1e-12
+    assert abs(lo.ackley_function([1.0, 1.0]) - 3.625384938440363) <= 1e-12
+    assert abs(lo.ackley_function([float(i % 10) for i in range(20)]) - 13.12408690638194) <= 1e-12
+
+
+def _ackley_local_search(seed=42):
+    # local_search.rs:364-391: dimensions 2, move size 1e-6..0.1, 100 000 iterations, window 256, capacities 16 / 10 000 / 10 000
+    return lo.LocalSearch(lo.Ackley(2, 1e-6, 0.1), 100_000, 256, 16, 10_000, 10_000, lo.ChaCha20Rng(lo.seed_from_u64(seed)))
+
+
+def test_ackley_local_minima_found():
+    # local_search.rs:363-418: from a random start the search ends strictly better and somewhere else
+    ls = _ackley_local_search()
+    start = ls.p.generate_initial_solution(lo.ChaCha20Rng(lo.seed_from_u64(42)))
+    end = ls.execute(start, 1)
+    assert end[0] < ls.p.score(start)
+    assert end[1] != start
+
+
+def test_ackley_when_starting_from_global_minima_does_not_move():
+    # local_search.rs:420-470
+    ls = _ackley_local_search()
+    start = (0.0, 0.0)
+    end = ls.execute(start, 1)
+    assert abs(end[0] - ls.p.score(start)) <= 1e-12
+    assert end[1] == start
+
+
+@pytest.mark.parametrize("dimensions", [2, 10, 20])
+def test_ackley_iterated_local_search_reaches_the_global_minimum(dimensions):
+    # iterated_local_search.rs:221-321 (`_ackley` for 2, 10 and 20 dimensions, seed 0): move size 1e-3..0.5, window 500,
+    # LS max 100 000, ILS max 10 000 rounds, no-improvement limit 5; the best solution scores 0 within 1e-2
+    params = dict(local_search_max_iterations=100_000, window_size=500, best_solutions_capacity=16,
+                  all_solutions_capacity=10_000, all_solution_iteration_expiry=10_000,
+                  iterated_local_search_max_iterations=10_000, max_allow_no_improvement_for=5)
+    ils = lo.IteratedLocalSearch(lo.Ackley(dimensions, 1e-3, 0.5), params, lo.seed_from_u64(0))
+    while not ils.is_finished():
+        ils.execute_round()
+        b = ils.get_best_solution()
+        if b is not None and lo.Ackley.is_best(b[0]):
+            break                                            # the reference keeps spinning through no-op rounds
+    assert abs(ils.get_best_solution()[0]) <= 1e-2
