@@ -135,6 +135,285 @@ def ensure_built():
         time.sleep(2.0)  # let the linker finish writing
 
 
+VALU_CLOCK_HZ = 2.4e9          # MI355X max engine clock (MI355X_MICROARCH.md: "Max clock 2400 MHz")
+VALU_CYCLES_PER_WAVE_INSTR = 2  # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (same guide, "SIMD / EU")
+
+
+def valu_issue_peak_wave_instr_per_s(n_cus: int) -> float:
+    """Spec VALU issue peak: 4 SIMDs per CU, one wave64 instruction per 2 cycles per SIMD at 2.4 GHz
+    (= 78.6 T lane-operations/s on 256 CUs, half the 157.3 TFLOP/s FMA figure: one operation per lane per instruction)."""
+    return 4 * n_cus * VALU_CLOCK_HZ / VALU_CYCLES_PER_WAVE_INSTR
+
+
+class _ThreadSync:
+    """Barrier + max-over-ranks + gather for ranks that are host threads of ONE process (one host thread,
+    one context and one stream per GPU; the path has no collective, so no torch.distributed is needed)."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self._bar = threading.Barrier(world)
+        self._slots = [None] * world
+
+    def barrier(self):
+        self._bar.wait()
+
+    def all_gather(self, rank, obj):
+        self._slots[rank] = obj
+        self._bar.wait()
+        out = list(self._slots)
+        self._bar.wait()
+        return out
+
+
+class _DistSync:
+    def __init__(self, dist, torch, red_dev, world):
+        self.dist, self.torch, self.red_dev, self.world = dist, torch, red_dev, world
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def all_gather(self, rank, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+
+def run_rank(args, rank, world, device, sync, launcher):
+    """One rank = one GPU: `device` is the HIP device index; `sync` provides barrier / all_gather over the ranks."""
+    import torch
+
+    import ls_amd
+    from ls_amd import sharding
+
+    dev = torch.device("cuda", device)
+    n, R = args.n, args.restarts_per_gpu
+    if args.total_restarts is not None:
+        if args.total_restarts % world:
+            raise SystemExit(f"--total-restarts {args.total_restarts} is not divisible by the {world} ranks")
+        R = args.total_restarts // world
+    with torch.cuda.device(dev):
+        # restart r -> rank r mod world (SURVEY 8(e)); R restarts per GPU
+        my_ids = sharding.shard_restarts(R * world, world, rank)
+        boards = make_boards(n, my_ids)
+        ctx = ls_amd.Context(device, algo=args.algo)
+        info = ctx.device_info()
+        # a dedicated (non-default) torch stream: HIP events recorded on it bracket the kernels
+        # (ls_ctx_set_stream(NULL) would select the context's own stream, and 0 is torch's default stream)
+        stream = torch.cuda.Stream(device=dev)
+        assert stream.cuda_stream != 0
+        ctx.set_stream(stream.cuda_stream)
+
+        # current scores from the GPU col-score kernel (bit-identical to get_col_scores; tested)
+        _, cur_np = ctx.nqueens_col_scores(boards)
+        rows_d = torch.from_numpy(boards).to(dev)
+        cur_d = torch.from_numpy(cur_np).to(dev)
+        cols_d = torch.arange(n, dtype=torch.int32, device=dev).repeat(R, 1).contiguous()
+        ncols_d = torch.full((R,), n, dtype=torch.int32, device=dev)
+        res_d = torch.zeros((R, 4), dtype=torch.int64, device=dev)
+        window = n * (n - 1)
+        neighbours_per_step = R * n * (n - 1)
+
+        def step():
+            ctx.nqueens_eval_batch_dev(R, n, rows_d.data_ptr(), cur_d.data_ptr(), cols_d.data_ptr(), ncols_d.data_ptr(),
+                                       n, window, res_d.data_ptr())
+
+        with torch.cuda.stream(stream):
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize(dev)
+            sync.barrier()
+            torch.cuda.synchronize(dev)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                ev[i][0].record(stream)
+                step()
+                ev[i][1].record(stream)
+            torch.cuda.synchronize(dev)
+            sync.barrier()
+            torch.cuda.synchronize(dev)
+            elapsed = time.perf_counter() - t0
+        launch_ms = [a.elapsed_time(b) for a, b in ev]
+
+        # results: host-side gather of one (score, board) record per restart, global minimum (no collective on the data path)
+        res = res_d.cpu().numpy()
+        recs = []
+        for i, rid in enumerate(my_ids):
+            b = boards[i].copy()
+            col, val = int(res[i, 3] & 0xFFFFFFFF), int(res[i, 3] >> 32)
+            b[col] = val
+            recs.append(sharding.record(rid, int(res[i, 2]), b))
+            assert res[i, 0] == n * (n - 1), "every non-tabu candidate of the full neighbourhood must be scored"
+        gathered = sync.all_gather(rank, dict(elapsed=elapsed, recs=recs, launch_ms=launch_ms))
+        elapsed = max(g["elapsed"] for g in gathered)                    # MAX over ranks
+        all_recs = [r for g in gathered for r in g["recs"]]
+        best = sharding.best_of(all_recs)
+
+        out = None
+        if rank == 0:
+            value = neighbours_per_step * world * args.steps / elapsed
+            avg_launch_s = float(np.mean(launch_ms)) / 1e3
+            out = build_report(args, world, R, n, info, value, elapsed, avg_launch_s, neighbours_per_step, window, best, launcher)
+            out["verified"] = verify_results(n, all_recs)           # every restart's record vs the oracle (after the timed region)
+            if not out["verified"]["ok"]:
+                print(json.dumps(out), flush=True)
+                raise SystemExit("bench.py: the timed launch's results differ from the oracle")
+            if not args.no_cpu_baseline and world == 1:
+                cb, ns, cb_best = cpu_baseline(n, boards[0], args.cpu_seconds)
+                out["cpu_baseline"] = cb
+                out["cpu_baseline"]["gpu_over_cpu"] = value / cb["value"]
+            if not args.no_extra and world == 1:
+                with torch.cuda.stream(stream):
+                    out["extra"] = extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info)
+            print(json.dumps(out), flush=True)
+        sync.barrier()
+        ctx.set_stream(None)
+        ctx.close()
+    return out
+
+
+def verify_results(n, all_recs):
+    """Parity gate of the timed region: the (score, winner board) record of EVERY restart, as produced by the timed
+    launches, against the oracle's count-table formulation of local_search.rs:315-325 on the same board (boards are
+    regenerated from the restart id).  The oracle is the checker here, never the thing measured."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+
+    orc.build()
+    t0 = time.perf_counter()
+    bad = []
+    cols = np.arange(n)
+    for (score, board, rid) in all_recs:
+        base = make_boards(n, [rid])[0]
+        exp = orc.nq_neighbourhood(base, cols, n * (n - 1), "table", want_scores=False)
+        want = base.copy()
+        want[exp["best_index"] // n] = exp["best_index"] % n
+        if score != (exp["best_score"],) or tuple(int(x) for x in want) != board or exp["n_scored"] != n * (n - 1):
+            bad.append(rid)
+    return {"ok": not bad, "restarts_checked": len(all_recs), "mismatching_restarts": bad,
+            "against": "oracle/nq_oracle.c table formulation, (score, winner board) per restart",
+            "seconds": time.perf_counter() - t0}
+
+
+def build_report(args, world, R, n, info, value, elapsed, avg_launch_s, neighbours_per_step, window, best, launcher):
+    bpn = algorithmic_bytes_per_neighbour(n)
+    eff_gbps = neighbours_per_step * bpn / avg_launch_s / 1e9
+    counters = load_counters()
+    traffic = counters.get("hbm_traffic", {}).get(f"nq_{args.algo}_n{n}_r{R}", {}).get("bytes_per_launch")
+    kernel = ("nq_scan_regs_kernel<BoardF32<64>, false>" if (args.algo == "scan" and 2048 < n <= 4096)
+              else ("nq_table_lds_kernel" if args.algo == "table" else "nq_scan_*"))
+    # VALU-issue roofline of the scan kernel (DESIGN.md 3.1): per neighbour every lane runs 4 full-rate fp32
+    # instructions (sub, sub, mul+clamp, add) for each of its ceil64(n)/64 columns; achieved counts ONLY those
+    # algorithmic instructions (measured SQ_INSTS_VALU per neighbour is in counters.*), peak is the spec issue rate.
+    simds = 4 * info["n_cus"]
+    algo_wave_instr = 4 * ((n + 63) // 64)
+    peak_wi = valu_issue_peak_wave_instr_per_s(info["n_cus"])
+    ach_wi = neighbours_per_step * algo_wave_instr / avg_launch_s
+    roof = {
+        "bound": "valu_issue",
+        "achieved": ach_wi * 64 / 1e12,
+        "peak": peak_wi * 64 / 1e12,
+        "unit": "TFLOP/s",
+        "frac": ach_wi / peak_wi,
+        "traffic": traffic,
+        "kernel": kernel,
+        "avg_launch_ms": avg_launch_s * 1e3,
+        "algorithmic_wave_instr_per_neighbour": algo_wave_instr,
+        "peak_source": "MI355X_MICROARCH.md: wave64 VALU instruction = 2 cycles per SIMD-32, 4 SIMDs x n_cus, 2.4 GHz max clock; "
+                       "1 fp32 operation per lane per instruction (sub / mul / add, no fused pairs), i.e. half the 157.3 TFLOP/s FMA peak",
+        "note": "no MFMA and not HBM-bound: the 16 KiB state of a restart is read once per wavefront and held in registers; "
+                "every candidate then costs 4 fp32 instructions per column (exact integer-valued arithmetic), so the limiter is VALU issue",
+        # SURVEY 8(d)'s fixed byte accounting, kept as a labelled secondary: NOT a usable roofline fraction (> 1), because
+        # those bytes are served from registers, not from HBM; measured HBM traffic is `traffic` (rocprofv3 counters)
+        "hbm_effective_secondary": {
+            "algorithmic_bytes_per_neighbour": bpn, "effective_GBps": eff_gbps, "hbm_peak_GBps": HBM_PEAK_GBPS,
+            "effective_over_hbm_peak": eff_gbps / HBM_PEAK_GBPS,
+            "measured_hbm_bytes_per_launch": traffic,
+            "measured_hbm_GBps": (traffic / avg_launch_s / 1e9) if traffic else None,
+            "measured_hbm_frac_of_peak": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+            "note": "SURVEY 8(d): 4n+16 bytes per neighbour; exceeds the HBM peak because the state is shared by all candidates of a "
+                    "restart and lives in VGPRs. Counter traffic: profiles/hbm_traffic.json"},
+    }
+    c = counters.get("kernels", {}).get("nq_scan_regs_kernel")
+    if c:
+        roof["counters"] = c
+    return {
+        "metric": "neighbor evals/sec (N=4096 nqueens)" if n == 4096 else f"neighbor evals/sec (N={n} nqueens)",
+        "value": value,
+        "unit": "neighbour evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak" if args.total_restarts is None else "strong",
+        "vs_baseline": None,
+        "dtype": "f32" if args.algo == "scan" and n <= 4096 else "int32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"nqueens n={n}, {R} independent restarts per GPU ({R * world} total, restart r on rank r mod {world}), "
+                        f"full n x n neighbourhood per restart per launch (window = n(n-1) = {window}), "
+                        f"uniform-random boards seeded by restart id, algo={args.algo}",
+            "n": n, "restarts_per_gpu": R, "neighbours_per_step_per_gpu": neighbours_per_step,
+            "algo": args.algo, "device": info["name"], "n_cus": info["n_cus"],
+            "ranks": launcher,
+            "algo_note": "scan = the reference's O(n) pair checks per candidate, the kernel the metric and SURVEY 8(d)'s byte "
+                         "accounting are defined on; the library default (auto) resolves to the count-table family, "
+                         "reported under extra.table_*",
+            "arithmetic": "state int32, scores int64; the scan kernel tests attacks with exact integer-valued fp32 "
+                          "arithmetic (|values| < 2^24), see DESIGN.md 3.1",
+        },
+        "roofline": roof,
+        # SURVEY 8(d) secondary metric.  Each neighbour tests its new placement against the n - 1 other
+        # columns; the old placement's n - 1 tests are done once per column and shared by its n - 1
+        # neighbours, so the kernel performs (n - 1) + 1 pair checks per neighbour (the survey's 2(n - 1)
+        # figure counts the shared half once per neighbour).
+        "secondary": {"pair_constraint_checks_per_s": value * n,
+                      "pair_constraint_checks_per_s_survey_convention_2x": value * 2 * (n - 1)},
+        "global_best": {"score": best[0][0], "restart": best[2]},
+    }
+
+
+def load_counters():
+    """Committed rocprofv3 summaries (profiles/): HBM traffic per launch and per-kernel SQ instruction counts."""
+    out = {}
+    for key, name in (("hbm_traffic", "hbm_traffic.json"), ("kernels", "kernel_counters.json")):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                out[key] = json.load(f)
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher, process flavour (--spawn): N fresh child processes, one per GPU,
+    started BEFORE this process touches the GPU, rendezvous on 127.0.0.1.  The parent relays rank 0's JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(args.gpus))
+        argv = [a for a in sys.argv[1:] if a != "--spawn"]
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, abs(p.wait()))
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,188 +430,97 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse ranks on one GPU)")
     ap.add_argument("--all-on-device", type=int, default=None,
-                    help="rehearsal only: put every rank on this one device (use with --backend gloo)")
+                    help="rehearsal only: put every rank on this one device")
+    ap.add_argument("--spawn", action="store_true",
+                    help="without a launcher and --gpus N > 1: N child processes (torch.distributed) instead of N host threads")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={env_world} but --gpus {args.gpus}; launch N ranks for --gpus N")
     ensure_built()
-    import ls_amd
-    from ls_amd import sharding
+    if env_world is None and args.gpus > 1 and args.spawn:
+        spawn_ranks(args)           # never returns
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the evaluator has no CPU fallback")
+    if args.all_on_device is None and args.gpus > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible "
+                         "(--all-on-device D rehearses the ranks on one device)")
+
+    if env_world is None and args.gpus > 1:
+        # No launcher: ONE process, one host thread + one context + one stream per GPU (SURVEY 8(e) / north star).
+        # The path has no collective, so the ranks only meet at the barriers and at the host-side gather.
+        import threading
+
+        world = args.gpus
+        sync = _ThreadSync(world)
+        errors = []
+
+        def target(rank):
+            try:
+                device = args.all_on_device if args.all_on_device is not None else rank
+                run_rank(args, rank, world, device, sync, "host threads of one process, one context + stream per GPU, no collective")
+            except BaseException as e:  # noqa: BLE001 - a failed rank must not leave the others at a barrier
+                errors.append((rank, repr(e)))
+                sync._bar.abort()
+
+        threads = [threading.Thread(target=target, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise SystemExit(f"bench.py: rank failure(s): {errors}")
+        return
+
+    # One process per GPU under torch.distributed.run (the driver's launch for N > 1), or the plain 1-GPU run.
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the evaluator has no CPU fallback")
-    if args.all_on_device is not None:
-        local_rank = args.all_on_device
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    world = int(env_world or "1")
+    device = args.all_on_device if args.all_on_device is not None else local_rank
+    torch.cuda.set_device(device)
+    dev = torch.device("cuda", device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if args.backend == "nccl" and args.all_on_device is None:
             dist.init_process_group("nccl", device_id=dev)
         else:
-            dist.init_process_group(args.backend)
-    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
-
-    n, R = args.n, args.restarts_per_gpu
-    if args.total_restarts is not None:
-        if args.total_restarts % world:
-            raise SystemExit(f"--total-restarts {args.total_restarts} is not divisible by the {world} ranks")
-        R = args.total_restarts // world
-    # restart r -> rank r mod world; R restarts per GPU
-    my_ids = sharding.shard_restarts(R * world, world, rank)
-    boards = make_boards(n, my_ids)
-    ctx = ls_amd.Context(local_rank, algo=args.algo)
-    info = ctx.device_info()
-    # a dedicated (non-default) torch stream: HIP events recorded on it bracket the kernels
-    # (ls_ctx_set_stream(NULL) would select the context's own stream, and 0 is torch's default stream)
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    ctx.set_stream(stream.cuda_stream)
-
-    # current scores from the GPU col-score kernel (bit-identical to get_col_scores; tested)
-    _, cur_np = ctx.nqueens_col_scores(boards)
-    rows_d = torch.from_numpy(boards).to(dev)
-    cur_d = torch.from_numpy(cur_np).to(dev)
-    cols_d = torch.arange(n, dtype=torch.int32, device=dev).repeat(R, 1).contiguous()
-    ncols_d = torch.full((R,), n, dtype=torch.int32, device=dev)
-    res_d = torch.zeros((R, 4), dtype=torch.int64, device=dev)
-    window = n * (n - 1)
-    neighbours_per_step = R * n * (n - 1)
-
-    def step():
-        ctx.nqueens_eval_batch_dev(R, n, rows_d.data_ptr(), cur_d.data_ptr(), cols_d.data_ptr(), ncols_d.data_ptr(),
-                                   n, window, res_d.data_ptr())
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        step()
-        ev[i][1].record()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    launch_ms = [a.elapsed_time(b) for a, b in ev]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # results: host-side gather of one (score, board) record per restart, global minimum
-    res = res_d.cpu().numpy()
-    recs = []
-    for i, rid in enumerate(my_ids):
-        b = boards[i].copy()
-        col, val = int(res[i, 3] & 0xFFFFFFFF), int(res[i, 3] >> 32)
-        b[col] = val
-        recs.append(sharding.record(rid, int(res[i, 2]), b))
-        assert res[i, 0] == n * (n - 1), "every non-tabu candidate of the full neighbourhood must be scored"
-    best, all_recs = sharding.gather_best(recs)
-
-    if rank == 0:
-        value = neighbours_per_step * world * args.steps / elapsed
-        avg_launch_s = float(np.mean(launch_ms)) / 1e3
-        bpn = algorithmic_bytes_per_neighbour(n)
-        achieved = neighbours_per_step * bpn / avg_launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get(f"nq_{args.algo}_n{n}_r{R}", {}).get("bytes_per_launch")
-        out = {
-            "metric": "neighbor evals/sec (N=4096 nqueens)" if n == 4096 else f"neighbor evals/sec (N={n} nqueens)",
-            "value": value,
-            "unit": "neighbour evals/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak" if args.total_restarts is None else "strong",
-            "vs_baseline": None,
-            "dtype": "f32" if args.algo == "scan" and n <= 4096 else "int32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"nqueens n={n}, {R} independent restarts per GPU ({R * world} total, restart r on rank r mod {world}), "
-                            f"full n x n neighbourhood per restart per launch (window = n(n-1) = {window}), "
-                            f"uniform-random boards seeded by restart id, algo={args.algo}",
-                "n": n, "restarts_per_gpu": R, "neighbours_per_step_per_gpu": neighbours_per_step,
-                "algo": args.algo, "device": info["name"], "n_cus": info["n_cus"],
-                "algo_note": "scan = the reference's O(n) pair checks per candidate, the kernel the metric and SURVEY 8(d)'s byte "
-                             "accounting are defined on; the library default (auto) resolves to the count-table family, "
-                             "reported under extra.table_*",
-                "arithmetic": "state int32, scores int64; the scan kernel tests attacks with exact integer-valued fp32 "
-                              "arithmetic (|values| < 2^24), see DESIGN.md 3.1",
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "kernel": ("nq_scan_regs_kernel<BoardF32<64>, false>" if (args.algo == "scan" and 2048 < n <= 4096)
-                           else ("nq_table_eval_kernel" if args.algo == "table" else "nq_scan_*")),
-                "avg_launch_ms": avg_launch_s * 1e3,
-                "algorithmic_bytes_per_neighbour": bpn,
-                "note": "algorithmic bytes per SURVEY 8(d) (4n+16 per neighbour); the 16 KiB state is shared by all "
-                        "candidates of a restart and is held in registers, so the effective rate exceeds the HBM peak; the "
-                        "kernel's real limiter is VALU issue (4 fp32 instructions per candidate and column), see DESIGN.md 3.1",
-                # one wavefront per candidate: n/64 columns per lane x 4 full-rate fp32 instructions, issued at
-                # 0.92 ns per wave-instruction per SIMD with 2 waves/SIMD (tools/valu_rates.hip)
-                "issue_bound": {"wave_instr_per_neighbour": 4 * n // 64, "ns_per_instr_per_simd": 0.92,
-                                "simds": 4 * info["n_cus"],
-                                "neighbours_per_s_at_bound": 4 * info["n_cus"] / (4 * n / 64 * 0.92e-9),
-                                "frac_of_issue_bound": (value / world) / (4 * info["n_cus"] / (4 * n / 64 * 0.92e-9))},
-            },
-            # SURVEY 8(d) secondary metric.  Each neighbour tests its new placement against the n - 1 other
-            # columns; the old placement's n - 1 tests are done once per column and shared by its n - 1
-            # neighbours, so the kernel performs (n - 1) + 1 pair checks per neighbour (the survey's 2(n - 1)
-            # figure counts the shared half once per neighbour).
-            "secondary": {"pair_constraint_checks_per_s": value * n,
-                          "pair_constraint_checks_per_s_survey_convention_2x": value * 2 * (n - 1)},
-            "global_best": {"score": best[0][0], "restart": best[2]},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            cb, ns, cb_best = cpu_baseline(n, boards[0], args.cpu_seconds)
-            out["cpu_baseline"] = cb
-            out["cpu_baseline"]["gpu_over_cpu"] = value / cb["value"]
-        if not args.no_extra and world == 1:
-            out["extra"] = extra_measurements(ctx, torch, dev, n, R, boards, cur_np)
-        print(json.dumps(out), flush=True)
-    barrier()
-    ctx.set_stream(None)
-    ctx.close()
+            dist.init_process_group("gloo")     # several ranks on one device: RCCL refuses duplicate GPUs
+    red_dev = dev if (args.backend == "nccl" and args.all_on_device is None) else torch.device("cpu")
+    sync = _DistSync(dist, torch, red_dev, world)
+    run_rank(args, rank, world, device, sync,
+             "torch.distributed.run, one process per GPU; RCCL for the barrier only, host-side gather" if world > 1 else "single process")
     if world > 1:
         dist.destroy_process_group()
 
 
-def extra_measurements(ctx, torch, dev, n, R, boards, cur_np):
+def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info):
     """Secondary lines (not `value`): the other kernel family on the same workload and the
     reference-shaped small launch (<= 204 proposed columns, window 5n), SURVEY 8(d) config 4."""
     out = {}
     rows_d = torch.from_numpy(boards).to(dev)
     cur_d = torch.from_numpy(cur_np).to(dev)
     res_d = torch.zeros((R, 4), dtype=torch.int64, device=dev)
+    kc = load_counters().get("kernels", {})
+
+    def issue_roofline(workload, live_s):
+        """{bound, frac} of a secondary kernel: the larger of its VALU-issue and LDS-array bounds (instruction counts from
+        the committed rocprofv3 counters of the same workload, spec clock, every SIMD / LDS array busy) over the live time."""
+        c = kc.get(workload)
+        if not c or "valu_issue_bound_us" not in c:
+            return None
+        bounds = {"valu_issue": c["valu_issue_bound_us"]}
+        if "lds_array_bound_us" in c:
+            bounds["lds_array"] = c["lds_array_bound_us"]
+        b = max(bounds, key=bounds.get)
+        return {"bound": b, "frac": bounds[b] / (live_s * 1e6), "bound_us": bounds[b],
+                "valu_wave_instr_per_candidate": c.get("valu_wave_instr_per_candidate"),
+                "lds_wave_instr_per_candidate": c.get("lds_wave_instr_per_candidate"), "counters": c.get("source")}
 
     def timed(fn, iters):
         for _ in range(3):
@@ -357,7 +545,8 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np):
         s = timed(lambda: ctx.nqueens_eval_batch_dev(R, n, rows_d.data_ptr(), cur_d.data_ptr(), cols_full.data_ptr(),
                                                      ncols_full.data_ptr(), n, n * (n - 1), res_d.data_ptr()),
                   5 if algo == "scan" else 50)
-        out[f"{algo}_full_neighbourhood"] = {"neighbours_per_s": R * n * (n - 1) / s, "ms_per_launch": s * 1e3}
+        out[f"{algo}_full_neighbourhood"] = {"neighbours_per_s": R * n * (n - 1) / s, "ms_per_launch": s * 1e3,
+                                             "roofline": issue_roofline("nq_scan_regs_kernel" if algo == "scan" else "nq_table_lds_kernel", s)}
         w = 5 * n
         s = timed(lambda: ctx.nqueens_eval_batch_dev(R, n, rows_d.data_ptr(), cur_d.data_ptr(), cols_ref.data_ptr(),
                                                      ncols_ref.data_ptr(), mc, w, res_d.data_ptr()), 200)
@@ -393,7 +582,7 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np):
         out[f"fused_ls_step_host_round_trip_{RR}_restarts"] = {"us_per_call": s * 1e6, "candidates_per_call": RR * min(5 * n, mc * (n - 1)),
                                                                "note": "includes ctypes/numpy marshalling of the Python wrapper"}
     ctx.set_algo("scan")
-    out.update(sched_measurements(ctx, torch, dev, timed))
+    out.update(sched_measurements(ctx, torch, dev, timed, issue_roofline))
     # the HBM figure the rooflines divide by is the vendor's 8 TB/s; this is what a plain device-to-device
     # copy of 2 GiB reaches on this box (torch's copy kernel; bytes read + bytes written per second)
     try:
@@ -407,7 +596,7 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np):
     return out
 
 
-def sched_measurements(ctx, torch, dev, timed):
+def sched_measurements(ctx, torch, dev, timed, issue_roofline):
     """Scheduling path, kernel throughput with moves and states resident in HBM."""
     out = {}
     rng = np.random.default_rng(2022)
@@ -452,7 +641,9 @@ def sched_measurements(ctx, torch, dev, timed):
         torch.cuda.synchronize()
         n_scored = int(res.cpu().numpy()[0, 0])
         out[name] = {"neighbours_per_s": n_scored / s, "us_per_launch": s * 1e6, "candidates_per_launch": n_scored,
-                     "effective_GBps_at_144B": n_scored * 144 / s / 1e9}
+                     "effective_GBps_at_144B": n_scored * 144 / s / 1e9,
+                     "roofline_eval_kernel_only": issue_roofline("sched_eval32_kernel_exhaustive" if "exhaustive" in name
+                                                                 else "sched_eval32_kernel_random65536", s)}
     # the same exhaustive neighbourhood through the host entry that generates the move list on the device:
     # only the 128-byte state and the 32-byte result cross PCIe (round trip incl. sync and the Python wrapper)
     ctx.sched_eval_exhaustive(state_np, 10 ** 9)

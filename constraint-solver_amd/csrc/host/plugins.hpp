@@ -48,6 +48,7 @@ public:
     void submit(NqRequest *r)
     {
         std::unique_lock<std::mutex> lk(m_);
+        if (!error_.empty()) throw std::runtime_error(error_); // a restart already failed: nobody parks any more
         r->done.store(false, std::memory_order_relaxed);
         pending_.push_back(r);
         if ((int)pending_.size() == live_) {
@@ -66,7 +67,13 @@ public:
             lk.lock();
             cv_.wait(lk, [&] { return r->done.load(std::memory_order_acquire) || !error_.empty(); });
         }
-        if (!error_.empty()) throw std::runtime_error(error_);
+        if (!error_.empty()) {
+            // `r` lives on this thread's stack, which unwinds now: it must not stay parked (a later flush would
+            // write r->done through a dangling pointer)
+            for (size_t i = 0; i < pending_.size(); i++)
+                if (pending_[i] == r) { pending_.erase(pending_.begin() + (long)i); break; }
+            throw std::runtime_error(error_);
+        }
     }
     void thread_done()
     {
@@ -79,6 +86,9 @@ public:
         std::unique_lock<std::mutex> lk(m_);
         if (error_.empty()) error_ = msg;
         failed_.store(true);
+        // release every parked restart; each finds error_ set, takes itself off the list and throws
+        for (NqRequest *r : pending_) r->done.store(true, std::memory_order_release);
+        pending_.clear();
         cv_.notify_all();
     }
     uint64_t launches = 0;

@@ -44,6 +44,25 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
                          ls_sched_result *results_d, long long *hard_out_d, long long *soft_out_d);
 int sched_exhaustive_moves_dev(ls_ctx *ctx, int n_restarts, const int *states_d, ls_sched_move *moves_d, long long *n_moves_d);
 
+static void for_each_buf(ls_ctx *ctx, void (*f)(DevBuf &))
+{
+    DevBuf *bufs[] = {&ctx->nq_rows, &ctx->nq_cur, &ctx->nq_cols, &ctx->nq_ncols, &ctx->nq_results,
+                      &ctx->nq_scores, &ctx->nq_keys, &ctx->nq_tabs, &ctx->nq_colscores, &ctx->nq_totals, &ctx->nq_next_rows,
+                      &ctx->sc_states, &ctx->sc_moves, &ctx->sc_nmoves, &ctx->sc_results, &ctx->sc_hard,
+                      &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sched.holiday_bits, &ctx->sched.lane_tab,
+                      &ctx->sc_resident_moves};
+    for (DevBuf *b : bufs) f(*b);
+}
+
+// Block until the context's stream has drained, then hand back the workspaces that grew out of use meanwhile
+// (DevBuf::retired): nothing queued can still be reading them.
+int sync_and_collect(ls_ctx *ctx)
+{
+    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for_each_buf(ctx, [](DevBuf &b) { if (!b.retired.empty()) b.collect(); });
+    return LS_OK;
+}
+
 static int bind(ls_ctx *ctx)
 {
     if (!ctx) return LS_ERR_INVALID;
@@ -59,6 +78,12 @@ using namespace lsamd;
     do {                                     \
         int rc__ = lsamd::bind(ctx);         \
         if (rc__ != LS_OK) return rc__;      \
+    } while (0)
+
+#define LS_SYNC(ctx)                                 \
+    do {                                             \
+        int rc__ = lsamd::sync_and_collect(ctx);     \
+        if (rc__ != LS_OK) return rc__;              \
     } while (0)
 
 #define LS_REQUIRE(ctx, cond, ...)                                           \
@@ -125,12 +150,7 @@ int ls_ctx_destroy(ls_ctx *ctx)
     if (!ctx) return LS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->nq_rows, &ctx->nq_cur, &ctx->nq_cols, &ctx->nq_ncols, &ctx->nq_results,
-                      &ctx->nq_scores, &ctx->nq_keys, &ctx->nq_tabs, &ctx->nq_colscores, &ctx->nq_totals, &ctx->nq_next_rows,
-                      &ctx->sc_states, &ctx->sc_moves, &ctx->sc_nmoves, &ctx->sc_results, &ctx->sc_hard,
-                      &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sched.holiday_bits, &ctx->sched.lane_tab,
-                      &ctx->sc_resident_moves};
-    for (DevBuf *b : bufs) b->release();
+    for_each_buf(ctx, [](DevBuf &b) { b.release(); });
     ctx->stage_in.release();
     ctx->stage_out.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -143,15 +163,24 @@ const char *ls_last_error(const ls_ctx *ctx) { return ctx ? ctx->err.c_str() : g
 int ls_ctx_set_stream(ls_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return LS_ERR_INVALID;
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    hipStream_t next = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    if (next != ctx->stream) {
+        // Work queued on the old stream (e.g. a finalize kernel restoring the argmin keys, or kernels reading
+        // the context's workspaces) is not ordered before launches on the new one: drain it first -- unless the
+        // old stream is being captured, where nothing runs and a synchronisation would break the capture.
+        LS_BIND(ctx);
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess) { (void)hipGetLastError(); st = hipStreamCaptureStatusNone; }
+        if (st == hipStreamCaptureStatusNone) LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->stream = next;
+    }
     return LS_OK;
 }
 
 int ls_ctx_synchronize(ls_ctx *ctx)
 {
     LS_BIND(ctx);
-    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return LS_OK;
+    return sync_and_collect(ctx);
 }
 
 int ls_ctx_set_nq_algo(ls_ctx *ctx, int algo)
@@ -279,7 +308,7 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
                          cs_b ? reinterpret_cast<long long *>(ob + o_cs) : nullptr, nullptr);
         if (rc != LS_OK) return rc;
         if (!zc) LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
-        LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        LS_SYNC(ctx);
         memcpy(results, so.h<char>(o_res), res_b);
         if (cs_b) memcpy(next_col_scores, so.h<char>(o_cs), cs_b);
         return LS_OK;
@@ -295,7 +324,7 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
     }
     LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
     if (sc_b) LS_HIP(ctx, hipMemcpyAsync(scores_out, ctx->nq_scores.p, sc_b, hipMemcpyDeviceToHost, ctx->stream));
-    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LS_SYNC(ctx);
     memcpy(results, so.h<char>(o_res), res_b);
     if (cs_b) memcpy(next_col_scores, so.h<char>(o_cs), cs_b);
     return LS_OK;
@@ -377,7 +406,7 @@ int ls_nqueens_col_scores(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int3
     if (col_scores)
         LS_HIP(ctx, hipMemcpyAsync(col_scores, ctx->nq_colscores.p, cs_b, hipMemcpyDeviceToHost, ctx->stream));
     if (scores) LS_HIP(ctx, hipMemcpyAsync(scores, ctx->nq_totals.p, t_b, hipMemcpyDeviceToHost, ctx->stream));
-    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LS_SYNC(ctx);
     return LS_OK;
 }
 
@@ -394,6 +423,19 @@ int ls_sched_instance_upload(ls_ctx *ctx, int32_t n_days_scored, int32_t n_days_
     LS_REQUIRE(ctx, n_days_stored >= n_days_scored, "n_days_stored (%d) < n_days_scored (%d)", n_days_stored,
                n_days_scored);
     LS_REQUIRE(ctx, start_weekday >= 0 && start_weekday <= 6, "start_weekday %d outside [0, 6]", start_weekday);
+    {   // The argmin key holds hard in 10 bits and soft in 8 (sched_kernels.hip); both are bounded by the instance length D:
+        //   hard <= D (H1) + D-1 (H2) + 4*ceil(D/7) (H3: a 9-window counts only when it starts on a Saturday)
+        //           + 3*(D-13) (H4: at most three employees can hold > 3 of 14 days)
+        //   soft <= 2*(D-6) (S1: at most two employees hold > 2 of 7 days) + 5*floor(ceil(D/7)/2) (S2: minimum over >= 2
+        //           employees of one weekday's ceil(D/7) days) + D-2 (S3) + 2*ceil(D/7) (S4: weekend days)
+        // D = 64 gives 320 and 223.  Checked here so that raising LS_SCHED_MAX_DAYS cannot silently overflow the fields.
+        const int D = n_days_scored, wk = (D + 6) / 7;
+        const int hard_max = D + (D - 1) + 4 * wk + 3 * (D > 13 ? D - 13 : 0);
+        const int soft_max = 2 * (D > 6 ? D - 6 : 0) + 5 * (wk / 2) + (D > 2 ? D - 2 : 0) + 2 * wk;
+        if (hard_max > 1023 || soft_max > 255)
+            return set_err(ctx, LS_ERR_UNSUPPORTED, "%d scored days: score bounds (hard %d, soft %d) exceed the argmin key fields",
+                           D, hard_max, soft_max);
+    }
     LS_REQUIRE(ctx, n_employees >= 1, "n_employees must be >= 1 (got %d)", n_employees);
     LS_REQUIRE(ctx, holiday_bits != nullptr, "holiday_bits is NULL");
     const uint64_t scored_mask = n_days_scored >= 64 ? ~0ull : ((1ull << n_days_scored) - 1);
@@ -402,7 +444,7 @@ int ls_sched_instance_upload(ls_ctx *ctx, int32_t n_days_scored, int32_t n_days_
                    "employee %d has a holiday outside the scored range (the reference panics here: "
                    "examples/employee-scheduling/src/lib.rs:275)", e);
     // the stream may still be reading the previous instance
-    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LS_SYNC(ctx);
     LS_RESERVE(ctx, ctx->sched.holiday_bits, (size_t)n_employees * 8);
     LS_HIP(ctx, hipMemcpyAsync(ctx->sched.holiday_bits.p, holiday_bits, (size_t)n_employees * 8,
                                hipMemcpyHostToDevice, ctx->stream));
@@ -410,7 +452,7 @@ int ls_sched_instance_upload(ls_ctx *ctx, int32_t n_days_scored, int32_t n_days_
     lsamd::sched_build_lane_table(n_days_scored, start_weekday, tab);
     LS_RESERVE(ctx, ctx->sched.lane_tab, sizeof tab);
     LS_HIP(ctx, hipMemcpyAsync(ctx->sched.lane_tab.p, tab, sizeof tab, hipMemcpyHostToDevice, ctx->stream));
-    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LS_SYNC(ctx);
     ctx->sched.n_days_scored = n_days_scored;
     ctx->sched.n_days_stored = n_days_stored;
     ctx->sched.start_weekday = start_weekday;
@@ -449,7 +491,7 @@ int ls_sched_score(ls_ctx *ctx, int32_t n_states, const int32_t *states, int64_t
     LS_HIP(ctx, hipMemcpyAsync(hard, ctx->sc_hard.p, sc_b, hipMemcpyDeviceToHost, ctx->stream));
     LS_HIP(ctx, hipMemcpyAsync(soft, ctx->sc_soft.p, sc_b, hipMemcpyDeviceToHost, ctx->stream));
     if (terms) LS_HIP(ctx, hipMemcpyAsync(terms, ctx->sc_terms.p, tm_b, hipMemcpyDeviceToHost, ctx->stream));
-    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LS_SYNC(ctx);
     return LS_OK;
 }
 
@@ -521,7 +563,7 @@ int ls_sched_eval_batch(ls_ctx *ctx, int32_t n_restarts, const int32_t *states, 
                                   reinterpret_cast<ls_sched_result *>(ob), nullptr, nullptr);
         if (rc != LS_OK) return rc;
         if (!zc) LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, res_pad, hipMemcpyDeviceToHost, ctx->stream));
-        LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        LS_SYNC(ctx);
         memcpy(results, so.h<char>(0), res_b);
         return LS_OK;
     }
@@ -545,7 +587,7 @@ int ls_sched_eval_batch(ls_ctx *ctx, int32_t n_restarts, const int32_t *states, 
         LS_HIP(ctx, hipMemcpyAsync(hard_out, ctx->sc_hard.p, out_b, hipMemcpyDeviceToHost, ctx->stream));
     if (soft_out && out_b)
         LS_HIP(ctx, hipMemcpyAsync(soft_out, ctx->sc_soft.p, out_b, hipMemcpyDeviceToHost, ctx->stream));
-    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LS_SYNC(ctx);
     return LS_OK;
 }
 
@@ -573,12 +615,12 @@ int ls_sched_moves_upload(ls_ctx *ctx, const ls_sched_move *moves, int64_t n_mov
     LS_REQUIRE(ctx, n_moves >= 0 && (moves || n_moves == 0), "bad arguments");
     int rc = sched_check_moves(ctx, moves, n_moves, 0);
     if (rc != LS_OK) return rc;
-    LS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the stream may still read the previous list
+    LS_SYNC(ctx); // the stream may still read the previous list
     LS_RESERVE(ctx, ctx->sc_resident_moves, (size_t)n_moves * sizeof(ls_sched_move));
     if (n_moves)
         LS_HIP(ctx, hipMemcpyAsync(ctx->sc_resident_moves.p, moves, (size_t)n_moves * sizeof(ls_sched_move),
                                    hipMemcpyHostToDevice, ctx->stream));
-    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LS_SYNC(ctx);
     ctx->sc_resident_n = n_moves;
     return LS_OK;
 }
@@ -611,7 +653,7 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
                               zc ? so.h<ls_sched_result>(0) : so.d<ls_sched_result>(0), nullptr, nullptr);
     if (rc != LS_OK) return rc;
     if (!zc) LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
-    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LS_SYNC(ctx);
     *out = *so.h<ls_sched_result>(0);
     return LS_OK;
 }
@@ -639,7 +681,7 @@ int ls_sched_exhaustive_moves(ls_ctx *ctx, int32_t n_restarts, const int32_t *st
     rc = sched_exhaustive_moves_dev(ctx, n_restarts, ctx->sc_states.as<int>(), ctx->sc_moves.as<ls_sched_move>(), nullptr);
     if (rc != LS_OK) return rc;
     LS_HIP(ctx, hipMemcpyAsync(moves_out, ctx->sc_moves.p, mv_b, hipMemcpyDeviceToHost, ctx->stream));
-    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LS_SYNC(ctx);
     return LS_OK;
 }
 
@@ -667,7 +709,7 @@ int ls_sched_eval_exhaustive(ls_ctx *ctx, int32_t n_restarts, const int32_t *sta
                               ctx->sc_nmoves.as<long long>(), per, window, ctx->sc_results.as<ls_sched_result>(), nullptr, nullptr);
     if (rc != LS_OK) return rc;
     LS_HIP(ctx, hipMemcpyAsync(results, ctx->sc_results.p, res_b, hipMemcpyDeviceToHost, ctx->stream));
-    LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LS_SYNC(ctx);
     return LS_OK;
 }
 

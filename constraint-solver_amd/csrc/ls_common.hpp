@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/ls_amd.h"
 
@@ -17,18 +18,32 @@ namespace lsamd {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
-    // grow-only; contents are not preserved across a grow
+    // Buffers this one outgrew.  Launches already queued on the context's stream may still use them, so they
+    // are not freed on the spot (hipFree would also stall the whole device until it drains): they are handed
+    // back by collect(), which the API calls right after a stream synchronisation, and by release().
+    std::vector<void *> retired;
+    // grow-only (geometric, so a slowly growing batch retires O(log) buffers); contents are not preserved
     hipError_t reserve(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes < 256 ? 256 : bytes;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
+        if (cap && want < cap + cap / 2) want = cap + cap / 2;
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, want);
+        if (e != hipSuccess && want > bytes) { want = bytes; e = hipMalloc(&q, want); }
+        if (e != hipSuccess) return e;
+        if (p) retired.push_back(p);
+        p = q; cap = want;
+        return hipSuccess;
+    }
+    void collect() // only when the stream that used the retired buffers has drained
+    {
+        for (void *q : retired) (void)hipFree(q);
+        retired.clear();
     }
     void release()
     {
+        collect();
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
     }
@@ -83,7 +98,11 @@ struct ls_ctx {
     hipStream_t stream = nullptr;
     int nq_algo = LS_NQ_ALGO_AUTO;
     int nq_step_mode = 2; // fused LS-step kernel: 0 off, 1 through device staging copies, 2 zero-copy on pinned host memory (LS_NQ_STEP)
-    long long nq_keys_ready = 0; // leading argmin keys known to hold NQ_KEY_EMPTY (the finalize kernel resets what it reads)
+    // Argmin keys: every entry of nq_keys holds NQ_KEY_EMPTY whenever no N-queens call is in flight (set once,
+    // synchronously, when the buffer is allocated; the finalize kernel puts back what the eval kernels touched).
+    // nq_keys_dirty is raised while a call is being queued and stays up if it failed half-way: the next call then
+    // clears the keys in stream order first.
+    bool nq_keys_dirty = false;
     bool sched_zero_copy = true; // ls_sched_eval_resident: kernels work on the pinned staging blocks directly (LS_SCHED_ZEROCOPY)
     bool sched_fused = true;     // small scheduling launches: locate + eval + reduce in one kernel (LS_SCHED_FUSED)
     bool sched_force_64 = false; // LS_SCHED_FORCE_64: use the full-wavefront scheduling kernel even for <= 32 days

@@ -1,6 +1,7 @@
 // ls_solver.hip — C entry points for the whole-solver view (include/ls_amd.h, "whole solver"):
 // the host driver of csrc/host/ wired to the GPU path of this library.  Plain host C++; it is a
 // .hip file only so that the one hipcc invocation style builds everything.
+#include <atomic>
 #include <chrono>
 #include <memory>
 #include <new>
@@ -27,6 +28,8 @@ struct ls_multi_solver {
     std::vector<std::string> seeds;
     std::vector<ScoredSolution<NQueensProblem>> best;
     std::vector<int> have;
+    int n_slots = 8;              // restarts in flight at once (host threads); further seeds queue behind them
+    int mode = LS_MULTI_LOCKSTEP; // LS_MULTI_LOCKSTEP: one batched launch per step; LS_MULTI_FREE_RUNNING: a context per slot
     uint64_t ls_iterations = 0, neighbours_scored = 0, gpu_launches = 0, rounds = 0;
 };
 
@@ -52,6 +55,8 @@ template <class F> int guarded(ls_ctx *ctx, F &&f)
         return lsamd::set_err(ctx, LS_ERR_NOMEM, "out of host memory");
     } catch (const std::exception &e) {
         return lsamd::set_err(ctx, LS_ERR_STATE, "%s", e.what());
+    } catch (...) { // nothing crosses the C boundary
+        return lsamd::set_err(ctx, LS_ERR_STATE, "unknown C++ exception");
     }
 }
 
@@ -236,60 +241,94 @@ int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_r
     });
 }
 
+int ls_multi_solver_configure(ls_multi_solver *m, int32_t n_slots, int32_t mode)
+{
+    if (!m) return LS_ERR_INVALID;
+    if (n_slots < 1 || n_slots > 256 || (mode != LS_MULTI_LOCKSTEP && mode != LS_MULTI_FREE_RUNNING))
+        return lsamd::set_err(m->ctx, LS_ERR_INVALID, "ls_multi_solver_configure: n_slots %d (1..256), mode %d", n_slots, mode);
+    m->n_slots = n_slots;
+    m->mode = mode;
+    return LS_OK;
+}
+
 int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, double max_seconds)
 {
     if (!m) return LS_ERR_INVALID;
     return guarded(m->ctx, [&]() {
         const int R = (int)m->seeds.size();
-        NqBatcher batcher(m->ctx, (int32_t)m->board_size, R);
-        std::vector<std::string> errors((size_t)R);
-        std::vector<uint64_t> ls_it((size_t)R, 0), scored((size_t)R, 0), rounds((size_t)R, 0);
+        const int T = m->n_slots < R ? m->n_slots : R; // slots = host threads; a finished restart's slot takes the next seed
+        const bool lockstep = m->mode == LS_MULTI_LOCKSTEP;
+        NqBatcher batcher(m->ctx, (int32_t)m->board_size, T);
+        std::vector<std::string> errors((size_t)T);
+        std::vector<uint64_t> ls_it((size_t)R, 0), scored((size_t)R, 0), rounds((size_t)R, 0), launches((size_t)T, 0);
+        std::atomic<int> next_restart{0};
+        std::atomic<bool> stop{false};
         const auto t0 = std::chrono::steady_clock::now();
-        auto worker = [&](int r) {
+        auto worker = [&](int t) {
+            ls_ctx *own = nullptr;
             try {
-                const ls_solver_params &p = m->params;
-                NQueensProblem problem(m->ctx, m->board_size, &batcher);
-                const ChaCha20Rng solver_rng = ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]);
-                const ChaCha20Rng ils_rng = ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]);
-                LocalSearch<NQueensProblem> ls(&problem, p.local_search_max_iterations, (size_t)p.window_size,
-                                               (size_t)p.best_solutions_capacity, (size_t)p.all_solutions_capacity,
-                                               p.all_solution_iteration_expiry, solver_rng);
-                History<NQueensProblem> history((size_t)p.best_solutions_capacity, (size_t)p.all_solutions_capacity,
-                                                p.all_solution_iteration_expiry);
-                IteratedLocalSearch<NQueensProblem> ils(&problem, std::move(ls), std::move(history),
-                                                        p.iterated_local_search_max_iterations,
-                                                        p.max_allow_no_improvement_for, ils_rng);
-                while (!ils.is_finished() && rounds[(size_t)r] < max_rounds_per_restart) {
-                    ils.execute_round();
-                    rounds[(size_t)r]++;
-                    ScoredSolution<NQueensProblem> b;
-                    if (ils.get_best_solution(b) && NQueensProblem::is_best(b.score)) break; // later rounds are no-ops
-                    if (max_seconds > 0 &&
-                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > max_seconds)
-                        break;
+                ls_ctx *ctx = m->ctx;
+                if (!lockstep && t > 0) { // free-running: one context (stream, staging block) per slot; slot 0 uses the caller's
+                    check_rc(nullptr, ls_ctx_create(m->ctx->device, &own), "ls_ctx_create");
+                    own->nq_algo = m->ctx->nq_algo;
+                    own->nq_step_mode = m->ctx->nq_step_mode;
+                    ctx = own;
                 }
-                ScoredSolution<NQueensProblem> b;
-                if (ils.get_best_solution(b)) { m->best[(size_t)r] = b; m->have[(size_t)r] = 1; }
-                ls_it[(size_t)r] = ils.ls_iterations();
-                scored[(size_t)r] = problem.neighbours_scored;
+                const ls_solver_params &p = m->params;
+                for (;;) {
+                    const int r = next_restart.fetch_add(1);
+                    if (r >= R || stop.load()) break;
+                    NQueensProblem problem(ctx, m->board_size, lockstep ? &batcher : nullptr);
+                    const ChaCha20Rng solver_rng = ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]);
+                    const ChaCha20Rng ils_rng = ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]);
+                    LocalSearch<NQueensProblem> ls(&problem, p.local_search_max_iterations, (size_t)p.window_size,
+                                                   (size_t)p.best_solutions_capacity, (size_t)p.all_solutions_capacity,
+                                                   p.all_solution_iteration_expiry, solver_rng);
+                    History<NQueensProblem> history((size_t)p.best_solutions_capacity, (size_t)p.all_solutions_capacity,
+                                                    p.all_solution_iteration_expiry);
+                    IteratedLocalSearch<NQueensProblem> ils(&problem, std::move(ls), std::move(history),
+                                                            p.iterated_local_search_max_iterations,
+                                                            p.max_allow_no_improvement_for, ils_rng);
+                    while (!ils.is_finished() && rounds[(size_t)r] < max_rounds_per_restart) {
+                        ils.execute_round();
+                        rounds[(size_t)r]++;
+                        ScoredSolution<NQueensProblem> b;
+                        if (ils.get_best_solution(b) && NQueensProblem::is_best(b.score)) break; // later rounds are no-ops
+                        if (max_seconds > 0 &&
+                            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > max_seconds) {
+                            stop.store(true); // no further seeds are started
+                            break;
+                        }
+                    }
+                    ScoredSolution<NQueensProblem> b;
+                    if (ils.get_best_solution(b)) { m->best[(size_t)r] = b; m->have[(size_t)r] = 1; }
+                    ls_it[(size_t)r] = ils.ls_iterations();
+                    scored[(size_t)r] = problem.neighbours_scored;
+                    launches[(size_t)t] += problem.gpu_evals + problem.gpu_col_score_calls;
+                }
             } catch (const std::exception &e) {
-                errors[(size_t)r] = e.what();
+                errors[(size_t)t] = e.what();
                 batcher.fail(e.what());
+            } catch (...) { // nothing may escape a std::thread (std::terminate)
+                errors[(size_t)t] = "unknown exception in a restart";
+                batcher.fail(errors[(size_t)t]);
             }
             batcher.thread_done();
+            if (own) (void)ls_ctx_destroy(own);
         };
         std::vector<std::thread> threads;
-        for (int r = 0; r < R; r++) threads.emplace_back(worker, r);
+        for (int t = 0; t < T; t++) threads.emplace_back(worker, t);
         for (auto &t : threads) t.join();
         for (const std::string &e : errors)
             if (!e.empty()) throw std::runtime_error(e);
-        m->ls_iterations = m->neighbours_scored = m->rounds = 0;
+        m->ls_iterations = m->neighbours_scored = m->rounds = m->gpu_launches = 0;
         for (int r = 0; r < R; r++) {
             m->ls_iterations += ls_it[(size_t)r];
             m->neighbours_scored += scored[(size_t)r];
             m->rounds += rounds[(size_t)r];
         }
-        m->gpu_launches = batcher.launches;
+        if (lockstep) m->gpu_launches = batcher.launches;
+        else for (int t = 0; t < T; t++) m->gpu_launches += launches[(size_t)t];
         return LS_OK;
     });
 }

@@ -30,6 +30,8 @@
 //         keep running key minima, blocks combine through LDS, one 64-bit atomicMin per block.
 //   TABLE occupancy histograms (rows / two diagonals) built once per board;
 //         a candidate is three table reads.  One lane per candidate.
+#include <atomic>
+
 #include "ls_common.hpp"
 
 namespace lsamd {
@@ -402,8 +404,8 @@ __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs 
             const long long left = k1 - k;
             const int ve = (left < (long long)(n - v0)) ? (int)(v0 + left) : n;
             const int c = cols[slot];
-            if ((unsigned)c < (unsigned)n) {
-                const int rc = rows[c];
+            const int rc = (unsigned)c < (unsigned)n ? rows[c] : -1;
+            if ((unsigned)rc < (unsigned)n) { // device-pointer callers are not validated: such a slot is skipped (nq_slot_scored)
                 const long long base = (long long)slot * (n - 1);
                 const NqRanges rg = nq_ranges(v0, ve, rc, base, a.window);
                 if (rg.d1 > rg.d0 || rg.u1 > rg.u0) {
@@ -524,8 +526,8 @@ __global__ __launch_bounds__(NQ_LDS_BLOCK) void nq_scan_lds_kernel(NqArgs a)
             const long long left = k1 - k;
             const int ve = (left < (long long)(n - v0)) ? (int)(v0 + left) : n;
             const int c = cols[slot];
-            if ((unsigned)c < (unsigned)n) {
-                const int rc = rows[c];
+            const int rc = (unsigned)c < (unsigned)n ? rows[c] : -1;
+            if ((unsigned)rc < (unsigned)n) {
                 const long long base = (long long)slot * (n - 1);
                 const NqRanges rg = nq_ranges(v0, ve, rc, base, a.window);
                 if (rg.d1 > rg.d0 || rg.u1 > rg.u0) {
@@ -763,21 +765,46 @@ __global__ __launch_bounds__(256) void nq_col_scores_kernel(const int *rows_all,
 // One block per restart: decode the winning key into the result record, put the key back to EMPTY for
 // the next call (so no separate clearing launch is needed), and - when asked - write the winner board
 // (rows with the selected move applied: MoveIterator, lib.rs:226-228) for the fused column-score pass.
+// Candidates one restart's launch scores: slot s holds the n - 1 real candidates of column cols[s] at window ranks
+// [s(n-1), (s+1)(n-1)); a slot whose column (or, for unvalidated device-pointer callers, whose rows[column]) is
+// outside [0, n) is skipped by every eval kernel but keeps its window positions, so
+//   n_scored = sum over valid slots of clamp(window - s(n-1), 0, n-1).
+__device__ __forceinline__ int nq_slot_scored(int s, int c, int rc, int n, long long window)
+{
+    if ((unsigned)c >= (unsigned)n || (unsigned)rc >= (unsigned)n) return 0;
+    const long long left = window - (long long)s * (n - 1);
+    return left <= 0 ? 0 : (left < n - 1 ? (int)left : n - 1);
+}
+
 __global__ __launch_bounds__(256) void nq_finalize_kernel(NqArgs a, ls_nq_result *results, int *next_rows)
 {
     __shared__ ls_nq_result s_out;
+    __shared__ int s_cnt[4];
     const int r = blockIdx.x;
     const int n = a.n;
-    if (threadIdx.x == 0) {
+    {   // n_scored: what the eval kernels really scored (they skip out-of-range columns)
         int ncols = a.n_cols[r];
         ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
-        const long long total = (long long)ncols * (n - 1);
+        long long slots = ncols;
+        if (n > 1 && a.window / (n - 1) < slots) slots = a.window / (n - 1) + 1;
+        if (n <= 1 || a.window <= 0) slots = 0;
+        int cnt = 0; // <= 32768 * 32767 < 2^31
+        for (int sl = threadIdx.x; sl < (int)slots; sl += 256) {
+            const int c = a.cols[(long long)r * a.max_cols + sl];
+            const int rc = (unsigned)c < (unsigned)n ? a.rows[(long long)r * n + c] : -1;
+            cnt += nq_slot_scored(sl, c, rc, n, a.window);
+        }
+        cnt = wave_sum_i32(cnt);
+        if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         ls_nq_result out;
-        out.n_scored = a.window < total ? (a.window < 0 ? 0 : a.window) : total;
+        out.n_scored = (long long)s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
         const unsigned long long key = a.best_keys[r];
         a.best_keys[r] = NQ_KEY_EMPTY;
         if (key == NQ_KEY_EMPTY || out.n_scored == 0) {
-            out.n_scored = key == NQ_KEY_EMPTY ? 0 : out.n_scored;
+            out.n_scored = 0;
             out.best_index = -1;
             out.best_score = 0;
             out.best_col = -1;
@@ -866,7 +893,7 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
 {
     extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[]; // tables (packed u16: R[n] | A[2n] | B[2n]) | rows[n] | slot records[n_slots]
     __shared__ unsigned long long s_best[16];
-    __shared__ int s_sum[16];
+    __shared__ int s_sum[16], s_cnt[16];
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
     const int r = blockIdx.x, n = a.n;
     const int words = (((5 * n + 1) >> 1) + 3) & ~3; // keeps the slot records 16-byte aligned
@@ -906,6 +933,7 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
         }
     }
     __syncthreads();
+    int my_scored = 0; // this slot's share of n_scored (nq_slot_scored: skipped slots keep their window positions)
     if (tid < n_slots) {
         const int c = cv;
         const int rc = (unsigned)c < (unsigned)n ? s_rows[c] : -1;
@@ -913,7 +941,10 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
         if ((unsigned)rc < (unsigned)n)
             conf_old = tab16_get(s_t16, rc) + tab16_get(s_t16, oA + rc - c + n) + tab16_get(s_t16, oB + rc + c) - 3;
         s_slot[tid] = make_int4(c, (unsigned)rc < (unsigned)n ? rc : -1, conf_old, 0);
+        my_scored = nq_slot_scored(tid, c, rc, n, a.window);
     }
+    my_scored = wave_sum_i32(my_scored);
+    if (lane == 0) s_cnt[wib] = my_scored;
     __syncthreads();
     // Flat walk over the unfiltered positions k = slot * n + v that take(window) can reach; iterations are
     // independent, so the LDS look-ups of several candidates are in flight together.  k / n by an exact
@@ -940,11 +971,11 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
     if (tid == 0) {
         unsigned long long key = s_best[0];
         for (int i = 1; i < 16; i++) key = u64min(key, s_best[i]);
-        const long long total = (long long)ncols * (n - 1);
         ls_nq_result out;
-        out.n_scored = a.window < total ? (a.window < 0 ? 0 : a.window) : total;
+        out.n_scored = 0;
+        for (int i = 0; i < 16; i++) out.n_scored += s_cnt[i];
         if (key == NQ_KEY_EMPTY || out.n_scored == 0) {
-            out.n_scored = key == NQ_KEY_EMPTY ? 0 : out.n_scored;
+            out.n_scored = 0;
             out.best_index = -1;
             out.best_score = 0;
             out.best_col = -1;
@@ -1005,14 +1036,16 @@ static int launch_scan_board(ls_ctx *ctx, const NqArgs &a, long long bpr_cap)
     // number of waves per SIMD, so a dynamic-LDS reservation (never touched) caps residency.
     constexpr int bpc = Board::WAVES;
     constexpr size_t lds_cap = bpc >= 8 ? 0 : (size_t)(160 * 1024 / bpc - 2048 - 4 * NQ_TILE_DWORDS * 4);
-    static bool attr_done_dev[64] = {false}; // per device: function attributes belong to the device's code object
-    bool &attr_done = attr_done_dev[ctx->device & 63];
-    if (!attr_done && lds_cap > 0) {
+    // per device: function attributes belong to the device's code object.  Contexts may run on different threads:
+    // the flag is atomic and setting the (same) attribute twice is harmless.
+    static std::atomic<bool> attr_done_dev[64];
+    std::atomic<bool> &attr_done = attr_done_dev[ctx->device & 63];
+    if (!attr_done.load(std::memory_order_acquire) && lds_cap > 0) {
         LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_scan_regs_kernel<Board, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
         LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_scan_regs_kernel<Board, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-        attr_done = true;
+        attr_done.store(true, std::memory_order_release);
     }
     long long total = (long long)ctx->n_cus * bpc;
     long long bpr = total / a.n_restarts;
@@ -1108,17 +1141,18 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
     // (Small launches are NOT routed to the one-block-per-restart step kernel here: back to back on a stream the
     // table kernel + finalize pair is faster -- 10.7 vs 12.6 us for 8 restarts x window 5n -- because its launch
     // latency pipelines; the step kernel pays off where a host round trip follows every launch, see ls_api.hip.)
-    {   // the finalize kernel leaves every key it read EMPTY again: clear only what it has not seen yet
+    {   // Invariant: all keys are EMPTY between calls.  A fresh buffer is filled once, synchronously (so the fill can
+        // never be "captured but not run" when the first call happens under hipGraph capture -- callers warm up
+        // before capturing, like for every other workspace); the finalize kernel restores what a call touched.
         const void *before = ctx->nq_keys.p;
         LS_RESERVE(ctx, ctx->nq_keys, (size_t)n_restarts * 8);
-        if (ctx->nq_keys.p != before) ctx->nq_keys_ready = 0;
-        const long long ready = ctx->nq_keys_ready;
-        ctx->nq_keys_ready = 0; // until this call's finalize is queued
-        if (ready < n_restarts) {
-            hipLaunchKernelGGL(fill_i64_kernel, dim3((n_restarts + 255) / 256), dim3(256), 0, ctx->stream,
-                               ctx->nq_keys.as<long long>(), -1ll, (long long)n_restarts); // NQ_KEY_EMPTY
+        if (ctx->nq_keys.p != before) LS_HIP(ctx, hipMemset(ctx->nq_keys.p, 0xff, ctx->nq_keys.cap)); // NQ_KEY_EMPTY
+        if (ctx->nq_keys_dirty) { // an earlier call failed between its eval and finalize launches
+            hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((ctx->nq_keys.cap / 8 + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->nq_keys.as<long long>(), -1ll, (long long)(ctx->nq_keys.cap / 8));
             LS_HIP(ctx, hipGetLastError());
         }
+        ctx->nq_keys_dirty = true; // until this call's finalize is queued
     }
     NqArgs a;
     a.rows = rows_d; a.cur_scores = cur_d; a.cols = cols_d; a.n_cols = n_cols_d;
@@ -1142,12 +1176,12 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
     if (max_cols > 0) {
         if (ctx->nq_algo != LS_NQ_ALGO_SCAN && n <= NQ_TABLE_LDS_MAX_N) {
             const size_t lds = (size_t)((5 * n + 1) / 2) * 4 + 16;
-            static bool attr_done_dev[64] = {false};
-            if (!attr_done_dev[ctx->device & 63]) {
+            static std::atomic<bool> attr_done_dev[64];
+            if (!attr_done_dev[ctx->device & 63].load(std::memory_order_acquire)) {
                 LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_table_lds_kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (5 * NQ_TABLE_LDS_MAX_N + 1) / 2 * 4 + 16));
-                attr_done_dev[ctx->device & 63] = true;
+                attr_done_dev[ctx->device & 63].store(true, std::memory_order_release);
             }
             long long per_cu = (160 * 1024) / (long long)(lds + 64);
             per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu); // LDS-latency bound: residency beats wave-count parity here (measured)
@@ -1179,7 +1213,7 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
     }
     hipLaunchKernelGGL(nq_finalize_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a, results_d, next_rows_d);
     LS_HIP(ctx, hipGetLastError());
-    ctx->nq_keys_ready = n_restarts;
+    ctx->nq_keys_dirty = false;
     return LS_OK;
 }
 
@@ -1188,11 +1222,11 @@ int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, lon
 {
     if (n <= NQ_CS_LDS_MAX_N) {
         const size_t lds = (size_t)5 * n * sizeof(int);
-        static bool attr_done_dev[64] = {false};
-        if (!attr_done_dev[ctx->device & 63]) {
+        static std::atomic<bool> attr_done_dev[64];
+        if (!attr_done_dev[ctx->device & 63].load(std::memory_order_acquire)) {
             LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_col_scores_lds_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 5 * NQ_CS_LDS_MAX_N * (int)sizeof(int)));
-            attr_done_dev[ctx->device & 63] = true;
+            attr_done_dev[ctx->device & 63].store(true, std::memory_order_release);
         }
         hipLaunchKernelGGL(nq_col_scores_lds_kernel, dim3(n_restarts), dim3(1024), lds, ctx->stream, rows_d, n, col_scores_d,
                            scores_d);
@@ -1232,11 +1266,11 @@ int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long 
     a.rows = rows; a.cur_scores = cur; a.cols = cols; a.n_cols = n_cols;
     a.n = n; a.n_restarts = n_restarts; a.max_cols = max_cols; a.window = window;
     a.best_keys = nullptr; a.scores_out = nullptr; a.tabs = nullptr; a.tab_stride = 0;
-    static bool attr_done_dev[64] = {false};
-    if (!attr_done_dev[ctx->device & 63]) {
+    static std::atomic<bool> attr_done_dev[64];
+    if (!attr_done_dev[ctx->device & 63].load(std::memory_order_acquire)) {
         LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         ((5 * NQ_STEP_MAX_N + 1) / 2 + 4 + NQ_STEP_MAX_N + 4 * NQ_STEP_MAX_SLOTS) * 4));
-        attr_done_dev[ctx->device & 63] = true;
+        attr_done_dev[ctx->device & 63].store(true, std::memory_order_release);
     }
     long long slots = (long long)max_cols;
     if (window / (n - 1) < max_cols) slots = window / (n - 1) + 1;

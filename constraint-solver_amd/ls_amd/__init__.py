@@ -325,7 +325,9 @@ class MultiSolver:
     """ls_multi_solver: R independent N-queens restarts on one GPU in lockstep (one batched launch
     per step); each restart's result equals running it alone."""
 
-    def __init__(self, ctx: Context, board_size: int, seeds, params: dict):
+    MODES = {"lockstep": 0, "free": 1}
+
+    def __init__(self, ctx: Context, board_size: int, seeds, params: dict, n_slots: int | None = None, mode: str = "lockstep"):
         self._ctx, self._l, self.n, self.seeds = ctx, ctx._l, int(board_size), [str(s) for s in seeds]
         arr = (C.c_char_p * len(self.seeds))(*[s.encode() for s in self.seeds])
         h = C.c_void_p()
@@ -333,6 +335,8 @@ class MultiSolver:
         ctx._check(self._l.ls_multi_solver_create_nqueens(ctx._h, self.n, len(self.seeds), C.cast(arr, C.c_void_p),
                                                           C.byref(p), C.byref(h)))
         self._h = h
+        if n_slots is not None or mode != "lockstep":
+            ctx._check(self._l.ls_multi_solver_configure(h, int(n_slots or 8), self.MODES[mode]))
 
     def run(self, max_rounds_per_restart=2 ** 62, max_seconds=0.0):
         self._ctx._check(self._l.ls_multi_solver_run(self._h, int(max_rounds_per_restart), float(max_seconds)))

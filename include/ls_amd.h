@@ -305,15 +305,24 @@ int ls_solver_get_current_solution(const ls_solver *s, int64_t score[2], int64_t
 int ls_solver_get_stats(const ls_solver *s, uint64_t *ls_iterations, uint64_t *neighbours_scored, uint64_t *gpu_evals);
 int ls_solver_free(ls_solver *s);
 
-/* Many independent restarts on one GPU, in lockstep (the reference's only
- * multi-seed convention is consecutive seed strings, examples/nqueens/src/main.rs:167).  Each
- * restart is a complete, unchanged solver on its own host thread; their GPU requests are served
- * by ONE batched launch per step (ls_nqueens_eval_batch / ls_nqueens_col_scores), so the result
- * of every restart is identical to running it alone.  ls_multi_solver_run drives all restarts
- * until each is finished, has found a best-possible solution, or a limit is reached. */
+/* Many independent restarts on one GPU (the reference's only multi-seed convention is
+ * consecutive seed strings, examples/nqueens/src/main.rs:167).  Each restart is a complete, unchanged solver
+ * on a host thread; n_slots of them are in flight at once and a finished restart's slot takes the next seed of
+ * the list, so the GPU stays fed while restarts need very different numbers of iterations.  The result of
+ * every restart is identical to running it alone with ls_solver_*.  Two ways to serve the slots' GPU requests:
+ *   LS_MULTI_LOCKSTEP      (default) the slots' requests of one step are merged into ONE batched launch on the
+ *                          caller's context (ls_nqueens_eval_batch_next / ls_nqueens_col_scores);
+ *   LS_MULTI_FREE_RUNNING  every slot owns a context (stream + pinned staging block) on the same device and
+ *                          issues its own one-restart launches; no slot ever waits for another.
+ * ls_multi_solver_run drives all restarts until each is finished, has found a best-possible solution, or a
+ * limit is reached (restarts not started before max_seconds elapsed report have = 0). */
+#define LS_MULTI_LOCKSTEP      0
+#define LS_MULTI_FREE_RUNNING  1
 typedef struct ls_multi_solver ls_multi_solver;
 int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_restarts, const char *const *seeds,
                                    const ls_solver_params *params, ls_multi_solver **out);
+/* n_slots in [1, 256] (default 8), mode as above; call before ls_multi_solver_run. */
+int ls_multi_solver_configure(ls_multi_solver *m, int32_t n_slots, int32_t mode);
 int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, double max_seconds);
 int ls_multi_solver_get_best(const ls_multi_solver *m, int32_t restart, int64_t score[2], int64_t *solution,
                              int32_t cap, int32_t *len, int *have);

@@ -437,3 +437,71 @@ def test_fused_step_device_entry_is_graph_capturable(ctx):
             board, score = nb.astype(np.int32).copy(), tot.copy()
     finally:
         ctx.set_stream(None)
+
+
+# ---------------------------------------------------------------------------------------------
+# The PRODUCTION (no score dump) instantiations at BASELINE size.  bench.py times
+# nq_scan_regs_kernel<BoardF32<64>, false>; with want_scores=True the <.., true> sibling runs, which always
+# fetches conf_old in a separate pass.  These cases run the no-score kernels and compare n_scored, best_index and
+# best_score with the oracle's count-table formulation (local_search.rs:315-325).
+
+def _check_batch_noscores(ctx, algo, rows, cols, n_cols, window):
+    ctx.set_algo(algo)
+    R, n = rows.shape
+    cur = [orc.nq_score(rows[r]) if n <= 512 else int(orc.nq_col_scores_table(rows[r]).sum()) for r in range(R)]
+    out, scores = ctx.nqueens_eval_batch(rows, cur, cols, n_cols, window, want_scores=False)
+    assert scores is None
+    for r in range(R):
+        exp = orc.nq_neighbourhood(rows[r], cols[r, :n_cols[r]], window, "table", want_scores=False)
+        got = out[r]
+        assert got["n_scored"] == exp["n_scored"], (r, got, exp)
+        assert got["best_index"] == exp["best_index"], (r, got, exp)
+        if exp["best_index"] >= 0:
+            assert got["best_score"] == exp["best_score"], (r, got, exp)
+            assert got["best_col"] == cols[r, exp["best_index"] // n]
+            assert got["best_value"] == exp["best_index"] % n
+    return out
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_bench_workload_production_path(ctx, algo):
+    # exactly bench.py's step: 8 restarts, uniform boards seeded by restart id, all n columns in order,
+    # window = n(n-1), no score dump
+    n, R = 4096, 8
+    rows = np.stack([np.random.default_rng(r).integers(0, n, size=n) for r in range(R)])
+    cols = np.tile(np.arange(n), (R, 1))
+    out = _check_batch_noscores(ctx, algo, rows, cols, np.full(R, n), n * (n - 1))
+    assert all(o["n_scored"] == n * (n - 1) for o in out)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("n,R,n_cols,window", [
+    (4096, 1, 204, 20480),            # the reference-shaped launch of config 4 (window 5n cuts the 6th column)
+    (4096, 1, 1000, 10 ** 12),        # wavefront shares of 2000 positions: most ranges start/stop inside a column
+    (4096, 3, 333, 333 * 4095 - 7),   # grid not a multiple of the restart count; window cuts the last column
+    (4095, 5, 77, 50000),             # padded lanes (n not a multiple of 64), window cut inside a column
+    (3001, 2, 64, 10 ** 12),
+    (2049, 7, 9, 5 * 2049),
+])
+def test_scan_production_path_large_n(ctx, algo, n, R, n_cols, window):
+    rng = np.random.default_rng(n * 31 + R)
+    rows = np.stack([_board(rng, n, "uniform" if r % 2 == 0 else "perm") for r in range(R)])
+    cols = np.stack([rng.integers(0, n, size=n_cols) for _ in range(R)])     # duplicates allowed
+    _check_batch_noscores(ctx, algo, rows, cols, np.full(R, n_cols), window)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_scan_production_path_own_square_at_share_boundaries(ctx, algo):
+    # rows[c] placed at the first / last value of a 64-candidate pass and of the board, and next to the positions
+    # where a wavefront's share of the candidate list starts or stops: both ways nq_scan_column_regs obtains
+    # conf_old (own square inside the range -> readlane; outside -> the extra one-step pass) must agree
+    n = 4096
+    rng = np.random.default_rng(2024)
+    rows = rng.integers(0, n, size=n)
+    special = [0, 1, 62, 63, 64, 65, 127, 128, 2047, 2048, 4031, 4032, 4094, 4095]
+    cols = rng.permutation(n)[:len(special) * 3]
+    for i, c in enumerate(cols):
+        rows[c] = special[i % len(special)]
+    for n_cols, window in ((len(cols), 10 ** 12), (len(cols), 20480), (5, 4 * 4095 + 63), (5, 4 * 4095 + 64),
+                           (5, 4 * 4095 + 65), (17, 16 * 4095 + 1), (2, 4095 + 4094), (1, 1), (1, 4095)):
+        _check_batch_noscores(ctx, algo, rows[None], cols[None, :n_cols], np.array([n_cols]), window)

@@ -246,3 +246,58 @@ def test_exhaustive_proposer_entries(ctx):
                     assert (got[r]["best_hard"], got[r]["best_soft"]) == (exp["best_hard"], exp["best_soft"])
                 if window == 10 ** 9:
                     assert exp["n_scored"] == S * (n_emp - 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# Config 5 at its launch size: 10 000 employees x 31 scored / 32 stored days, holidays U{0..3} per
+# employee.  The 320 000-move exhaustive list is the only workload that takes the second trip of the 256-chunk
+# prefix loop in sched_locate_kernel (313 chunks of 1024 moves).
+
+def _config5(ctx, seed=2022):
+    rng = np.random.default_rng(seed)
+    E, D = 10_000, 31
+    hol = {e: rng.choice(D, size=int(rng.integers(0, 4)), replace=False).tolist() for e in range(E)}
+    inst, D2, S = _upload(ctx, (2022, 5, 9), (2022, 6, 8), E, hol)
+    assert (D2, S) == (31, 32)
+    return rng, inst, E, D, S
+
+
+@pytest.mark.parametrize("window", [10 ** 9, 300_000, 270_000, 262_144 + 1, 1024 * 256, 1])
+def test_config5_exhaustive_at_launch_size(ctx, window):
+    # window 270 000 stops inside chunk 263 (second trip of the prefix loop), 262 145 in its first chunk,
+    # 262 144 = 256 * 1024 at the seam (one tabu move per day shifts the cut a few positions past the chunk edge)
+    rng, inst, E, D, S = _config5(ctx)
+    states = np.stack([rng.integers(0, E, size=S), rng.integers(0, 50, size=S)])
+    got = ctx.sched_eval_exhaustive(states, window)
+    for r in range(2):
+        moves = orc.Sched.exhaustive_moves(states[r], range(E))
+        assert len(moves) == 320_000
+        exp = inst.neighbourhood(states[r], moves, window)
+        assert got[r]["n_scored"] == exp["n_scored"] == min(window, S * (E - 1))
+        assert got[r]["best_index"] == exp["best_index"]
+        assert (got[r]["best_hard"], got[r]["best_soft"]) == (exp["best_hard"], exp["best_soft"])
+        if r == 1 and window in (10 ** 9, 270_000):
+            # the same list through the caller-supplied-moves entry (ls_sched_eval) must agree, incl. every score
+            g1, hard, soft = ctx.sched_eval(states[1], moves, window, want_scores=True)
+            assert (g1["n_scored"], g1["best_index"]) == (exp["n_scored"], exp["best_index"])
+            assert np.array_equal(hard, exp["hard"]) and np.array_equal(soft, exp["soft"])
+
+
+@pytest.mark.parametrize("window", [65_536, 10 ** 9])
+def test_config5_random_stream_at_launch_size(ctx, window):
+    # the 70 000-move random stream of bench.py's sched10k_random_stream_window_65536 line
+    rng, inst, E, D, S = _config5(ctx, seed=77)
+    for trial in range(2):
+        state = rng.integers(0, E if trial == 0 else 30, size=S)
+        moves = _random_moves(rng, 70_000, D, E if trial == 0 else 30, state)
+        exp = inst.neighbourhood(state, moves, window)
+        got, hard, soft = ctx.sched_eval(state, moves, window, want_scores=True)
+        assert got["n_scored"] == exp["n_scored"]
+        assert got["best_index"] == exp["best_index"]
+        assert (got["best_hard"], got["best_soft"]) == (exp["best_hard"], exp["best_soft"])
+        assert np.array_equal(hard, exp["hard"]) and np.array_equal(soft, exp["soft"])
+        # production shape (no score dump, resident list) agrees
+        ctx.sched_moves_upload(moves)
+        res = ctx.sched_eval_resident(state, len(moves), window)
+        assert (res["n_scored"], res["best_index"], res["best_hard"], res["best_soft"]) == \
+               (exp["n_scored"], exp["best_index"], exp["best_hard"], exp["best_soft"])

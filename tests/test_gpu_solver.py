@@ -166,6 +166,33 @@ def test_multi_restart_lockstep_equals_single_runs(ctx):
     assert o.get_best_solution() == singles[1]
 
 
+@pytest.mark.parametrize("mode,n_slots", [("lockstep", 4), ("free", 4), ("free", 16), ("lockstep", 1)])
+def test_seeds_stream_through_slots(ctx, mode, n_slots):
+    # config 4's shape in small: more seeds than slots -- a finished restart's slot takes the next seed
+    # (examples/nqueens/src/main.rs:167 seed convention) -- every restart equal to its single-solver run
+    import ls_amd
+    n, rounds = 48, 6
+    seeds = [str(s) for s in range(42, 42 + 13)]
+    p = _nq_params(n)
+    singles, iters = [], 0
+    for seed in seeds:
+        s = ls_amd.Solver.nqueens(ctx, n, seed, p)
+        for _ in range(rounds):
+            s.execute_round()
+            b = s.best()
+            if b is not None and b[0] == 0:
+                break
+        singles.append(s.best())
+        iters += s.stats()["ls_iterations"]
+        s.close()
+    m = ls_amd.MultiSolver(ctx, n, seeds, p, n_slots=n_slots, mode=mode)
+    m.run(max_rounds_per_restart=rounds)
+    assert [m.best(r) for r in range(len(seeds))] == singles
+    st = m.stats()
+    assert st["ls_iterations"] == iters
+    m.close()
+
+
 def test_c_example_program_matches_python_solver(ctx, tmp_path):
     # examples/nqueens_c.c: the reference's nqueens binary in plain C on the C ABI (no Python, no torch in the process)
     import subprocess

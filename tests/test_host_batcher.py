@@ -1,0 +1,20 @@
+"""Host logic, no GPU: the lockstep batcher of csrc/host/plugins.hpp (ls_multi_solver's launch merger) compiled against
+a fake CPU C ABI (tests/cpp/batcher_fault_test.cpp) and run under AddressSanitizer and ThreadSanitizer.  Covers the
+failure path ADVICE r1 flagged: a failing restart must not leave parked requests of unwound stacks behind."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "batcher_fault_test.cpp")
+
+
+@pytest.mark.parametrize("sanitizer", ["address,undefined", "thread"])
+def test_batcher_failure_paths_under_sanitizers(tmp_path, sanitizer):
+    exe = str(tmp_path / "batcher_fault_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-mavx2", f"-fsanitize={sanitizer}", "-fno-omit-frame-pointer", SRC, "-o", exe,
+                    "-lpthread"], check=True, capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", TSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-2000:], r.stderr[-4000:])

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""One launch set per kernel family, for `rocprofv3 --pmc ...` (tools/profile_counters.sh): the bench workload of
+each N-queens family, the solver's per-iteration step, and the scheduling launches of configs 3 and 5.  Prints the
+number of candidates each launch scores, which tools/summarise_counters.py divides the counters by.  Host-pointer
+entries only (no torch): the program runs directly under the profiler."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "constraint-solver_amd"))
+
+import numpy as np  # noqa: E402
+
+import ls_amd  # noqa: E402
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    n, R = 4096, 8
+    boards = np.stack([np.random.default_rng(r).integers(0, n, size=n) for r in range(R)]).astype(np.int32)
+    meta = {}
+    with ls_amd.Context(0) as ctx:
+        _, cur = ctx.nqueens_col_scores(boards)
+        cols = np.tile(np.arange(n, dtype=np.int32), (R, 1))
+        ncols = np.full(R, n, dtype=np.int32)
+        for algo, kernel in (("scan", "nq_scan_regs_kernel"), ("table", "nq_table_lds_kernel")):
+            ctx.set_algo(algo)
+            for _ in range(reps):
+                out, _ = ctx.nqueens_eval_batch(boards, cur, cols, ncols, n * (n - 1))
+            meta[kernel] = dict(candidates_per_launch=int(sum(o["n_scored"] for o in out)), restarts=R, n=n,
+                                workload="bench workload: 8 restarts x full n x n neighbourhood")
+        # n = 1024 scan: 32 restarts x 1024 columns
+        n2, R2 = 1024, 32
+        b2 = np.stack([np.random.default_rng(100 + r).integers(0, n2, size=n2) for r in range(R2)]).astype(np.int32)
+        _, cur2 = ctx.nqueens_col_scores(b2)
+        ctx.set_algo("scan")
+        for _ in range(reps):
+            out, _ = ctx.nqueens_eval_batch(b2, cur2, np.tile(np.arange(n2, dtype=np.int32), (R2, 1)), np.full(R2, n2, np.int32),
+                                            n2 * (n2 - 1))
+        meta["nq_scan_regs_kernel_n1024"] = dict(candidates_per_launch=int(sum(o["n_scored"] for o in out)), restarts=R2, n=n2,
+                                                  workload="32 restarts x full 1024 x 1024 neighbourhood",
+                                                  match="BoardF32<16>")
+        # the solver's per-iteration call: 204 proposed columns, window 5n -> fused step kernel (auto)
+        ctx.set_algo("auto")
+        rng = np.random.default_rng(12345)
+        mc = n // 20
+        cols_ref = np.stack([rng.permutation(n)[:mc] for _ in range(R)]).astype(np.int32)
+        for RR in (1, R):
+            for _ in range(reps):
+                out, _ = ctx.nqueens_eval_batch_next(boards[:RR], cur[:RR], cols_ref[:RR], np.full(RR, mc, np.int32), 5 * n)
+            meta[f"nq_step_kernel_r{RR}"] = dict(candidates_per_launch=int(sum(o["n_scored"] for o in out)), restarts=RR, n=n,
+                                                 workload="LS step: window 5n, 204 proposed columns", match="nq_step_kernel",
+                                                 grid_blocks=RR)
+        # scheduling, config 5 shape
+        rng = np.random.default_rng(2022)
+        D, S, E = 31, 32, 10_000
+        bits = np.zeros(E, dtype=np.uint64)
+        for e in range(E):
+            for d in rng.choice(D, size=int(rng.integers(0, 4)), replace=False):
+                bits[e] |= np.uint64(1) << np.uint64(d)
+        ctx.sched_instance_upload(D, S, 0, E, bits)
+        state = rng.integers(0, E, size=(1, S)).astype(np.int32)
+        for _ in range(reps):
+            r0 = ctx.sched_eval_exhaustive(state, 10 ** 9)[0]
+        meta["sched_eval32_kernel_exhaustive"] = dict(candidates_per_launch=int(r0["n_scored"]), workload="10 000 employees, exhaustive 32 x 10 000",
+                                                      match="sched_eval32_kernel<4, false>", grid_hint="large")
+        mv = np.zeros((70_000, 3), dtype=np.int32)
+        for i in range(len(mv)):
+            if rng.integers(0, 5) == 0:
+                mv[i] = (0, rng.integers(0, D), rng.integers(0, E))
+            else:
+                a, b = rng.choice(D, size=2, replace=False)
+                mv[i] = (1, a, b)
+        ctx.sched_moves_upload(mv)
+        for _ in range(reps):
+            r1 = ctx.sched_eval_resident(state[0], len(mv), 65_536)
+        meta["sched_eval32_kernel_random65536"] = dict(candidates_per_launch=int(r1["n_scored"]), workload="10 000 employees, random stream, window 65 536",
+                                                       match="sched_eval32_kernel<4, false>", grid_hint="small")
+    print("PMC_WORKLOADS " + json.dumps(meta))
+
+
+if __name__ == "__main__":
+    main()

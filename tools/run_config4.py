@@ -20,7 +20,9 @@ sys.path.insert(0, os.path.join(ROOT, "constraint-solver_amd"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--board-size", "--n", dest="n", type=int, default=4096)
-    ap.add_argument("--restarts-per-gpu", type=int, default=8)
+    ap.add_argument("--restarts-per-gpu", type=int, default=8, help="seeds per GPU (64 on one GPU = the whole of config 4)")
+    ap.add_argument("--slots", type=int, default=8, help="restarts in flight at once; further seeds queue behind them")
+    ap.add_argument("--mode", default="lockstep", choices=["lockstep", "free"])
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--rounds", type=int, default=10_000)
     ap.add_argument("--algo", default="auto", choices=["auto", "table", "scan"])
@@ -49,7 +51,7 @@ def main():
                   all_solutions_capacity=100_000, all_solution_iteration_expiry=10_000,
                   iterated_local_search_max_iterations=10_000, max_allow_no_improvement_for=5)
     with ls_amd.Context(local_rank, algo=args.algo) as ctx:
-        m = ls_amd.MultiSolver(ctx, args.n, seeds, params)
+        m = ls_amd.MultiSolver(ctx, args.n, seeds, params, n_slots=args.slots, mode=args.mode)
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
@@ -69,7 +71,8 @@ def main():
                               neighbours_scored=int(tot[0].item()), neighbours_per_s=tot[0].item() / tmax.item(),
                               ls_iterations=int(tot[1].item()), gpu_launches=int(tot[2].item()),
                               scores=sorted(r[0][0] for r in allr), global_best_score=best[0][0],
-                              global_best_restart=best[2], algo=args.algo)))
+                              global_best_restart=best[2], algo=args.algo, slots=args.slots, mode=args.mode,
+                              ls_iterations_per_s=tot[1].item() / tmax.item())))
     if world > 1:
         dist.destroy_process_group()
 
