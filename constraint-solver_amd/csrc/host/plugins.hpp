@@ -231,6 +231,14 @@ struct NQueensProblem {
             batcher->submit(&rq);
         } else
             check_rc(ctx, ls_nqueens_col_scores(ctx, 1, (int32_t)s.size(), rows.data(), cs.data(), &tot), "ls_nqueens_col_scores");
+        {   // fail loudly on an impossible answer: the column scores are non-negative and sum to the (even) total
+            int64_t sum = 0;
+            bool ok = true;
+            for (int64_t v : cs) { sum += v; ok = ok && v >= 0; }
+            if (!ok || sum != tot || (tot & 1))
+                throw std::runtime_error("ls_nqueens_col_scores returned inconsistent column scores (sum " + std::to_string(sum) +
+                                         ", total " + std::to_string(tot) + ")");
+        }
         if (total) *total = tot;
         cached_board = s; cached_cs.swap(cs); cached_total = tot; cache_valid = true;
         return cached_cs;
@@ -299,6 +307,20 @@ struct NQueensProblem {
         gpu_evals++;
         neighbours_scored += (uint64_t)res.n_scored;
         if (res.best_index < 0) return false;
+        {   // fail loudly on an impossible record instead of walking on from it
+            const int64_t n = (int64_t)rows.size();
+            int64_t sum = 0;
+            for (int64_t v : next_cs) sum += v;
+            const bool ok = res.best_score >= 0 && !(res.best_score & 1) && res.best_col >= 0 && res.best_col < n &&
+                            res.best_value >= 0 && res.best_value < n && res.best_index / n < (int64_t)cols.size() &&
+                            cols[(size_t)(res.best_index / n)] == res.best_col && res.best_index % n == res.best_value &&
+                            res.n_scored > 0 && res.n_scored <= (int64_t)window && sum == res.best_score;
+            if (!ok)
+                throw std::runtime_error("neighbourhood launch returned an inconsistent record: n_scored " + std::to_string(res.n_scored) +
+                                         " best_index " + std::to_string(res.best_index) + " best_score " + std::to_string(res.best_score) +
+                                         " best_col " + std::to_string(res.best_col) + " best_value " + std::to_string(res.best_value) +
+                                         " cur " + std::to_string(current.score) + " sum(next col scores) " + std::to_string(sum));
+        }
         out.solution = current.solution;
         out.solution[(size_t)res.best_col] = res.best_value; // MoveIterator, lib.rs:226-228
         out.score = res.best_score;

@@ -98,8 +98,8 @@ struct ls_ctx {
     hipStream_t stream = nullptr;
     int nq_algo = LS_NQ_ALGO_AUTO;
     int nq_step_mode = 2; // fused LS-step kernel: 0 off, 1 through device staging copies, 2 zero-copy on pinned host memory (LS_NQ_STEP)
-    // Argmin keys: every entry of nq_keys holds NQ_KEY_EMPTY whenever no N-queens call is in flight (set once,
-    // synchronously, when the buffer is allocated; the finalize kernel puts back what the eval kernels touched).
+    // Argmin keys: every entry of nq_keys holds NQ_KEY_EMPTY whenever no N-queens call is in flight (filled once, in
+    // stream order, when the buffer is allocated; the finalize kernel puts back what the eval kernels touched).
     // nq_keys_dirty is raised while a call is being queued and stays up if it failed half-way: the next call then
     // clears the keys in stream order first.
     bool nq_keys_dirty = false;

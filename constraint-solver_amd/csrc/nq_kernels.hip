@@ -1141,15 +1141,26 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
     // (Small launches are NOT routed to the one-block-per-restart step kernel here: back to back on a stream the
     // table kernel + finalize pair is faster -- 10.7 vs 12.6 us for 8 restarts x window 5n -- because its launch
     // latency pipelines; the step kernel pays off where a host round trip follows every launch, see ls_api.hip.)
-    {   // Invariant: all keys are EMPTY between calls.  A fresh buffer is filled once, synchronously (so the fill can
-        // never be "captured but not run" when the first call happens under hipGraph capture -- callers warm up
-        // before capturing, like for every other workspace); the finalize kernel restores what a call touched.
+    {   // Invariant: all keys are EMPTY between calls: a fresh buffer is filled once, in stream order, and the finalize
+        // kernel restores what a call touched.  The fill must really run, so a buffer may not be born while the stream
+        // is being captured into a hipGraph (callers warm up before capturing, like for every other workspace).
+        // (hipMemset is no alternative: it is asynchronous to the host and ordered on the NULL stream, which the
+        // context's non-blocking stream does not wait for.)
         const void *before = ctx->nq_keys.p;
         LS_RESERVE(ctx, ctx->nq_keys, (size_t)n_restarts * 8);
-        if (ctx->nq_keys.p != before) LS_HIP(ctx, hipMemset(ctx->nq_keys.p, 0xff, ctx->nq_keys.cap)); // NQ_KEY_EMPTY
-        if (ctx->nq_keys_dirty) { // an earlier call failed between its eval and finalize launches
+        const bool fresh = ctx->nq_keys.p != before;
+        if (fresh) {
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess) { (void)hipGetLastError(); st = hipStreamCaptureStatusNone; }
+            if (st != hipStreamCaptureStatusNone) {
+                ctx->nq_keys.cap = 0; // keep the buffer (it is retired on the next reserve) but never use it unfilled
+                return set_err(ctx, LS_ERR_STATE, "first N-queens launch of this size during stream capture: run one launch "
+                                                  "before capturing so that the workspaces exist");
+            }
+        }
+        if (fresh || ctx->nq_keys_dirty) { // dirty: an earlier call failed between its eval and finalize launches
             hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((ctx->nq_keys.cap / 8 + 255) / 256)), dim3(256), 0, ctx->stream,
-                               ctx->nq_keys.as<long long>(), -1ll, (long long)(ctx->nq_keys.cap / 8));
+                               ctx->nq_keys.as<long long>(), -1ll, (long long)(ctx->nq_keys.cap / 8)); // NQ_KEY_EMPTY
             LS_HIP(ctx, hipGetLastError());
         }
         ctx->nq_keys_dirty = true; // until this call's finalize is queued

@@ -135,7 +135,7 @@ def test_unvalidated_device_entry_counts_what_it_scores(algo, n):
                 torch.cuda.synchronize()
             finally:
                 ctx.set_stream(None)
-            assert res.cpu().numpy()[0, 0] == (n - 1) + 10        # slot 0 in full, slot 1 skipped, 10 of slot 2
+            assert res.cpu().numpy()[0, 0] == 2 * (n - 1)         # slots 0 and 2 in full; slots 1 and 3 (the window's last 10) are skipped
         # a row value outside [0, n) at a proposed column: that slot is skipped as well
         rows2 = rows.copy()
         rows2[0, good[1]] = n + 17

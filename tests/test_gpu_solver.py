@@ -166,11 +166,13 @@ def test_multi_restart_lockstep_equals_single_runs(ctx):
     assert o.get_best_solution() == singles[1]
 
 
+@pytest.mark.parametrize("algo", ["auto", "scan"])      # fused one-launch LS step / multi-launch chain (argmin keys + finalize)
 @pytest.mark.parametrize("mode,n_slots", [("lockstep", 4), ("free", 4), ("free", 16), ("lockstep", 1)])
-def test_seeds_stream_through_slots(ctx, mode, n_slots):
+def test_seeds_stream_through_slots(ctx, mode, n_slots, algo):
     # config 4's shape in small: more seeds than slots -- a finished restart's slot takes the next seed
     # (examples/nqueens/src/main.rs:167 seed convention) -- every restart equal to its single-solver run
     import ls_amd
+    ctx.set_algo(algo)
     n, rounds = 48, 6
     seeds = [str(s) for s in range(42, 42 + 13)]
     p = _nq_params(n)
