@@ -2,6 +2,8 @@
 // life-cycle, argument validation, host<->device staging.  Kernels live in
 // nq_kernels.hip / sched_kernels.hip.  No CPU fallback exists anywhere in this
 // library: without a HIP device ls_ctx_create fails.
+#include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -35,13 +37,15 @@ int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, lon
 bool nq_step_eligible(const ls_ctx *ctx, int n, int max_cols, long long window);
 int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long long *cur, const int *cols,
                 const int *n_cols, int max_cols, long long window, ls_nq_result *results, int *next_rows,
-                long long *next_col_scores, long long *next_totals);
+                long long *next_col_scores, long long *next_totals, const NqStepExtra *extra);
 // sched_kernels.hip
 int sched_score_dev(ls_ctx *ctx, int n_states, const int *states_d, long long *hard_d, long long *soft_d,
                     long long *terms_d);
 int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const ls_sched_move *moves_d,
                          const long long *n_moves_d, long long max_moves, long long window,
-                         ls_sched_result *results_d, long long *hard_out_d, long long *soft_out_d);
+                         ls_sched_result *results_d, long long *hard_out_d, long long *soft_out_d,
+                         unsigned long long *done_flag = nullptr, unsigned long long done_seq = 0);
+bool sched_is_fused_launch(const ls_ctx *ctx, long long max_moves);
 int sched_exhaustive_moves_dev(ls_ctx *ctx, int n_restarts, const int *states_d, ls_sched_move *moves_d, long long *n_moves_d);
 
 static void for_each_buf(ls_ctx *ctx, void (*f)(DevBuf &))
@@ -153,6 +157,9 @@ int ls_ctx_destroy(ls_ctx *ctx)
     for_each_buf(ctx, [](DevBuf &b) { b.release(); });
     ctx->stage_in.release();
     ctx->stage_out.release();
+    ctx->nq_res.dev_rows.release();
+    ctx->nq_res.counter.release();
+    if (ctx->nq_res.flag) (void)hipHostFree(ctx->nq_res.flag);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return LS_OK;
@@ -253,6 +260,97 @@ int ls_nqueens_eval_batch_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, const 
                              reinterpret_cast<long long *>(scores_out_d), nullptr);
 }
 
+// Wait for a kernel's completion word (coherent host memory) instead of synchronising the stream: the poll sees the
+// word a PCIe write after the kernel's last store, a stream synchronisation costs a runtime round trip on top.
+// Falls back to the stream (and reports its error) if the word does not arrive.
+static int wait_done_word(ls_ctx *ctx, const unsigned long long *flag, unsigned long long seq)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return LS_OK;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+        if ((spins & 0xfff) == 0xfff) {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dt > 0.002) { // far beyond any LS step: let the runtime tell whether the launch failed
+                LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return LS_OK;
+                return set_err(ctx, LS_ERR_HIP, "the LS-step kernel finished without publishing its completion word");
+            }
+        }
+    }
+}
+
+// LS_NQ_STEP=3: the fused LS step with boards resident on the device.  Inputs that cross PCIe per call: the current
+// scores, the proposed columns and -- only for a restart whose board is not the one the device already holds -- the
+// board; outputs: the result records and the winners' column scores as 16-bit values.  One launch, no stream sync.
+static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_t *rows, const int64_t *cur_scores,
+                                 const int32_t *cols, const int32_t *n_cols, int32_t max_cols, long long win,
+                                 ls_nq_result *results, int64_t *next_col_scores)
+{
+    NqResident &rs = ctx->nq_res;
+    if (!rs.flag) {
+        LS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&rs.flag), 64, hipHostMallocCoherent));
+        *rs.flag = 0;
+        LS_RESERVE(ctx, rs.counter, 256);
+        LS_HIP(ctx, hipMemsetAsync(rs.counter.p, 0, 256, ctx->stream));
+    }
+    if (rs.n != n || (int)rs.valid.size() < R) { // geometry changed: nothing on the device can be reused
+        rs.n = n;
+        rs.valid.assign((size_t)R, 0);
+        rs.shadow.resize((size_t)R * n);
+        LS_RESERVE(ctx, rs.dev_rows, (size_t)R * n * 4);
+    }
+    const size_t rows_b = (size_t)R * n * 4, cur_b = (size_t)R * 8, cols_b = (size_t)R * max_cols * 4, nc_b = (size_t)R * 4,
+                 res_b = (size_t)R * sizeof(ls_nq_result), cs_b = next_col_scores ? (size_t)R * n * 2 : 0;
+    const size_t o_cur = 0, o_cols = align256(o_cur + cur_b), o_nc = align256(o_cols + cols_b), o_rows = align256(o_nc + nc_b),
+                 in_b = align256(o_rows + rows_b);
+    const size_t o_res = 0, o_cs = align256(o_res + res_b), out_b = align256(o_cs + cs_b);
+    {
+        hipError_t e = ctx->stage_in.reserve(in_b);
+        if (e == hipSuccess) e = ctx->stage_out.reserve(out_b);
+        if (e != hipSuccess) return set_err(ctx, LS_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
+    }
+    Staging &si = ctx->stage_in, &so = ctx->stage_out;
+    unsigned long long fresh = 0;
+    for (int r = 0; r < R; r++) {
+        const int32_t *src = rows + (size_t)r * n;
+        int32_t *sh = rs.shadow.data() + (size_t)r * n;
+        if (r >= 64 || !rs.valid[(size_t)r] || memcmp(src, sh, (size_t)n * 4) != 0) {
+            memcpy(si.h<char>(o_rows) + (size_t)r * n * 4, src, (size_t)n * 4);
+            memcpy(sh, src, (size_t)n * 4);
+            rs.valid[(size_t)r] = 1;
+            if (r < 64) fresh |= 1ull << r;
+        }
+    }
+    memcpy(si.h<char>(o_cur), cur_scores, cur_b);
+    if (cols_b) memcpy(si.h<char>(o_cols), cols, cols_b);
+    memcpy(si.h<char>(o_nc), n_cols, nc_b);
+    NqStepExtra x;
+    x.fresh_mask = fresh;
+    x.resident_rows = rs.dev_rows.as<int>();
+    x.next_cs16 = cs_b ? so.h<unsigned short>(o_cs) : nullptr;
+    x.done_flag = rs.flag;
+    x.done_seq = ++rs.seq;
+    x.block_counter = rs.counter.as<unsigned>();
+    int rc = nq_step_dev(ctx, R, n, si.h<int>(o_rows), si.h<long long>(o_cur), si.h<int>(o_cols), si.h<int>(o_nc), max_cols, win,
+                         so.h<ls_nq_result>(o_res), nullptr, nullptr, nullptr, &x);
+    if (rc != LS_OK) { std::fill(rs.valid.begin(), rs.valid.end(), 0); return rc; }
+    rc = wait_done_word(ctx, rs.flag, rs.seq);
+    if (rc != LS_OK) { std::fill(rs.valid.begin(), rs.valid.end(), 0); return rc; }
+    memcpy(results, so.h<char>(o_res), res_b);
+    for (int r = 0; r < R; r++) {
+        if (results[r].best_index >= 0) rs.shadow[(size_t)r * n + (size_t)results[r].best_col] = results[r].best_value; // the device applied it
+        if (cs_b) {
+            const unsigned short *s16 = so.h<unsigned short>(o_cs) + (size_t)r * n;
+            int64_t *dst = next_col_scores + (size_t)r * n;
+            for (int j = 0; j < n; j++) dst[j] = s16[j];
+        }
+    }
+    return LS_OK;
+}
+
 // Shared host-pointer path: validate, pack the inputs into the pinned staging block (one H2D copy), run the
 // neighbourhood (+ optionally the winner's column scores), fetch results (+ column scores) with one D2H copy.
 // Only the parity-mode per-candidate score array (up to GBs) is copied separately.
@@ -296,6 +394,8 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
     if (cols_b) memcpy(si.h<char>(o_cols), cols, cols_b);
     memcpy(si.h<char>(o_nc), n_cols, nc_b);
     const long long win = nq_clamp_window(window, max_cols, n);
+    if (!sc_b && ctx->nq_step_mode >= 3 && n_restarts <= 64 && nq_step_eligible(ctx, n, max_cols, win))
+        return nq_host_step_resident(ctx, n_restarts, n, rows, cur_scores, cols, n_cols, max_cols, win, results, next_col_scores);
     if (!sc_b && ctx->nq_step_mode > 0 && nq_step_eligible(ctx, n, max_cols, win)) {
         // One LS step per restart in one launch.  Mode 2: the kernel reads the pinned staging block and writes
         // the pinned result block directly (each byte crosses PCIe once, no copy dispatches in the chain).
@@ -305,7 +405,7 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
         rc = nq_step_dev(ctx, n_restarts, n, reinterpret_cast<int *>(ib + o_rows), reinterpret_cast<long long *>(ib + o_cur),
                          reinterpret_cast<int *>(ib + o_cols), reinterpret_cast<int *>(ib + o_nc), max_cols, win,
                          reinterpret_cast<ls_nq_result *>(ob + o_res), nullptr,
-                         cs_b ? reinterpret_cast<long long *>(ob + o_cs) : nullptr, nullptr);
+                         cs_b ? reinterpret_cast<long long *>(ob + o_cs) : nullptr, nullptr, nullptr);
         if (rc != LS_OK) return rc;
         if (!zc) LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
         LS_SYNC(ctx);
@@ -351,7 +451,7 @@ int ls_nqueens_eval_batch_next_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, c
     if (ctx->nq_step_mode > 0 && nq_step_eligible(ctx, n, max_cols, win))
         return nq_step_dev(ctx, n_restarts, n, rows_d, reinterpret_cast<const long long *>(cur_scores_d), cols_d, n_cols_d,
                            max_cols, win, results_d, next_rows_d, reinterpret_cast<long long *>(next_col_scores_d),
-                           reinterpret_cast<long long *>(next_scores_d));
+                           reinterpret_cast<long long *>(next_scores_d), nullptr);
     rc = nq_eval_batch_dev(ctx, n_restarts, n, rows_d, reinterpret_cast<const long long *>(cur_scores_d), cols_d, n_cols_d,
                            max_cols, win, results_d, nullptr, next_rows_d);
     if (rc != LS_OK) return rc;
@@ -648,12 +748,26 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
     // (LS_SCHED_ZEROCOPY=0 restores the two staging copies), so the chain is kernels only.
     const bool zc = ctx->sched_zero_copy && n_moves <= 4096; // many blocks re-reading the state over PCIe cost more than the copies
     if (!zc) LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
+    // one-block fused launch on pinned memory: poll a completion word instead of synchronising the stream
+    const bool poll = zc && sched_is_fused_launch(ctx, n_moves);
+    NqResident &rs = ctx->nq_res; // the context's completion word is shared with the N-queens LS step (one call at a time per context)
+    if (poll && !rs.flag) {
+        LS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&rs.flag), 64, hipHostMallocCoherent));
+        *rs.flag = 0;
+        LS_RESERVE(ctx, rs.counter, 256);
+        LS_HIP(ctx, hipMemsetAsync(rs.counter.p, 0, 256, ctx->stream));
+    }
     rc = sched_eval_batch_dev(ctx, 1, zc ? si.h<int>(o_st) : si.d<int>(o_st), ctx->sc_resident_moves.as<ls_sched_move>(),
                               zc ? si.h<long long>(o_nm) : si.d<long long>(o_nm), n_moves, window,
-                              zc ? so.h<ls_sched_result>(0) : so.d<ls_sched_result>(0), nullptr, nullptr);
+                              zc ? so.h<ls_sched_result>(0) : so.d<ls_sched_result>(0), nullptr, nullptr,
+                              poll ? rs.flag : nullptr, poll ? ++rs.seq : 0);
     if (rc != LS_OK) return rc;
     if (!zc) LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
-    LS_SYNC(ctx);
+    if (poll) {
+        rc = wait_done_word(ctx, rs.flag, rs.seq);
+        if (rc != LS_OK) return rc;
+    } else
+        LS_SYNC(ctx);
     *out = *so.h<ls_sched_result>(0);
     return LS_OK;
 }

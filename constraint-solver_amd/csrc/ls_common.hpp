@@ -81,7 +81,32 @@ struct Staging {
     template <class T> T *d(size_t off) const { return reinterpret_cast<T *>(static_cast<char *>(dev) + off); }
 };
 
+// Optional extras of the host-pointer route (all nullable): boards resident on the device between calls, 16-bit column
+// scores on the wire (a column score is < 3n <= 24576 for n <= NQ_STEP_MAX_N) and a completion word in coherent host
+// memory that the caller polls instead of synchronising the stream.
+struct NqStepExtra {
+    unsigned long long fresh_mask; // bit r set: restart r's board comes from a.rows; clear: from resident_rows (n_restarts <= 64)
+    int *resident_rows;           // [n_restarts][n] device copy; receives the winner board
+    unsigned short *next_cs16;    // [n_restarts][n]
+    unsigned long long *done_flag; // host word <- done_seq once every block's outputs are visible to the host
+    unsigned long long done_seq;
+    unsigned *block_counter;      // device word, zero between launches
+};
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Boards the fused LS step keeps on the device between host-pointer calls (LS_NQ_STEP=3): `shadow` is the host's copy
+// of what the device holds, so a call whose board equals it uploads nothing; the kernel leaves the winner board in
+// `dev_rows` and the host applies the same move to the shadow.
+struct NqResident {
+    int n = 0;
+    std::vector<int32_t> shadow; // [slots][n]
+    std::vector<char> valid;     // [slots]
+    DevBuf dev_rows;             // [slots][n]
+    DevBuf counter;              // completion-word block counter (one u32, zero between launches)
+    unsigned long long *flag = nullptr; // hipHostMalloc'd coherent word the kernel publishes done_seq to
+    unsigned long long seq = 0;
+};
 
 struct SchedInstance {
     bool valid = false;
@@ -97,7 +122,8 @@ struct ls_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int nq_algo = LS_NQ_ALGO_AUTO;
-    int nq_step_mode = 2; // fused LS-step kernel: 0 off, 1 through device staging copies, 2 zero-copy on pinned host memory (LS_NQ_STEP)
+    int nq_step_mode = 3; // fused LS-step kernel (LS_NQ_STEP): 0 off, 1 through device staging copies, 2 zero-copy on pinned host memory +
+                          // stream sync, 3 = 2 + boards resident on the device, 16-bit column scores on the wire, polled completion word
     // Argmin keys: every entry of nq_keys holds NQ_KEY_EMPTY whenever no N-queens call is in flight (filled once, in
     // stream order, when the buffer is allocated; the finalize kernel puts back what the eval kernels touched).
     // nq_keys_dirty is raised while a call is being queued and stays up if it failed half-way: the next call then
@@ -120,6 +146,7 @@ struct ls_ctx {
     lsamd::SchedInstance sched;
     lsamd::DevBuf sc_resident_moves; // ls_sched_moves_upload
     lsamd::Staging stage_in, stage_out;
+    lsamd::NqResident nq_res;
     long long sc_resident_n = 0;
 };
 

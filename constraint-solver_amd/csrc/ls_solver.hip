@@ -28,8 +28,8 @@ struct ls_multi_solver {
     std::vector<std::string> seeds;
     std::vector<ScoredSolution<NQueensProblem>> best;
     std::vector<int> have;
-    int n_slots = 8;              // restarts in flight at once (host threads); further seeds queue behind them
-    int mode = LS_MULTI_LOCKSTEP; // LS_MULTI_LOCKSTEP: one batched launch per step; LS_MULTI_FREE_RUNNING: a context per slot
+    int n_slots = 16;                 // restarts in flight at once (host threads); further seeds queue behind them
+    int mode = LS_MULTI_FREE_RUNNING; // LS_MULTI_FREE_RUNNING: a context per slot; LS_MULTI_LOCKSTEP: one batched launch per step
     uint64_t ls_iterations = 0, neighbours_scored = 0, gpu_launches = 0, rounds = 0;
 };
 
@@ -236,6 +236,8 @@ int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_r
         }
         m->best.resize((size_t)n_restarts);
         m->have.assign((size_t)n_restarts, 0);
+        const unsigned hw = std::thread::hardware_concurrency(); // a slot is a host thread that spins while its launch runs
+        if (hw >= 2 && (unsigned)m->n_slots > hw) m->n_slots = (int)hw;
         *out = m.release();
         return LS_OK;
     });

@@ -889,7 +889,7 @@ constexpr int NQ_STEP_MAX_SLOTS = 1024;
 __device__ __forceinline__ void tab16_dec(unsigned *t, int idx) { atomicSub(&t[idx >> 1], 1u << (16 * (idx & 1))); }
 
 __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *results, int *next_rows,
-                                                       long long *next_col_scores, long long *next_totals)
+                                                       long long *next_col_scores, long long *next_totals, NqStepExtra x)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[]; // tables (packed u16: R[n] | A[2n] | B[2n]) | rows[n] | slot records[n_slots]
     __shared__ unsigned long long s_best[16];
@@ -900,7 +900,8 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
     unsigned *s_t16 = s_dyn;
     int *s_rows = reinterpret_cast<int *>(s_dyn + words);
     int4 *s_slot = reinterpret_cast<int4 *>(s_rows + ((n + 3) & ~3)); // {column, its row, conf(column, row), -}
-    const int *__restrict__ rows = a.rows + (long long)r * n;
+    const bool from_resident = x.resident_rows != nullptr && r < 64 && !((x.fresh_mask >> r) & 1ull);
+    const int *__restrict__ rows = from_resident ? x.resident_rows + (long long)r * n : a.rows + (long long)r * n;
     const int *__restrict__ cols = a.cols + (long long)r * a.max_cols;
     // every global (possibly PCIe) read of the kernel is issued here, back to back: one latency, not three
     int rv[NQ_STEP_MAX_N / 1024];
@@ -1006,7 +1007,9 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
         int sc = 0;
         if ((unsigned)q < (unsigned)n) sc = tab16_get(s_t16, q) + tab16_get(s_t16, oA + q - j + n) + tab16_get(s_t16, oB + q + j) - 3;
         if (next_col_scores) next_col_scores[(long long)r * n + j] = sc;
+        if (x.next_cs16) x.next_cs16[(long long)r * n + j] = (unsigned short)sc;
         if (next_rows) next_rows[(long long)r * n + j] = q;
+        if (x.resident_rows) x.resident_rows[(long long)r * n + j] = q;
         local += sc;
     }
     if (next_totals) { // block-uniform
@@ -1017,6 +1020,20 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
             long long t = 0;
             for (int i = 0; i < 16; i++) t += s_sum[i];
             next_totals[r] = t;
+        }
+    }
+    if (x.done_flag) { // block-uniform
+        // Completion word: every block makes its outputs (host memory) visible at system scope, then counts itself;
+        // the block that counts last publishes the sequence number.  __syncthreads orders the other wavefronts'
+        // stores before thread 0's release fence.
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence_system();
+            const unsigned done = __hip_atomic_fetch_add(x.block_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (done == gridDim.x - 1) {
+                __hip_atomic_store(x.block_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(x.done_flag, x.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -1271,7 +1288,7 @@ bool nq_step_eligible(const ls_ctx *ctx, int n, int max_cols, long long window)
 // Pointers may be device memory or pinned host memory (each input is read once, each output written once).
 int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long long *cur, const int *cols,
                 const int *n_cols, int max_cols, long long window, ls_nq_result *results, int *next_rows,
-                long long *next_col_scores, long long *next_totals)
+                long long *next_col_scores, long long *next_totals, const NqStepExtra *extra)
 {
     NqArgs a;
     a.rows = rows; a.cur_scores = cur; a.cols = cols; a.n_cols = n_cols;
@@ -1286,8 +1303,11 @@ int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long 
     long long slots = (long long)max_cols;
     if (window / (n - 1) < max_cols) slots = window / (n - 1) + 1;
     const size_t lds = ((((size_t)(5 * n + 1) / 2 + 3) & ~(size_t)3) + (((size_t)n + 3) & ~(size_t)3) + 4 * (size_t)slots) * 4;
+    NqStepExtra x;
+    if (extra) x = *extra;
+    else { x.fresh_mask = ~0ull; x.resident_rows = nullptr; x.next_cs16 = nullptr; x.done_flag = nullptr; x.done_seq = 0; x.block_counter = nullptr; }
     hipLaunchKernelGGL(nq_step_kernel, dim3(n_restarts), dim3(1024), lds, ctx->stream, a, results, next_rows, next_col_scores,
-                       next_totals);
+                       next_totals, x);
     LS_HIP(ctx, hipGetLastError());
     return LS_OK;
 }

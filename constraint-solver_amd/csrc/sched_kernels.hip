@@ -201,6 +201,8 @@ struct SchedEvalArgs {
     long long *part_idx; // [n_restarts][blocks_per_restart] and its move index
     long long *hard_out, *soft_out; // nullable [n_restarts][max_moves]
     ls_sched_result *results;       // written by pass 2 itself when blocks_per_restart == 1
+    unsigned long long *done_flag;  // nullable; fused one-restart launch only: host word <- done_seq after the result record
+    unsigned long long done_seq;
 };
 
 __device__ __forceinline__ bool sched_move_ok(int type, int a, int b, int S, int E)
@@ -513,6 +515,10 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_kernel(SchedEvalArgs a)
             }
         if (FUSED) {
             sched_write_result_n(a, r, best_key, best_idx, n_scored_f);
+            if (a.done_flag) { // the caller polls this word instead of synchronising the stream (one restart, one block)
+                __threadfence_system();
+                __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         } else if (a.blocks_per_restart == 1) {
             sched_write_result(a, r, best_key, best_idx);
         } else {
@@ -745,6 +751,10 @@ __global__ __launch_bounds__(64 * NW) void sched_eval32_kernel(SchedEvalArgs a)
             }
         if (FUSED) {
             sched_write_result_n(a, r, best_key, best_idx, n_scored_f);
+            if (a.done_flag) { // the caller polls this word instead of synchronising the stream (one restart, one block)
+                __threadfence_system();
+                __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         } else if (a.blocks_per_restart == 1) {
             sched_write_result(a, r, best_key, best_idx);
         } else {
@@ -845,9 +855,17 @@ int sched_exhaustive_moves_dev(ls_ctx *ctx, int n_restarts, const int *states_d,
     return LS_OK;
 }
 
+bool sched_is_fused_launch(const ls_ctx *ctx, long long max_moves)
+{
+    const long long n_chunks = max_moves > 0 ? (max_moves + SC_COUNT_CHUNK - 1) / SC_COUNT_CHUNK : 1;
+    const long long batches = max_moves > 0 ? (max_moves + 63) / 64 : 1;
+    return n_chunks == 1 && batches * 4 <= 2 * SC_FUSED_WAVES && ctx->sched_fused;
+}
+
 int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const ls_sched_move *moves_d,
                          const long long *n_moves_d, long long max_moves, long long window,
-                         ls_sched_result *results_d, long long *hard_out_d, long long *soft_out_d)
+                         ls_sched_result *results_d, long long *hard_out_d, long long *soft_out_d,
+                         unsigned long long *done_flag, unsigned long long done_seq)
 {
     if (ctx->sched.n_employees > 32768)
         return set_err(ctx, LS_ERR_UNSUPPORTED, "n_employees = %d exceeds the 15-bit argmin key field (32768)",
@@ -880,6 +898,8 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
     a.chunk_counts = reinterpret_cast<int *>(a.part_idx + parts);
     a.hard_out = hard_out_d; a.soft_out = soft_out_d;
     a.results = results_d;
+    a.done_flag = (n_restarts == 1 && sched_is_fused_launch(ctx, max_moves)) ? done_flag : nullptr;
+    a.done_seq = done_seq;
     const long long total = (long long)n_restarts * max_moves;
     const unsigned fill_grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (hard_out_d && total > 0) {

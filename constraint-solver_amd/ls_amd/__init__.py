@@ -327,7 +327,7 @@ class MultiSolver:
 
     MODES = {"lockstep": 0, "free": 1}
 
-    def __init__(self, ctx: Context, board_size: int, seeds, params: dict, n_slots: int | None = None, mode: str = "lockstep"):
+    def __init__(self, ctx: Context, board_size: int, seeds, params: dict, n_slots: int | None = None, mode: str | None = None):
         self._ctx, self._l, self.n, self.seeds = ctx, ctx._l, int(board_size), [str(s) for s in seeds]
         arr = (C.c_char_p * len(self.seeds))(*[s.encode() for s in self.seeds])
         h = C.c_void_p()
@@ -335,8 +335,8 @@ class MultiSolver:
         ctx._check(self._l.ls_multi_solver_create_nqueens(ctx._h, self.n, len(self.seeds), C.cast(arr, C.c_void_p),
                                                           C.byref(p), C.byref(h)))
         self._h = h
-        if n_slots is not None or mode != "lockstep":
-            ctx._check(self._l.ls_multi_solver_configure(h, int(n_slots or 8), self.MODES[mode]))
+        if n_slots is not None or mode is not None:
+            ctx._check(self._l.ls_multi_solver_configure(h, int(n_slots or 16), self.MODES[mode or "free"]))
 
     def run(self, max_rounds_per_restart=2 ** 62, max_seconds=0.0):
         self._ctx._check(self._l.ls_multi_solver_run(self._h, int(max_rounds_per_restart), float(max_seconds)))

@@ -310,10 +310,10 @@ int ls_solver_free(ls_solver *s);
  * on a host thread; n_slots of them are in flight at once and a finished restart's slot takes the next seed of
  * the list, so the GPU stays fed while restarts need very different numbers of iterations.  The result of
  * every restart is identical to running it alone with ls_solver_*.  Two ways to serve the slots' GPU requests:
- *   LS_MULTI_LOCKSTEP      (default) the slots' requests of one step are merged into ONE batched launch on the
- *                          caller's context (ls_nqueens_eval_batch_next / ls_nqueens_col_scores);
- *   LS_MULTI_FREE_RUNNING  every slot owns a context (stream + pinned staging block) on the same device and
- *                          issues its own one-restart launches; no slot ever waits for another.
+ *   LS_MULTI_FREE_RUNNING  (default) every slot owns a context (stream + pinned staging block) on the same device
+ *                          and issues its own one-restart launches; no slot ever waits for another;
+ *   LS_MULTI_LOCKSTEP      the slots' requests of one step are merged into ONE batched launch on the caller's
+ *                          context (ls_nqueens_eval_batch_next / ls_nqueens_col_scores).
  * ls_multi_solver_run drives all restarts until each is finished, has found a best-possible solution, or a
  * limit is reached (restarts not started before max_seconds elapsed report have = 0). */
 #define LS_MULTI_LOCKSTEP      0
@@ -321,7 +321,7 @@ int ls_solver_free(ls_solver *s);
 typedef struct ls_multi_solver ls_multi_solver;
 int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_restarts, const char *const *seeds,
                                    const ls_solver_params *params, ls_multi_solver **out);
-/* n_slots in [1, 256] (default 8), mode as above; call before ls_multi_solver_run. */
+/* n_slots in [1, 256] (default: 16, at most the host's hardware threads), mode as above; call before ls_multi_solver_run. */
 int ls_multi_solver_configure(ls_multi_solver *m, int32_t n_slots, int32_t mode);
 int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, double max_seconds);
 int ls_multi_solver_get_best(const ls_multi_solver *m, int32_t restart, int64_t score[2], int64_t *solution,

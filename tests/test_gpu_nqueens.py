@@ -334,10 +334,11 @@ def _expect_step(rows, cols, n_cols, window):
     return out
 
 
-@pytest.mark.parametrize("mode", ["2", "1", "0"])
+@pytest.mark.parametrize("mode", ["3", "2", "1", "0"])
 def test_fused_step_kernel_matches_oracle(monkeypatch, mode):
     # the solver's per-iteration launch: one block per restart does tables + argmin + move + column scores.
-    # LS_NQ_STEP: 2 = zero-copy on pinned host memory (default), 1 = through staging copies, 0 = multi-launch path
+    # LS_NQ_STEP: 3 = zero-copy + resident boards + 16-bit column scores + polled completion word (default),
+    # 2 = zero-copy on pinned host memory + stream sync, 1 = through staging copies, 0 = multi-launch path
     import ls_amd
     monkeypatch.setenv("LS_NQ_STEP", mode)
     rng = np.random.default_rng(100 + int(mode))
@@ -363,6 +364,46 @@ def test_fused_step_kernel_matches_oracle(monkeypatch, mode):
                     assert out[r]["best_col"] == cols[r][exp["best_index"] // n]
                     assert out[r]["best_value"] == exp["best_index"] % n
                 assert np.array_equal(nxt[r], cs), (n, r)
+
+
+def test_fused_step_resident_boards_follow_any_call_sequence():
+    # LS_NQ_STEP=3 keeps every restart's winner board on the device and uploads a board only when the caller's differs
+    # from it.  Whatever the caller does next -- continue from the winner (local_search.rs:335), jump to an unrelated
+    # board (perturbation, iterated_local_search.rs:192-194), change the batch size or the board size, repeat a call --
+    # each call must equal a stateless evaluation.
+    import ls_amd
+    rng = np.random.default_rng(333)
+    with ls_amd.Context(0) as c:
+        def call(rows, cols, n_cols, window):
+            cur = [int(orc.nq_col_scores_table(rows[r]).sum()) for r in range(len(rows))]
+            out, nxt = c.nqueens_eval_batch_next(rows, cur, cols, n_cols, window)
+            boards = []
+            for r, (exp, board, cs) in enumerate(_expect_step(rows, cols, n_cols, window)):
+                assert (out[r]["n_scored"], out[r]["best_index"]) == (exp["n_scored"], exp["best_index"]), r
+                if exp["best_index"] >= 0:
+                    assert out[r]["best_score"] == exp["best_score"]
+                assert np.array_equal(nxt[r], cs), r
+                boards.append(board)
+            return np.stack(boards)
+
+        for n, R, mc in ((300, 3, 5), (4096, 2, 204), (300, 5, 5), (64, 1, 3)):
+            window = 5 * n
+            rows = np.stack([_board(rng, n, "uniform") for _ in range(R)])
+            for it in range(12):
+                cols = np.stack([rng.permutation(n)[:mc] for _ in range(R)])
+                n_cols = rng.integers(1, mc + 1, size=R)
+                nxt = call(rows, cols, n_cols, window)
+                what = it % 4
+                if what == 0 or what == 1:
+                    rows = nxt                                    # continue from the winners: nothing is uploaded
+                elif what == 2:
+                    rows = nxt.copy()
+                    rows[rng.integers(0, R)] = _board(rng, n, "perm")   # one restart perturbed, the others continue
+                else:
+                    pass                                          # the same boards again (the device holds the winners!)
+            # an empty neighbourhood leaves the resident board as it is
+            call(rows, np.zeros((R, 1), dtype=np.int64), np.zeros(R, dtype=np.int64), window)
+            call(rows, np.stack([rng.permutation(n)[:mc] for _ in range(R)]), np.full(R, mc), window)
 
 
 def test_fused_step_device_entry(ctx):

@@ -150,11 +150,15 @@ def test_multi_restart_lockstep_equals_single_runs(ctx):
                 break
         singles.append(s.best())
         s.close()
-    m = ls_amd.MultiSolver(ctx, n, seeds, p)
+    m = ls_amd.MultiSolver(ctx, n, seeds, p, n_slots=len(seeds), mode="lockstep")
     m.run(max_rounds_per_restart=rounds)
     assert [m.best(r) for r in range(len(seeds))] == singles
     st = m.stats()
     assert st["gpu_launches"] < 2 * st["ls_iterations"]            # launches are shared between restarts
+    m.close()
+    m = ls_amd.MultiSolver(ctx, n, seeds, p)                        # the default: free-running slots
+    m.run(max_rounds_per_restart=rounds)
+    assert [m.best(r) for r in range(len(seeds))] == singles
     m.close()
     # oracle cross-check of one of them
     o = lo.IteratedLocalSearch(lo.NQueens(n), p, seeds[1])
