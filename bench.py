@@ -305,7 +305,7 @@ def build_report(args, world, R, n, info, value, elapsed, avg_launch_s, neighbou
     counters = load_counters()
     traffic = counters.get("hbm_traffic", {}).get(f"nq_{args.algo}_n{n}_r{R}", {}).get("bytes_per_launch")
     kernel = ("nq_scan_regs_kernel<BoardF32<64>, false>" if (args.algo == "scan" and 2048 < n <= 4096)
-              else ("nq_table_lds_kernel" if args.algo == "table" else "nq_scan_*"))
+              else ("nq_table_teams_kernel" if args.algo == "table" else "nq_scan_*"))
     # VALU-issue roofline of the scan kernel: per neighbour every lane runs 4 full-rate fp32
     # instructions (sub, sub, mul+clamp, add) for each of its ceil64(n)/64 columns; achieved counts ONLY those
     # algorithmic instructions (measured SQ_INSTS_VALU per neighbour is in counters.*), peak is the spec issue rate.
@@ -546,7 +546,7 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info):
                                                      ncols_full.data_ptr(), n, n * (n - 1), res_d.data_ptr()),
                   5 if algo == "scan" else 50)
         out[f"{algo}_full_neighbourhood"] = {"neighbours_per_s": R * n * (n - 1) / s, "ms_per_launch": s * 1e3,
-                                             "roofline": issue_roofline("nq_scan_regs_kernel" if algo == "scan" else "nq_table_lds_kernel", s)}
+                                             "roofline": issue_roofline("nq_scan_regs_kernel" if algo == "scan" else "nq_table_teams_kernel", s)}
         w = 5 * n
         s = timed(lambda: ctx.nqueens_eval_batch_dev(R, n, rows_d.data_ptr(), cur_d.data_ptr(), cols_ref.data_ptr(),
                                                      ncols_ref.data_ptr(), mc, w, res_d.data_ptr()), 200)

@@ -131,6 +131,7 @@ int ls_ctx_create(int device_id, ls_ctx **out)
     ctx->stream = ctx->own_stream;
     if (const char *v = getenv("LS_NQ_SCAN_VARIANT")) ctx->nq_scan_variant = atoi(v);
     if (const char *v = getenv("LS_NQ_STEP")) ctx->nq_step_mode = atoi(v);
+    if (const char *v = getenv("LS_NQ_TABLE_VARIANT")) ctx->nq_table_variant = atoi(v);
     if (const char *v = getenv("LS_SCHED_ZEROCOPY")) ctx->sched_zero_copy = atoi(v) != 0;
     if (const char *v = getenv("LS_SCHED_FUSED")) ctx->sched_fused = atoi(v) != 0;
     ctx->sched_force_64 = getenv("LS_SCHED_FORCE_64") != nullptr;

@@ -132,6 +132,9 @@ struct ls_ctx {
     bool sched_zero_copy = true; // ls_sched_eval_resident: kernels work on the pinned staging blocks directly (LS_SCHED_ZEROCOPY)
     bool sched_fused = true;     // small scheduling launches: locate + eval + reduce in one kernel (LS_SCHED_FUSED)
     bool sched_force_64 = false; // LS_SCHED_FORCE_64: use the full-wavefront scheduling kernel even for <= 32 days
+    int nq_table_variant = 24; // TABLE family (LS_NQ_TABLE_VARIANT): 0 per-range kernel; 1/2/4 column teams of 256 lanes per block;
+                               // 11/12/14 the same with two candidates per lane and LDS look-up (even n >= 512); 21/22/24 (default)
+                               // two candidates per lane and look-up, one wavefront per column
     int nq_scan_variant = 0; // register-scan formulation: 0 auto (fp32), 1 packed u16 (LS_NQ_SCAN_VARIANT)
     int n_cus = 0;
     int wave_size = 0;

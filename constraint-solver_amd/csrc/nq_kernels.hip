@@ -733,6 +733,356 @@ __global__ __launch_bounds__(256) void nq_table_lds_kernel(NqArgs a)
     }
 }
 
+// TABLE, column-team formulation (256 <= n <= NQ_TABLE_LDS_MAX_N): the default for every launch that holds whole columns.
+// Why the per-range loops above run at 0.3 of their issue bound (rocprofv3 counters, profiles/): a candidate is three
+// DEPENDENT-on-nothing LDS look-ups, but the loops have data-dependent trip counts (the column is split at rows[c]), so
+// only one candidate per lane is in flight; and every column starts with two dependent global loads (cols[slot],
+// rows[c]).  Here instead
+//  * the block first turns its slot range into LDS records {column, its row, conf_old} (one pass, loads in flight together);
+//  * a TEAM of 256 lanes owns one (slot, part) unit at a time; lane t walks v = t + 256 i.  Within one slot the (score, board)
+//    order is (count, v) -- every "down" value is below every "up" value -- so ONE 32-bit running minimum of (count << 15 | v)
+//    per unit is exact; the direction bit is recovered from v when the minimum is widened to the 64-bit key;
+//  * the walk is unrolled by four with immediate LDS offsets: 12 look-ups in flight, v_add3 + v_lshl_or + half a v_min3 per
+//    candidate;
+//  * the no-op (v == rows[c], tabu) is not tested per candidate: its key value is known ((conf_old + 3) << 15 | rows[c]), keys of
+//    one unit are distinct, so a lane re-walks its values with the test only if its minimum IS that value.
+// A slot cut by the window (at most one per restart) is scored by the last block with the per-range loops.
+constexpr int NQ_REC_CAP = 256; // slot records per pass
+
+template <int TEAMS, bool WANT_SCORES>
+__global__ __launch_bounds__(256 * TEAMS) void nq_table_teams_kernel(NqArgs a, int parts)
+{
+    extern __shared__ unsigned s_t16[]; // packed u16: cntR[0..n) | cntA[0..2n) | cntB[0..2n), then int4 records [NQ_REC_CAP]
+    __shared__ unsigned long long s_best[4 * TEAMS];
+    constexpr int NT = 256 * TEAMS;
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    const int team = tid >> 8, tv = tid & 255;
+    const int restart = blockIdx.x % a.n_restarts;
+    const int chunk = blockIdx.x / a.n_restarts;
+    const int n_chunks = gridDim.x / a.n_restarts;
+    const int n = a.n;
+    const int *__restrict__ rows = a.rows + (long long)restart * n;
+    const int *__restrict__ cols = a.cols + (long long)restart * a.max_cols;
+    int ncols = a.n_cols[restart];
+    ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
+    // slots [0, n_whole) lie entirely inside the window; slot n_whole (if it exists) holds the window's last `rem` candidates
+    long long n_whole = a.window / (n - 1);
+    if (n_whole > ncols) n_whole = ncols;
+    const long long rem = n_whole < ncols ? a.window - n_whole * (n - 1) : 0;
+    const long long units = n_whole * parts;
+    const long long u0 = units * chunk / n_chunks, u1 = units * (chunk + 1) / n_chunks;
+    const bool do_partial = rem > 0 && chunk == n_chunks - 1;
+    unsigned long long best = NQ_KEY_EMPTY;
+    if (u0 < u1 || do_partial) { // block-uniform
+        const int words = (((5 * n + 1) >> 1) + 3) & ~3;
+        int4 *s_rec = reinterpret_cast<int4 *>(s_t16 + words);
+        for (int i = tid; i < words; i += NT) s_t16[i] = 0;
+        __syncthreads();
+        for (int j = tid; j < n; j += NT) {
+            const int q = rows[j];
+            if ((unsigned)q < (unsigned)n) {
+                tab16_inc(s_t16, q);
+                tab16_inc(s_t16, n + (q - j + n));
+                tab16_inc(s_t16, 3 * n + (q + j));
+            }
+        }
+        __syncthreads();
+        const unsigned short *t16 = reinterpret_cast<const unsigned short *>(s_t16);
+        const int oA = n, oB = 3 * n;
+        const long long cur = WANT_SCORES ? a.cur_scores[restart] : 0;
+        const int per_part = (((n + 255) >> 8) + parts - 1) / parts; // 256-value steps per part
+        const int slot_lo = (int)(u0 / parts);
+        const int slot_hi = u0 < u1 ? (int)((u1 - 1) / parts) : slot_lo - 1; // inclusive
+        for (int pass_lo = slot_lo; pass_lo <= slot_hi; pass_lo += NQ_REC_CAP) {
+            const int pass_hi = pass_lo + NQ_REC_CAP - 1 < slot_hi ? pass_lo + NQ_REC_CAP - 1 : slot_hi;
+            __syncthreads(); // the previous pass's records are no longer read
+            for (int sl = pass_lo + tid; sl <= pass_hi; sl += NT) {
+                const int c = cols[sl];
+                const int rc = (unsigned)c < (unsigned)n ? rows[c] : -1;
+                int conf_old = 0;
+                if ((unsigned)rc < (unsigned)n) conf_old = (int)t16[rc] + (int)t16[oA + rc - c + n] + (int)t16[oB + rc + c] - 3;
+                s_rec[sl - pass_lo] = make_int4(c, (unsigned)rc < (unsigned)n ? rc : -1, conf_old, 0);
+            }
+            __syncthreads();
+            long long ua = (long long)pass_lo * parts, ub = (long long)(pass_hi + 1) * parts;
+            ua = ua < u0 ? u0 : ua;
+            ub = ub > u1 ? u1 : ub;
+            for (long long u = ua + team; u < ub; u += TEAMS) { // team-uniform
+                const int slot = (int)(u / parts), part = (int)(u - (long long)slot * parts);
+                const int4 rec = s_rec[slot - pass_lo];
+                const int c = rec.x, rc = rec.y, conf_old = rec.z;
+                if (rc < 0) continue; // unvalidated device-pointer input: the slot is skipped (nq_slot_scored)
+                const int i0 = part * per_part;
+                int i1 = i0 + per_part;
+                const int steps = (n + 255) >> 8;
+                i1 = i1 > steps ? steps : i1;
+                const int full = n >> 8; // steps in which every lane's v is < n
+                const int i1f = i1 < full ? i1 : full;
+                const unsigned short *pR = t16 + tv, *pA = t16 + oA + tv - c + n, *pB = t16 + oB + tv + c;
+                long long *srow = WANT_SCORES ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
+                unsigned m = NQ_KEY32_EMPTY;
+                int i = i0;
+#define LS_CAND(J)                                                                                              \
+    const int v##J = tv + ((i + J) << 8);                                                                       \
+    const unsigned k##J = (((unsigned)pR[(i + J) << 8] + (unsigned)pA[(i + J) << 8] + (unsigned)pB[(i + J) << 8]) << 15) | (unsigned)v##J;
+                for (; i + 4 <= i1f; i += 4) {
+                    LS_CAND(0) LS_CAND(1) LS_CAND(2) LS_CAND(3)
+                    unsigned m01 = k0 < k1 ? k0 : k1, m23 = k2 < k3 ? k2 : k3;
+                    m01 = m01 < m23 ? m01 : m23;
+                    m = m01 < m ? m01 : m;
+                    if (WANT_SCORES) {
+                        if (v0 != rc) srow[v0] = cur + 2ll * ((int)(k0 >> 15) - conf_old);
+                        if (v1 != rc) srow[v1] = cur + 2ll * ((int)(k1 >> 15) - conf_old);
+                        if (v2 != rc) srow[v2] = cur + 2ll * ((int)(k2 >> 15) - conf_old);
+                        if (v3 != rc) srow[v3] = cur + 2ll * ((int)(k3 >> 15) - conf_old);
+                    }
+                }
+                for (; i < i1; i++) {
+                    const int v0 = tv + (i << 8);
+                    if (v0 < n) {
+                        const unsigned k0 = (((unsigned)pR[i << 8] + (unsigned)pA[i << 8] + (unsigned)pB[i << 8]) << 15) | (unsigned)v0;
+                        m = k0 < m ? k0 : m;
+                        if (WANT_SCORES && v0 != rc) srow[v0] = cur + 2ll * ((int)(k0 >> 15) - conf_old);
+                    }
+                }
+#undef LS_CAND
+                const unsigned noop = ((unsigned)(conf_old + 3) << 15) | (unsigned)rc;
+                if (m == noop) { // this lane's minimum is the tabu square itself: walk again without it
+                    m = NQ_KEY32_EMPTY;
+                    for (int i2 = i0; i2 < i1; i2++) {
+                        const int v0 = tv + (i2 << 8);
+                        if (v0 < n && v0 != rc) {
+                            const unsigned k0 = (((unsigned)pR[i2 << 8] + (unsigned)pA[i2 << 8] + (unsigned)pB[i2 << 8]) << 15) | (unsigned)v0;
+                            m = k0 < m ? k0 : m;
+                        }
+                    }
+                }
+                if (m != NQ_KEY32_EMPTY) {
+                    const int v = (int)(m & 0x7fffu);
+                    best = u64min(best, nq_key((int)(m >> 15) - conf_old, nq_key_hi(v > rc ? 1 : 0, c, n, slot), v));
+                }
+            }
+        }
+        if (do_partial) { // the slot the window cuts: per-range loops, all lanes of the block
+            const int slot = (int)n_whole;
+            const int c = cols[slot];
+            const int rc = (unsigned)c < (unsigned)n ? rows[c] : -1;
+            if ((unsigned)rc < (unsigned)n) {
+                const NqRanges rg = nq_ranges(0, n, rc, (long long)slot * (n - 1), a.window);
+                const int conf_old = (int)t16[rc] + (int)t16[oA + rc - c + n] + (int)t16[oB + rc + c] - 3;
+                long long *srow = WANT_SCORES ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
+                unsigned m = NQ_KEY32_EMPTY;
+                for (int v = rg.d0 + tid; v < rg.d1; v += NT) {
+                    const unsigned k = (((unsigned)t16[v] + (unsigned)t16[oA + v - c + n] + (unsigned)t16[oB + v + c]) << 15) | (unsigned)v;
+                    m = k < m ? k : m;
+                    if (WANT_SCORES) srow[v] = cur + 2ll * ((int)(k >> 15) - conf_old);
+                }
+                for (int v = rg.u0 + tid; v < rg.u1; v += NT) {
+                    const unsigned k = (((unsigned)t16[v] + (unsigned)t16[oA + v - c + n] + (unsigned)t16[oB + v + c]) << 15) | (unsigned)v;
+                    m = k < m ? k : m;
+                    if (WANT_SCORES) srow[v] = cur + 2ll * ((int)(k >> 15) - conf_old);
+                }
+                if (m != NQ_KEY32_EMPTY) {
+                    const int v = (int)(m & 0x7fffu);
+                    best = u64min(best, nq_key((int)(m >> 15) - conf_old, nq_key_hi(v > rc ? 1 : 0, c, n, slot), v));
+                }
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) s_best[wib] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long b = s_best[0];
+        for (int i = 1; i < 4 * TEAMS; i++) b = u64min(b, s_best[i]);
+        if (b != NQ_KEY_EMPTY) atomicMin(&a.best_keys[restart], b);
+    }
+}
+
+// TABLE, column teams, TWO candidates per lane and LDS look-up (even n, 512 <= n <= NQ_TABLE_LDS_MAX_N): the team kernel
+// above is bound by the LDS array (three 2-byte look-ups per candidate, 2 LDS cycles per wave-instruction whatever the
+// width).  Here a lane owns the PAIR (v, v + 1): one ds_read_b32 per table returns both candidates' counts, which are
+// added as packed 16-bit fields (a count is <= n + 2 < 2^15: no carry between the halves).  The three pairs are 4-byte
+// aligned when v = c (mod 2): then v - c + n and v + c are even (n even), and the row table is read at v for even c and
+// through a copy shifted by one entry (R1[i] = R[i + 1]) for odd c.  For odd c the pairs are (1,2) .. (n-1, n): square
+// v = n does not exist -- R1[n - 1] holds a sentinel count that can never win -- and v = 0 is scored separately by lane 0.
+constexpr unsigned NQ_PAIR_SENTINEL = 0x4000u; // > any real count (<= n + 2 <= 12290), and sentinel + 2n < 2^16: no carry
+
+template <int NT, int TL, bool WANT_SCORES>
+__global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts)
+{
+    extern __shared__ unsigned s_t16[]; // packed u16: R[n] | R1[n] | A[2n+2] | B[2n+2], then int4 records [NQ_REC_CAP]
+    constexpr int TEAMS = NT / TL;            // a team = TL lanes (one wavefront or four) walking one column
+    constexpr int SH = TL == 64 ? 6 : 8;      // log2(TL)
+    static_assert(TL == 64 || TL == 256, "team width");
+    __shared__ unsigned long long s_best[NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    const int team = __builtin_amdgcn_readfirstlane(tid >> SH), tv = tid & (TL - 1);
+    const int restart = blockIdx.x % a.n_restarts;
+    const int chunk = blockIdx.x / a.n_restarts;
+    const int n_chunks = gridDim.x / a.n_restarts;
+    const int n = a.n;
+    const int *__restrict__ rows = a.rows + (long long)restart * n;
+    const int *__restrict__ cols = a.cols + (long long)restart * a.max_cols;
+    int ncols = a.n_cols[restart];
+    ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
+    long long n_whole = a.window / (n - 1);
+    if (n_whole > ncols) n_whole = ncols;
+    const long long rem = n_whole < ncols ? a.window - n_whole * (n - 1) : 0;
+    const long long units = n_whole * parts;
+    const long long u0 = units * chunk / n_chunks, u1 = units * (chunk + 1) / n_chunks;
+    const bool do_partial = rem > 0 && chunk == n_chunks - 1;
+    unsigned long long best = NQ_KEY_EMPTY;
+    if (u0 < u1 || do_partial) { // block-uniform
+        const int oR1 = n, oA = 2 * n, oB = 4 * n + 2; // u16 indices (all even)
+        const int words = (((6 * n + 4) >> 1) + 3) & ~3;
+        int4 *s_rec = reinterpret_cast<int4 *>(s_t16 + words);
+        for (int i = tid; i < words; i += NT) s_t16[i] = 0;
+        __syncthreads();
+        for (int j = tid; j < n; j += NT) {
+            const int q = rows[j];
+            if ((unsigned)q < (unsigned)n) {
+                tab16_inc(s_t16, q);
+                if (q > 0) tab16_inc(s_t16, oR1 + q - 1);
+                tab16_inc(s_t16, oA + (q - j + n));
+                tab16_inc(s_t16, oB + (q + j));
+            }
+        }
+        if (tid == 0) atomicAdd(&s_t16[(oR1 + n - 1) >> 1], NQ_PAIR_SENTINEL << (16 * ((oR1 + n - 1) & 1)));
+        __syncthreads();
+        const unsigned short *t16 = reinterpret_cast<const unsigned short *>(s_t16);
+        const long long cur = WANT_SCORES ? a.cur_scores[restart] : 0;
+        const int steps = (n + 2 * TL - 1) >> (SH + 1);    // 2 TL values (TL pairs) per step
+        const int per_part = (steps + parts - 1) / parts;
+        const int slot_lo = (int)(u0 / parts);
+        const int slot_hi = u0 < u1 ? (int)((u1 - 1) / parts) : slot_lo - 1; // inclusive
+        for (int pass_lo = slot_lo; pass_lo <= slot_hi; pass_lo += NQ_REC_CAP) {
+            const int pass_hi = pass_lo + NQ_REC_CAP - 1 < slot_hi ? pass_lo + NQ_REC_CAP - 1 : slot_hi;
+            __syncthreads(); // the previous pass's records are no longer read
+            for (int sl = pass_lo + tid; sl <= pass_hi; sl += NT) {
+                const int c = cols[sl];
+                const int rc = (unsigned)c < (unsigned)n ? rows[c] : -1;
+                int conf_old = 0;
+                if ((unsigned)rc < (unsigned)n) conf_old = (int)t16[rc] + (int)t16[oA + rc - c + n] + (int)t16[oB + rc + c] - 3;
+                s_rec[sl - pass_lo] = make_int4(c, (unsigned)rc < (unsigned)n ? rc : -1, conf_old, 0);
+            }
+            __syncthreads();
+            long long ua = (long long)pass_lo * parts, ub = (long long)(pass_hi + 1) * parts;
+            ua = ua < u0 ? u0 : ua;
+            ub = ub > u1 ? u1 : ub;
+            for (long long u = ua + team; u < ub; u += TEAMS) { // team-uniform (team is an SGPR)
+                const int slot = (int)(u / parts), part = (int)(u - (long long)slot * parts);
+                const int4 rec = s_rec[slot - pass_lo];
+                const int c = __builtin_amdgcn_readfirstlane(rec.x), rc = __builtin_amdgcn_readfirstlane(rec.y),
+                          conf_old = __builtin_amdgcn_readfirstlane(rec.z);
+                if (rc < 0) continue; // unvalidated device-pointer input: the slot is skipped (nq_slot_scored)
+                const int par = c & 1;
+                const int i0 = part * per_part;
+                int i1 = i0 + per_part;
+                i1 = i1 > steps ? steps : i1;
+                const int full = n >> (SH + 1); // steps in which every lane's pair starts below n
+                const int i1f = i1 < full ? i1 : full;
+                // dword pointers: lane tv owns the pair starting at v = 2 tv + par (+ 512 i)
+                const unsigned *pR = s_t16 + ((par ? oR1 : 0) >> 1) + tv;                 // R[v] / R1[v - 1]
+                const unsigned *pA = s_t16 + ((oA + par - c + n) >> 1) + tv;             // A[v - c + n]
+                const unsigned *pB = s_t16 + ((oB + par + c) >> 1) + tv;                 // B[v + c]
+                const int vbase = 2 * tv + par;
+                long long *srow = WANT_SCORES ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
+                unsigned m = NQ_KEY32_EMPTY;
+                int i = i0;
+#define LS_PAIR(J)                                                                                     \
+    const unsigned s##J = pR[(i + J) << SH] + pA[(i + J) << SH] + pB[(i + J) << SH];                      \
+    const int v##J = vbase + ((i + J) << (SH + 1));                                                           \
+    const unsigned lo##J = ((s##J << 15) & 0x7fffffffu) | (unsigned)v##J;                              \
+    const unsigned hi##J = ((s##J >> 16) << 15) | (unsigned)(v##J + 1);
+#define LS_PAIR_SCORES(J)                                                                              \
+    if (WANT_SCORES) {                                                                                 \
+        if (v##J != rc) srow[v##J] = cur + 2ll * ((int)(lo##J >> 15) - conf_old);                      \
+        if (v##J + 1 != rc && v##J + 1 < n) srow[v##J + 1] = cur + 2ll * ((int)(hi##J >> 15) - conf_old); \
+    }
+                for (; i + 4 <= i1f; i += 4) {
+                    LS_PAIR(0) LS_PAIR(1) LS_PAIR(2) LS_PAIR(3)
+                    unsigned m0 = lo0 < hi0 ? lo0 : hi0, m1 = lo1 < hi1 ? lo1 : hi1, m2 = lo2 < hi2 ? lo2 : hi2,
+                             m3 = lo3 < hi3 ? lo3 : hi3;
+                    m0 = m0 < m1 ? m0 : m1;
+                    m2 = m2 < m3 ? m2 : m3;
+                    m0 = m0 < m2 ? m0 : m2;
+                    m = m0 < m ? m0 : m;
+                    LS_PAIR_SCORES(0) LS_PAIR_SCORES(1) LS_PAIR_SCORES(2) LS_PAIR_SCORES(3)
+                }
+                for (; i < i1; i++) {
+                    if (vbase + (i << (SH + 1)) < n) {
+                        LS_PAIR(0)
+                        const unsigned m0 = lo0 < hi0 ? lo0 : hi0;
+                        m = m0 < m ? m0 : m;
+                        LS_PAIR_SCORES(0)
+                    }
+                }
+                if (par && i0 == 0 && tv == 0) { // odd column: square v = 0 belongs to no pair
+                    const unsigned k0 = ((unsigned)t16[0] + (unsigned)t16[oA - c + n] + (unsigned)t16[oB + c]) << 15;
+                    m = k0 < m ? k0 : m;
+                    if (WANT_SCORES && rc != 0) srow[0] = cur + 2ll * ((int)(k0 >> 15) - conf_old);
+                }
+                const unsigned noop = ((unsigned)(conf_old + 3) << 15) | (unsigned)rc;
+                if (m == noop) { // this lane's minimum is the tabu square itself: walk again without it
+                    m = NQ_KEY32_EMPTY;
+                    for (int i2 = i0; i2 < i1; i2++) {
+                        i = i2;
+                        if (vbase + (i << (SH + 1)) < n) {
+                            LS_PAIR(0)
+                            if (v0 != rc) m = lo0 < m ? lo0 : m;
+                            if (v0 + 1 != rc && v0 + 1 < n) m = hi0 < m ? hi0 : m;
+                        }
+                    }
+                    if (par && i0 == 0 && tv == 0 && rc != 0) {
+                        const unsigned k0 = ((unsigned)t16[0] + (unsigned)t16[oA - c + n] + (unsigned)t16[oB + c]) << 15;
+                        m = k0 < m ? k0 : m;
+                    }
+                }
+#undef LS_PAIR
+#undef LS_PAIR_SCORES
+                if (m != NQ_KEY32_EMPTY) {
+                    const int v = (int)(m & 0x7fffu);
+                    best = u64min(best, nq_key((int)(m >> 15) - conf_old, nq_key_hi(v > rc ? 1 : 0, c, n, slot), v));
+                }
+            }
+        }
+        if (do_partial) { // the slot the window cuts: per-range loops, all lanes of the block
+            const int slot = (int)n_whole;
+            const int c = cols[slot];
+            const int rc = (unsigned)c < (unsigned)n ? rows[c] : -1;
+            if ((unsigned)rc < (unsigned)n) {
+                const NqRanges rg = nq_ranges(0, n, rc, (long long)slot * (n - 1), a.window);
+                const int conf_old = (int)t16[rc] + (int)t16[oA + rc - c + n] + (int)t16[oB + rc + c] - 3;
+                long long *srow = WANT_SCORES ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
+                unsigned m = NQ_KEY32_EMPTY;
+                for (int v = rg.d0 + tid; v < rg.d1; v += NT) {
+                    const unsigned k = (((unsigned)t16[v] + (unsigned)t16[oA + v - c + n] + (unsigned)t16[oB + v + c]) << 15) | (unsigned)v;
+                    m = k < m ? k : m;
+                    if (WANT_SCORES) srow[v] = cur + 2ll * ((int)(k >> 15) - conf_old);
+                }
+                for (int v = rg.u0 + tid; v < rg.u1; v += NT) {
+                    const unsigned k = (((unsigned)t16[v] + (unsigned)t16[oA + v - c + n] + (unsigned)t16[oB + v + c]) << 15) | (unsigned)v;
+                    m = k < m ? k : m;
+                    if (WANT_SCORES) srow[v] = cur + 2ll * ((int)(k >> 15) - conf_old);
+                }
+                if (m != NQ_KEY32_EMPTY) {
+                    const int v = (int)(m & 0x7fffu);
+                    best = u64min(best, nq_key((int)(m >> 15) - conf_old, nq_key_hi(v > rc ? 1 : 0, c, n, slot), v));
+                }
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) s_best[wib] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long b = s_best[0];
+        for (int i = 1; i < NT / 64; i++) b = u64min(b, s_best[i]);
+        if (b != NQ_KEY_EMPTY) atomicMin(&a.best_keys[restart], b);
+    }
+}
+
 // get_col_scores + sum by tables (examples/nqueens/src/lib.rs:74-87,130-139).
 __global__ __launch_bounds__(256) void nq_col_scores_kernel(const int *rows_all, int n, const int *tabs,
                                                             int tab_stride, long long *col_scores,
@@ -1151,6 +1501,92 @@ static int build_tables(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, i
     return LS_OK;
 }
 
+// NT threads per block; teams of TL lanes; PAIRS: two candidates per lane and look-up
+template <int NT, int TL, bool PAIRS>
+static int launch_table_teams_t(ls_ctx *ctx, const NqArgs &a, long long window)
+{
+    constexpr int TEAMS = NT / TL;
+    const int n = a.n;
+    auto lds_for = [](int nn) {
+        const size_t tab_words = PAIRS ? ((((size_t)(6 * nn + 4) >> 1) + 3) & ~(size_t)3) : ((((size_t)(5 * nn + 1) / 2) + 3) & ~(size_t)3);
+        return (tab_words + 4 * (size_t)NQ_REC_CAP) * 4;
+    };
+    const size_t lds = lds_for(n);
+    const void *k_plain, *k_scores;
+    if constexpr (PAIRS) {
+        k_plain = reinterpret_cast<const void *>(&nq_table_pairs_kernel<NT, TL, false>);
+        k_scores = reinterpret_cast<const void *>(&nq_table_pairs_kernel<NT, TL, true>);
+    } else {
+        static_assert(PAIRS || TL == 256, "the one-candidate-per-lane kernel has 256-lane teams");
+        k_plain = reinterpret_cast<const void *>(&nq_table_teams_kernel<NT / 256, false>);
+        k_scores = reinterpret_cast<const void *>(&nq_table_teams_kernel<NT / 256, true>);
+    }
+    static std::atomic<bool> attr_done_dev[64];
+    if (!attr_done_dev[ctx->device & 63].load(std::memory_order_acquire)) {
+        const int max_lds = (int)lds_for(NQ_TABLE_LDS_MAX_N);
+        LS_HIP(ctx, hipFuncSetAttribute(k_plain, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        LS_HIP(ctx, hipFuncSetAttribute(k_scores, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        attr_done_dev[ctx->device & 63].store(true, std::memory_order_release);
+    }
+    // residency: LDS (160 KB per CU) and wave slots (32 per CU)
+    long long per_cu = (160 * 1024) / (long long)(lds + 512);
+    const long long by_waves = 32 / (NT / 64);
+    per_cu = per_cu > by_waves ? by_waves : per_cu;
+    per_cu = per_cu < 1 ? 1 : per_cu;
+    long long bpr = ((long long)ctx->n_cus * per_cu) / a.n_restarts;
+    if (bpr < 1) bpr = 1;
+    // work units: whole slots x parts; a unit should keep a team busy for >= 4 steps (of TL values, or TL pairs)
+    long long n_whole = window / (n - 1);
+    if (n_whole > a.max_cols) n_whole = a.max_cols;
+    const int per_step = PAIRS ? 2 * TL : TL;
+    const int steps = (n + per_step - 1) / per_step;
+    long long parts = 1;
+    if (n_whole > 0 && n_whole < bpr * TEAMS) {
+        parts = (bpr * TEAMS) / n_whole;
+        const long long max_parts = steps >= 4 ? steps / 4 : 1;
+        parts = parts > max_parts ? max_parts : parts;
+        parts = parts < 1 ? 1 : parts;
+    }
+    long long want_blocks = (n_whole * parts + TEAMS - 1) / TEAMS;
+    if (want_blocks < 1) want_blocks = 1;
+    if (bpr > want_blocks) bpr = want_blocks;
+    const dim3 grid((unsigned)(bpr * a.n_restarts));
+    void *args[] = {const_cast<NqArgs *>(&a), &parts};
+    int parts_i = (int)parts;
+    args[1] = &parts_i;
+    LS_HIP(ctx, hipLaunchKernel(a.scores_out ? k_scores : k_plain, grid, dim3(NT), args, lds, ctx->stream));
+    return LS_OK;
+}
+
+// LS_NQ_TABLE_VARIANT (measurement knob): 0 = per-range kernel; 1, 2, 4 = column teams of 256 lanes, one candidate per lane and
+// look-up; 11, 12, 14 = the same with two candidates per lane and look-up (even n >= 512); 21, 22, 24 = two candidates per
+// lane and look-up, a team is ONE wavefront (1, 2, 4 x 256 threads per block).
+static int launch_table_teams(ls_ctx *ctx, const NqArgs &a, long long window)
+{
+    const int v = ctx->nq_table_variant;
+    const bool pairs = v >= 10 && (a.n & 1) == 0 && a.n >= 512;
+    const int q = v % 10;
+    if (pairs && v >= 20) {
+        switch (q) {
+        case 1: return launch_table_teams_t<256, 64, true>(ctx, a, window);
+        case 2: return launch_table_teams_t<512, 64, true>(ctx, a, window);
+        default: return launch_table_teams_t<1024, 64, true>(ctx, a, window);
+        }
+    }
+    if (pairs) {
+        switch (q) {
+        case 1: return launch_table_teams_t<256, 256, true>(ctx, a, window);
+        case 2: return launch_table_teams_t<512, 256, true>(ctx, a, window);
+        default: return launch_table_teams_t<1024, 256, true>(ctx, a, window);
+        }
+    }
+    switch (q) {
+    case 1: return launch_table_teams_t<256, 256, false>(ctx, a, window);
+    case 2: return launch_table_teams_t<512, 256, false>(ctx, a, window);
+    default: return launch_table_teams_t<1024, 256, false>(ctx, a, window);
+    }
+}
+
 int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, const long long *cur_d,
                       const int *cols_d, const int *n_cols_d, int max_cols, long long window,
                       ls_nq_result *results_d, long long *scores_out_d, int *next_rows_d)
@@ -1202,7 +1638,10 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
         }
     }
     if (max_cols > 0) {
-        if (ctx->nq_algo != LS_NQ_ALGO_SCAN && n <= NQ_TABLE_LDS_MAX_N) {
+        if (ctx->nq_algo != LS_NQ_ALGO_SCAN && n >= 256 && n <= NQ_TABLE_LDS_MAX_N && ctx->nq_table_variant != 0) {
+            int rc = launch_table_teams(ctx, a, window);
+            if (rc != LS_OK) return rc;
+        } else if (ctx->nq_algo != LS_NQ_ALGO_SCAN && n <= NQ_TABLE_LDS_MAX_N) {
             const size_t lds = (size_t)((5 * n + 1) / 2) * 4 + 16;
             static std::atomic<bool> attr_done_dev[64];
             if (!attr_done_dev[ctx->device & 63].load(std::memory_order_acquire)) {

@@ -87,23 +87,26 @@ def main():
                "source": f"profiles/{tag}_kernel_counters.json (rocprofv3 --pmc, tools/profile_counters.sh)"}
         if "duration_ns" in e:
             ent["duration_us"] = e["duration_ns"]["mean"] / 1e3
+        # a grid smaller than the chip (LS step: one 1024-thread block per restart) can only use its own CUs
+        blocks = max(1, e["grid_threads"] // max(1, e.get("workgroup_size", 256)))
+        cus = min(256, blocks)
+        ent["cus_usable"] = cus
         if "SQ_INSTS_VALU" in c:
             ent["valu_wave_instr_per_candidate"] = c["SQ_INSTS_VALU"] / cand
-            ent["valu_issue_bound_us"] = c["SQ_INSTS_VALU"] * VALU_CYC / (SIMDS * CLOCK) * 1e6
+            ent["valu_issue_bound_us"] = c["SQ_INSTS_VALU"] * VALU_CYC / (4 * cus * CLOCK) * 1e6
         if "SQ_INSTS_LDS" in c:
             ent["lds_wave_instr_per_candidate"] = c["SQ_INSTS_LDS"] / cand
         if "SQ_INSTS_SALU" in c:
             ent["salu_wave_instr_per_candidate"] = c["SQ_INSTS_SALU"] / cand
         if "SQ_LDS_IDX_ACTIVE" in c:
-            ent["lds_array_bound_us"] = c["SQ_LDS_IDX_ACTIVE"] / (SIMDS / 4 * CLOCK) * 1e6   # LDS-array cycles summed over CUs
+            ent["lds_array_bound_us"] = c["SQ_LDS_IDX_ACTIVE"] / (cus * CLOCK) * 1e6   # LDS-array cycles summed over CUs
         if "duration_us" in ent and "valu_issue_bound_us" in ent:
             bounds = {"valu_issue": ent["valu_issue_bound_us"]}
             if "lds_array_bound_us" in ent:
                 bounds["lds_array"] = ent["lds_array_bound_us"]
             b = max(bounds, key=bounds.get)
             ent["roofline"] = {"bound": b, "frac": bounds[b] / ent["duration_us"], "bound_us": bounds[b],
-                               "note": "chip-wide issue bound at the spec clock with every SIMD / LDS array busy; small grids "
-                                       "(LS step: one block per restart) cannot reach it by construction"}
+                               "note": "issue bound at the spec clock with every SIMD / LDS array of the CUs the grid can occupy busy"}
         out[wname] = ent
     with open(os.path.join(ROOT, "profiles", "kernel_counters.json"), "w") as f:
         json.dump({"kernels": out} if False else out, f, indent=1)
