@@ -908,6 +908,86 @@ __global__ __launch_bounds__(256 * TEAMS) void nq_table_teams_kernel(NqArgs a, i
 // v = n does not exist -- R1[n - 1] holds a sentinel count that can never win -- and v = 0 is scored separately by lane 0.
 constexpr unsigned NQ_PAIR_SENTINEL = 0x4000u; // > any real count (<= n + 2 <= 12290), and sentinel + 2n < 2^16: no carry
 
+// One (slot, part) unit of the paired column walk: lane tv of a TL-lane team scores the pairs (v, v + 1),
+// v = 2 tv + (c & 1) + 2 TL i for the steps i in [i0, i0 + per_part), and folds the unit's (count, v) minimum into `best`.
+// Table layout (u16 indices): R at 0, R1 at n, A at 2n, B at 4n + 2 (nq_table_pairs_kernel).
+template <int TL, bool WANT_SCORES>
+__device__ __forceinline__ void nq_pairs_unit(const unsigned *s_t16, int n, int tv, int c, int rc, int conf_old, int slot, int i0,
+                                              int per_part, long long *srow, long long cur, unsigned long long &best)
+{
+    constexpr int SH = TL == 64 ? 6 : 8;
+    const unsigned short *t16 = reinterpret_cast<const unsigned short *>(s_t16);
+    const int oR1 = n, oA = 2 * n, oB = 4 * n + 2;
+    const int steps = (n + 2 * TL - 1) >> (SH + 1);
+    const int par = c & 1;
+    int i1 = i0 + per_part;
+    i1 = i1 > steps ? steps : i1;
+    const int full = n >> (SH + 1); // steps in which every lane's pair starts below n
+    const int i1f = i1 < full ? i1 : full;
+    // dword pointers: lane tv owns the pair starting at v = 2 tv + par (+ 512 i)
+    const unsigned *pR = s_t16 + ((par ? oR1 : 0) >> 1) + tv;                 // R[v] / R1[v - 1]
+    const unsigned *pA = s_t16 + ((oA + par - c + n) >> 1) + tv;             // A[v - c + n]
+    const unsigned *pB = s_t16 + ((oB + par + c) >> 1) + tv;                 // B[v + c]
+    const int vbase = 2 * tv + par;
+    unsigned m = NQ_KEY32_EMPTY;
+    int i = i0;
+#define LS_PAIR(J)                                                                                     \
+    const unsigned s##J = pR[(i + J) << SH] + pA[(i + J) << SH] + pB[(i + J) << SH];                      \
+    const int v##J = vbase + ((i + J) << (SH + 1));                                                           \
+    const unsigned lo##J = ((s##J << 15) & 0x7fffffffu) | (unsigned)v##J;                              \
+    const unsigned hi##J = ((s##J >> 16) << 15) | (unsigned)(v##J + 1);
+#define LS_PAIR_SCORES(J)                                                                              \
+    if (WANT_SCORES) {                                                                                 \
+        if (v##J != rc) srow[v##J] = cur + 2ll * ((int)(lo##J >> 15) - conf_old);                      \
+        if (v##J + 1 != rc && v##J + 1 < n) srow[v##J + 1] = cur + 2ll * ((int)(hi##J >> 15) - conf_old); \
+    }
+    for (; i + 4 <= i1f; i += 4) {
+        LS_PAIR(0) LS_PAIR(1) LS_PAIR(2) LS_PAIR(3)
+        unsigned m0 = lo0 < hi0 ? lo0 : hi0, m1 = lo1 < hi1 ? lo1 : hi1, m2 = lo2 < hi2 ? lo2 : hi2,
+                 m3 = lo3 < hi3 ? lo3 : hi3;
+        m0 = m0 < m1 ? m0 : m1;
+        m2 = m2 < m3 ? m2 : m3;
+        m0 = m0 < m2 ? m0 : m2;
+        m = m0 < m ? m0 : m;
+        LS_PAIR_SCORES(0) LS_PAIR_SCORES(1) LS_PAIR_SCORES(2) LS_PAIR_SCORES(3)
+    }
+    for (; i < i1; i++) {
+        if (vbase + (i << (SH + 1)) < n) {
+            LS_PAIR(0)
+            const unsigned m0 = lo0 < hi0 ? lo0 : hi0;
+            m = m0 < m ? m0 : m;
+            LS_PAIR_SCORES(0)
+        }
+    }
+    if (par && i0 == 0 && tv == 0) { // odd column: square v = 0 belongs to no pair
+        const unsigned k0 = ((unsigned)t16[0] + (unsigned)t16[oA - c + n] + (unsigned)t16[oB + c]) << 15;
+        m = k0 < m ? k0 : m;
+        if (WANT_SCORES && rc != 0) srow[0] = cur + 2ll * ((int)(k0 >> 15) - conf_old);
+    }
+    const unsigned noop = ((unsigned)(conf_old + 3) << 15) | (unsigned)rc;
+    if (m == noop) { // this lane's minimum is the tabu square itself: walk again without it
+        m = NQ_KEY32_EMPTY;
+        for (int i2 = i0; i2 < i1; i2++) {
+            i = i2;
+            if (vbase + (i << (SH + 1)) < n) {
+                LS_PAIR(0)
+                if (v0 != rc) m = lo0 < m ? lo0 : m;
+                if (v0 + 1 != rc && v0 + 1 < n) m = hi0 < m ? hi0 : m;
+            }
+        }
+        if (par && i0 == 0 && tv == 0 && rc != 0) {
+            const unsigned k0 = ((unsigned)t16[0] + (unsigned)t16[oA - c + n] + (unsigned)t16[oB + c]) << 15;
+            m = k0 < m ? k0 : m;
+        }
+    }
+#undef LS_PAIR
+#undef LS_PAIR_SCORES
+    if (m != NQ_KEY32_EMPTY) {
+        const int v = (int)(m & 0x7fffu);
+        best = u64min(best, nq_key((int)(m >> 15) - conf_old, nq_key_hi(v > rc ? 1 : 0, c, n, slot), v));
+    }
+}
+
 template <int NT, int TL, bool WANT_SCORES>
 __global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts)
 {
@@ -976,75 +1056,8 @@ __global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts)
                 const int c = __builtin_amdgcn_readfirstlane(rec.x), rc = __builtin_amdgcn_readfirstlane(rec.y),
                           conf_old = __builtin_amdgcn_readfirstlane(rec.z);
                 if (rc < 0) continue; // unvalidated device-pointer input: the slot is skipped (nq_slot_scored)
-                const int par = c & 1;
-                const int i0 = part * per_part;
-                int i1 = i0 + per_part;
-                i1 = i1 > steps ? steps : i1;
-                const int full = n >> (SH + 1); // steps in which every lane's pair starts below n
-                const int i1f = i1 < full ? i1 : full;
-                // dword pointers: lane tv owns the pair starting at v = 2 tv + par (+ 512 i)
-                const unsigned *pR = s_t16 + ((par ? oR1 : 0) >> 1) + tv;                 // R[v] / R1[v - 1]
-                const unsigned *pA = s_t16 + ((oA + par - c + n) >> 1) + tv;             // A[v - c + n]
-                const unsigned *pB = s_t16 + ((oB + par + c) >> 1) + tv;                 // B[v + c]
-                const int vbase = 2 * tv + par;
                 long long *srow = WANT_SCORES ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
-                unsigned m = NQ_KEY32_EMPTY;
-                int i = i0;
-#define LS_PAIR(J)                                                                                     \
-    const unsigned s##J = pR[(i + J) << SH] + pA[(i + J) << SH] + pB[(i + J) << SH];                      \
-    const int v##J = vbase + ((i + J) << (SH + 1));                                                           \
-    const unsigned lo##J = ((s##J << 15) & 0x7fffffffu) | (unsigned)v##J;                              \
-    const unsigned hi##J = ((s##J >> 16) << 15) | (unsigned)(v##J + 1);
-#define LS_PAIR_SCORES(J)                                                                              \
-    if (WANT_SCORES) {                                                                                 \
-        if (v##J != rc) srow[v##J] = cur + 2ll * ((int)(lo##J >> 15) - conf_old);                      \
-        if (v##J + 1 != rc && v##J + 1 < n) srow[v##J + 1] = cur + 2ll * ((int)(hi##J >> 15) - conf_old); \
-    }
-                for (; i + 4 <= i1f; i += 4) {
-                    LS_PAIR(0) LS_PAIR(1) LS_PAIR(2) LS_PAIR(3)
-                    unsigned m0 = lo0 < hi0 ? lo0 : hi0, m1 = lo1 < hi1 ? lo1 : hi1, m2 = lo2 < hi2 ? lo2 : hi2,
-                             m3 = lo3 < hi3 ? lo3 : hi3;
-                    m0 = m0 < m1 ? m0 : m1;
-                    m2 = m2 < m3 ? m2 : m3;
-                    m0 = m0 < m2 ? m0 : m2;
-                    m = m0 < m ? m0 : m;
-                    LS_PAIR_SCORES(0) LS_PAIR_SCORES(1) LS_PAIR_SCORES(2) LS_PAIR_SCORES(3)
-                }
-                for (; i < i1; i++) {
-                    if (vbase + (i << (SH + 1)) < n) {
-                        LS_PAIR(0)
-                        const unsigned m0 = lo0 < hi0 ? lo0 : hi0;
-                        m = m0 < m ? m0 : m;
-                        LS_PAIR_SCORES(0)
-                    }
-                }
-                if (par && i0 == 0 && tv == 0) { // odd column: square v = 0 belongs to no pair
-                    const unsigned k0 = ((unsigned)t16[0] + (unsigned)t16[oA - c + n] + (unsigned)t16[oB + c]) << 15;
-                    m = k0 < m ? k0 : m;
-                    if (WANT_SCORES && rc != 0) srow[0] = cur + 2ll * ((int)(k0 >> 15) - conf_old);
-                }
-                const unsigned noop = ((unsigned)(conf_old + 3) << 15) | (unsigned)rc;
-                if (m == noop) { // this lane's minimum is the tabu square itself: walk again without it
-                    m = NQ_KEY32_EMPTY;
-                    for (int i2 = i0; i2 < i1; i2++) {
-                        i = i2;
-                        if (vbase + (i << (SH + 1)) < n) {
-                            LS_PAIR(0)
-                            if (v0 != rc) m = lo0 < m ? lo0 : m;
-                            if (v0 + 1 != rc && v0 + 1 < n) m = hi0 < m ? hi0 : m;
-                        }
-                    }
-                    if (par && i0 == 0 && tv == 0 && rc != 0) {
-                        const unsigned k0 = ((unsigned)t16[0] + (unsigned)t16[oA - c + n] + (unsigned)t16[oB + c]) << 15;
-                        m = k0 < m ? k0 : m;
-                    }
-                }
-#undef LS_PAIR
-#undef LS_PAIR_SCORES
-                if (m != NQ_KEY32_EMPTY) {
-                    const int v = (int)(m & 0x7fffu);
-                    best = u64min(best, nq_key((int)(m >> 15) - conf_old, nq_key_hi(v > rc ? 1 : 0, c, n, slot), v));
-                }
+                nq_pairs_unit<TL, WANT_SCORES>(s_t16, n, tv, c, rc, conf_old, slot, part * per_part, per_part, srow, cur, best);
             }
         }
         if (do_partial) { // the slot the window cuts: per-range loops, all lanes of the block
@@ -1238,15 +1251,18 @@ constexpr int NQ_STEP_MAX_SLOTS = 1024;
 
 __device__ __forceinline__ void tab16_dec(unsigned *t, int idx) { atomicSub(&t[idx >> 1], 1u << (16 * (idx & 1))); }
 
+// PAIRS (even n >= 128): the tables carry the shifted row copy of nq_table_pairs_kernel and the candidates are scored by
+// wavefront teams, two per lane and look-up (nq_pairs_unit); otherwise a flat one-candidate-per-lane walk.
+template <bool PAIRS>
 __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *results, int *next_rows,
                                                        long long *next_col_scores, long long *next_totals, NqStepExtra x)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[]; // tables (packed u16: R[n] | A[2n] | B[2n]) | rows[n] | slot records[n_slots]
+    extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[]; // tables (packed u16: R[n] | A[2n] | B[2n], or R | R1 | A[2n+2] | B[2n+2]) | rows[n] | slot records[n_slots]
     __shared__ unsigned long long s_best[16];
     __shared__ int s_sum[16], s_cnt[16];
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
     const int r = blockIdx.x, n = a.n;
-    const int words = (((5 * n + 1) >> 1) + 3) & ~3; // keeps the slot records 16-byte aligned
+    const int words = PAIRS ? (((6 * n + 4) >> 1) + 3) & ~3 : (((5 * n + 1) >> 1) + 3) & ~3; // keeps the slot records 16-byte aligned
     unsigned *s_t16 = s_dyn;
     int *s_rows = reinterpret_cast<int *>(s_dyn + words);
     int4 *s_slot = reinterpret_cast<int4 *>(s_rows + ((n + 3) & ~3)); // {column, its row, conf(column, row), -}
@@ -1273,16 +1289,18 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
     const long long K = nq_k_limit((long long)ncols * n, n, a.window);
     const int n_slots = (int)((K + n - 1) / n);
     __syncthreads();
-    const int oA = n, oB = 3 * n;
+    const int oR1 = n, oA = PAIRS ? 2 * n : n, oB = PAIRS ? 4 * n + 2 : 3 * n;
 #pragma unroll
     for (int i = 0; i < NQ_STEP_MAX_N / 1024; i++) {
         const int j = tid + 1024 * i, q = rv[i];
         if (j < n && (unsigned)q < (unsigned)n) {
             tab16_inc(s_t16, q);
+            if (PAIRS && q > 0) tab16_inc(s_t16, oR1 + q - 1);
             tab16_inc(s_t16, oA + (q - j + n));
             tab16_inc(s_t16, oB + (q + j));
         }
     }
+    if (PAIRS && tid == 0) atomicAdd(&s_t16[(oR1 + n - 1) >> 1], NQ_PAIR_SENTINEL << (16 * ((oR1 + n - 1) & 1)));
     __syncthreads();
     int my_scored = 0; // this slot's share of n_scored (nq_slot_scored: skipped slots keep their window positions)
     if (tid < n_slots) {
@@ -1297,23 +1315,67 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
     my_scored = wave_sum_i32(my_scored);
     if (lane == 0) s_cnt[wib] = my_scored;
     __syncthreads();
-    // Flat walk over the unfiltered positions k = slot * n + v that take(window) can reach; iterations are
-    // independent, so the LDS look-ups of several candidates are in flight together.  k / n by an exact
-    // multiply-high (k < 2^17, n < 2^14).
     unsigned long long best = NQ_KEY_EMPTY;
-    const unsigned magic = (unsigned)(0x100000000ull / (unsigned)n) + 1u;
-    const int kmax = (int)K;
+    if constexpr (PAIRS) {
+        // whole slots by wavefront teams (sixteen per block), the slot the window cuts by every lane with per-range loops
+        long long n_whole = a.window / (n - 1);
+        if (n_whole > ncols) n_whole = ncols;
+        const long long rem = n_whole < ncols ? a.window - n_whole * (n - 1) : 0;
+        const int steps = (n + 127) >> 7;
+        int parts = n_whole > 0 && n_whole < 16 ? (int)(16 / n_whole) : 1;
+        parts = parts > (steps >> 1) ? (steps >> 1) : parts;
+        parts = parts < 1 ? 1 : parts;
+        const int per_part = (steps + parts - 1) / parts;
+        const int team = __builtin_amdgcn_readfirstlane(wib);
+        const int units = (int)n_whole * parts;
+        for (int u = team; u < units; u += 16) {
+            const int slot = u / parts, part = u - slot * parts;
+            const int4 si = s_slot[slot];
+            const int c = __builtin_amdgcn_readfirstlane(si.x), rc = __builtin_amdgcn_readfirstlane(si.y),
+                      conf_old = __builtin_amdgcn_readfirstlane(si.z);
+            if (rc < 0) continue;
+            nq_pairs_unit<64, false>(s_t16, n, lane, c, rc, conf_old, slot, part * per_part, per_part, nullptr, 0, best);
+        }
+        if (rem > 0) {
+            const int slot = (int)n_whole;
+            const int4 si = s_slot[slot];
+            const int c = si.x, rc = si.y, conf_old = si.z;
+            if (rc >= 0) {
+                const unsigned short *t16 = reinterpret_cast<const unsigned short *>(s_t16);
+                const NqRanges rg = nq_ranges(0, n, rc, (long long)slot * (n - 1), a.window);
+                unsigned m = NQ_KEY32_EMPTY;
+                for (int v = rg.d0 + tid; v < rg.d1; v += 1024) {
+                    const unsigned kk = (((unsigned)t16[v] + (unsigned)t16[oA + v - c + n] + (unsigned)t16[oB + v + c]) << 15) | (unsigned)v;
+                    m = kk < m ? kk : m;
+                }
+                for (int v = rg.u0 + tid; v < rg.u1; v += 1024) {
+                    const unsigned kk = (((unsigned)t16[v] + (unsigned)t16[oA + v - c + n] + (unsigned)t16[oB + v + c]) << 15) | (unsigned)v;
+                    m = kk < m ? kk : m;
+                }
+                if (m != NQ_KEY32_EMPTY) {
+                    const int v = (int)(m & 0x7fffu);
+                    best = u64min(best, nq_key((int)(m >> 15) - conf_old, nq_key_hi(v > rc ? 1 : 0, c, n, slot), v));
+                }
+            }
+        }
+    } else {
+        // Flat walk over the unfiltered positions k = slot * n + v that take(window) can reach; iterations are
+        // independent, so the LDS look-ups of several candidates are in flight together.  k / n by an exact
+        // multiply-high (k < 2^17, n < 2^14).
+        const unsigned magic = (unsigned)(0x100000000ull / (unsigned)n) + 1u;
+        const int kmax = (int)K;
 #pragma unroll 4
-    for (int k = tid; k < kmax; k += 1024) {
-        const int slot = (int)__umulhi((unsigned)k, magic);
-        const int v = k - slot * n;
-        const int4 si = s_slot[slot];
-        const int c = si.x, rc = si.y;
-        const bool up = v > rc;
-        const long long rank = (long long)slot * (n - 1) + v - (up ? 1 : 0); // tabu candidates do not consume window
-        if (rc >= 0 && v != rc && rank < a.window) {
-            const int delta = tab16_get(s_t16, v) + tab16_get(s_t16, oA + v - c + n) + tab16_get(s_t16, oB + v + c) - si.z;
-            best = u64min(best, nq_key(delta, nq_key_hi(up ? 1 : 0, c, n, slot), v));
+        for (int k = tid; k < kmax; k += 1024) {
+            const int slot = (int)__umulhi((unsigned)k, magic);
+            const int v = k - slot * n;
+            const int4 si = s_slot[slot];
+            const int c = si.x, rc = si.y;
+            const bool up = v > rc;
+            const long long rank = (long long)slot * (n - 1) + v - (up ? 1 : 0); // tabu candidates do not consume window
+            if (rc >= 0 && v != rc && rank < a.window) {
+                const int delta = tab16_get(s_t16, v) + tab16_get(s_t16, oA + v - c + n) + tab16_get(s_t16, oB + v + c) - si.z;
+                best = u64min(best, nq_key(delta, nq_key_hi(up ? 1 : 0, c, n, slot), v));
+            }
         }
     }
     best = wave_min_u64(best);
@@ -1346,6 +1408,10 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
             const int q = s_rows[c];
             tab16_dec(s_t16, q); tab16_dec(s_t16, oA + q - c + n); tab16_dec(s_t16, oB + q + c);
             tab16_inc(s_t16, v); tab16_inc(s_t16, oA + v - c + n); tab16_inc(s_t16, oB + v + c);
+            if (PAIRS) {
+                if (q > 0) tab16_dec(s_t16, oR1 + q - 1);
+                if (v > 0) tab16_inc(s_t16, oR1 + v - 1);
+            }
             s_rows[c] = v;
         }
         results[r] = out;
@@ -1733,20 +1799,23 @@ int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long 
     a.rows = rows; a.cur_scores = cur; a.cols = cols; a.n_cols = n_cols;
     a.n = n; a.n_restarts = n_restarts; a.max_cols = max_cols; a.window = window;
     a.best_keys = nullptr; a.scores_out = nullptr; a.tabs = nullptr; a.tab_stride = 0;
+    const bool pairs = (n & 1) == 0 && n >= 128 && ctx->nq_table_variant >= 10;
     static std::atomic<bool> attr_done_dev[64];
     if (!attr_done_dev[ctx->device & 63].load(std::memory_order_acquire)) {
-        LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        ((5 * NQ_STEP_MAX_N + 1) / 2 + 4 + NQ_STEP_MAX_N + 4 * NQ_STEP_MAX_SLOTS) * 4));
+        const int max_lds = (((6 * NQ_STEP_MAX_N + 4) / 2 + 4) + NQ_STEP_MAX_N + 4 * NQ_STEP_MAX_SLOTS) * 4;
+        LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        LS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&nq_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         attr_done_dev[ctx->device & 63].store(true, std::memory_order_release);
     }
     long long slots = (long long)max_cols;
     if (window / (n - 1) < max_cols) slots = window / (n - 1) + 1;
-    const size_t lds = ((((size_t)(5 * n + 1) / 2 + 3) & ~(size_t)3) + (((size_t)n + 3) & ~(size_t)3) + 4 * (size_t)slots) * 4;
+    const size_t tab_words = pairs ? ((((size_t)(6 * n + 4) >> 1) + 3) & ~(size_t)3) : ((((size_t)(5 * n + 1) / 2) + 3) & ~(size_t)3);
+    const size_t lds = (tab_words + (((size_t)n + 3) & ~(size_t)3) + 4 * (size_t)slots) * 4;
     NqStepExtra x;
     if (extra) x = *extra;
     else { x.fresh_mask = ~0ull; x.resident_rows = nullptr; x.next_cs16 = nullptr; x.done_flag = nullptr; x.done_seq = 0; x.block_counter = nullptr; }
-    hipLaunchKernelGGL(nq_step_kernel, dim3(n_restarts), dim3(1024), lds, ctx->stream, a, results, next_rows, next_col_scores,
-                       next_totals, x);
+    if (pairs) hipLaunchKernelGGL(nq_step_kernel<true>, dim3(n_restarts), dim3(1024), lds, ctx->stream, a, results, next_rows, next_col_scores, next_totals, x);
+    else hipLaunchKernelGGL(nq_step_kernel<false>, dim3(n_restarts), dim3(1024), lds, ctx->stream, a, results, next_rows, next_col_scores, next_totals, x);
     LS_HIP(ctx, hipGetLastError());
     return LS_OK;
 }
