@@ -68,6 +68,37 @@ def test_rust_sys_bindings_cover_the_header():
     assert sorted(set(re.findall(r"pub fn (ls_[a-z0-9_]+)\(", rs))) == _declared_functions()
 
 
+def test_rust_safe_wrapper_and_adaptors_cover_the_drop_in_path():
+    # bindings/rust is source only; keep it honest mechanically: the safe wrapper must wrap every entry point the two
+    # plug-in adaptors call, every wrapped C function must exist in the header, and the adaptors must implement the
+    # reference's own traits (MoveProposer / SolutionScoreCalculator: local-search/src/local_search.rs:58-90) with the
+    # reference's associated-type names, so that `local-search/` needs no edit.
+    root = os.path.dirname(os.path.dirname(os.path.abspath(_lib.HEADER_PATH)))
+    rs = os.path.join(root, "bindings", "rust")
+    with open(os.path.join(rs, "local-search-amd", "src", "lib.rs")) as f:
+        lib_rs = f.read()
+    wrapped_c = sorted(set(re.findall(r"sys::(ls_[a-z0-9_]+)\(", lib_rs)))
+    assert set(wrapped_c) <= set(_declared_functions())
+    for need in ("ls_ctx_create", "ls_ctx_destroy", "ls_last_error", "ls_nqueens_col_scores", "ls_nqueens_eval_batch_next",
+                 "ls_nqueens_eval", "ls_sched_instance_upload", "ls_sched_score", "ls_sched_eval", "ls_sched_moves_upload",
+                 "ls_sched_eval_resident", "ls_sched_eval_exhaustive"):
+        assert need in wrapped_c, need
+    safe_fns = set(re.findall(r"pub fn ([a-z_0-9]+)\(", lib_rs))
+    for ex, traits in (("nqueens", ("NQueensSolution", "NQueensScore")), ("employee-scheduling", ("ScheduleSolution", "ScheduleScore"))):
+        with open(os.path.join(rs, "examples", ex, "gpu.rs")) as f:
+            gpu = f.read()
+        called = set(re.findall(r"\.ctx\s*\.\s*([a-z_0-9]+)\(", gpu)) | set(re.findall(r"\.ctx\n\s*\.([a-z_0-9]+)\(", gpu))
+        assert called and called <= safe_fns, (ex, called - safe_fns)
+        assert "impl MoveProposer for" in gpu and "impl SolutionScoreCalculator for" in gpu
+        assert "type R = rand_chacha::ChaCha20Rng;" in gpu and f"type Solution = {traits[0]};" in gpu
+        assert f"type _Solution = {traits[0]};" in gpu and f"type _Score = {traits[1]};" in gpu
+        assert "Box<dyn Iterator<Item = Self::Solution>>" in gpu
+        with open(os.path.join(rs, "examples", ex, ex + ".patch")) as f:
+            patch = f.read()
+        touched = re.findall(r"^\+\+\+ b/(\S+)", patch, flags=re.M)
+        assert touched and not any(t.startswith("local-search/") for t in touched), touched   # zero diff in local-search/
+
+
 def _build_c_example(tmp_path, name="nqueens_c"):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(_lib.HEADER_PATH)))

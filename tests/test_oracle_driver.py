@@ -82,3 +82,46 @@ def test_ackley_iterated_local_search_reaches_the_global_minimum(dimensions):
         if b is not None and lo.Ackley.is_best(b[0]):
             break                                            # the reference keeps spinning through no-op rounds
     assert abs(ils.get_best_solution()[0]) <= 1e-2
+
+
+def _literal_pipeline(candidates, tabu, score, window):
+    """local_search.rs:315-325, literally: filter(!tabu) -> map(score) -> take(window) -> collect -> sort -> first."""
+    nb = []
+    for sol in candidates:
+        if sol in tabu:
+            continue
+        nb.append((score(sol), sol))
+        if len(nb) == window:
+            break
+    nb.sort()
+    return nb[0] if nb else None
+
+
+@pytest.mark.parametrize("n", [4, 8, 13, 20])
+def test_winner_only_proposer_is_equivalent_under_the_unchanged_pipeline(n):
+    # The Rust drop-in (INTEGRATION.md section 3, bindings/rust/examples/*/gpu.rs) leaves LocalSearch::execute untouched
+    # and plugs in a MoveProposer that yields ONLY the neighbourhood's winner.  With the tabu set the reference's History
+    # produces for its shipped configurations ({current}), feeding that one-element iterator through the literal
+    # filter/map/take/sort/first pipeline must select exactly what the full candidate stream selects.
+    import numpy as np
+    rng = np.random.default_rng(n)
+    for trial in range(60):
+        rows = tuple(int(x) for x in (rng.permutation(n) if trial % 2 else rng.integers(0, n, size=n)))
+        cols = [int(c) for c in rng.integers(0, n, size=int(rng.integers(1, 4)))]
+        window = int(rng.integers(1, len(cols) * n + 2))
+        tabu = {rows}
+
+        def full():                               # MoveIterator, examples/nqueens/src/lib.rs:214-234
+            for c in cols:
+                for v in range(n):
+                    b = list(rows); b[c] = v
+                    yield tuple(b)
+
+        expect = _literal_pipeline(full(), tabu, lambda b: lo.orc.nq_score(b), window)
+        res = lo.orc.nq_neighbourhood(rows, cols, window, "literal", want_scores=False)   # what the GPU call returns
+        if res["best_index"] < 0:
+            assert expect is None
+            continue
+        w = list(rows); w[cols[res["best_index"] // n]] = res["best_index"] % n
+        got = _literal_pipeline(iter([tuple(w)]), tabu, lambda b: lo.orc.nq_score(b), window)
+        assert got == expect == (res["best_score"], tuple(w))
