@@ -268,7 +268,7 @@ def run_rank(args, rank, world, device, sync, launcher):
                 out["cpu_baseline"]["gpu_over_cpu"] = value / cb["value"]
             if not args.no_extra and world == 1:
                 with torch.cuda.stream(stream):
-                    out["extra"] = extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info)
+                    out["extra"] = extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=not args.no_e2e)
             print(json.dumps(out), flush=True)
         sync.barrier()
         ctx.set_stream(None)
@@ -305,7 +305,7 @@ def build_report(args, world, R, n, info, value, elapsed, avg_launch_s, neighbou
     counters = load_counters()
     traffic = counters.get("hbm_traffic", {}).get(f"nq_{args.algo}_n{n}_r{R}", {}).get("bytes_per_launch")
     kernel = ("nq_scan_regs_kernel<BoardF32<64>, false>" if (args.algo == "scan" and 2048 < n <= 4096)
-              else ("nq_table_teams_kernel" if args.algo == "table" else "nq_scan_*"))
+              else ("nq_table_pairs_kernel" if args.algo == "table" else "nq_scan_*"))
     # VALU-issue roofline of the scan kernel: per neighbour every lane runs 4 full-rate fp32
     # instructions (sub, sub, mul+clamp, add) for each of its ceil64(n)/64 columns; achieved counts ONLY those
     # algorithmic instructions (measured SQ_INSTS_VALU per neighbour is in counters.*), peak is the spec issue rate.
@@ -339,8 +339,10 @@ def build_report(args, world, R, n, info, value, elapsed, avg_launch_s, neighbou
                     "restart and lives in VGPRs. Counter traffic: profiles/hbm_traffic.json"},
     }
     c = counters.get("kernels", {}).get("nq_scan_regs_kernel")
-    if c:
-        roof["counters"] = c
+    if c:   # committed rocprofv3 counters of this kernel on this workload (profiles/): what the kernel really issues
+        roof["counters"] = {k: c.get(k) for k in ("valu_wave_instr_per_candidate", "lds_wave_instr_per_candidate",
+                                                    "salu_wave_instr_per_candidate", "duration_us", "valu_issue_bound_us", "source")}
+        roof["counters"]["measured_issue_frac"] = (c["valu_issue_bound_us"] / 1e3 / (avg_launch_s * 1e3)) if c.get("valu_issue_bound_us") else None
     return {
         "metric": "neighbor evals/sec (N=4096 nqueens)" if n == 4096 else f"neighbor evals/sec (N={n} nqueens)",
         "value": value,
@@ -428,6 +430,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip extra.config4_end_to_end (16 host threads; rocprofv3 does not survive it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse ranks on one GPU)")
     ap.add_argument("--all-on-device", type=int, default=None,
                     help="rehearsal only: put every rank on this one device")
@@ -499,7 +502,7 @@ def main():
         dist.destroy_process_group()
 
 
-def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info):
+def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True):
     """Secondary lines (not `value`): the other kernel family on the same workload and the
     reference-shaped small launch (<= 204 proposed columns, window 5n), SURVEY 8(d) config 4."""
     out = {}
@@ -546,7 +549,7 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info):
                                                      ncols_full.data_ptr(), n, n * (n - 1), res_d.data_ptr()),
                   5 if algo == "scan" else 50)
         out[f"{algo}_full_neighbourhood"] = {"neighbours_per_s": R * n * (n - 1) / s, "ms_per_launch": s * 1e3,
-                                             "roofline": issue_roofline("nq_scan_regs_kernel" if algo == "scan" else "nq_table_teams_kernel", s)}
+                                             "roofline": issue_roofline("nq_scan_regs_kernel" if algo == "scan" else "nq_table_pairs_kernel", s)}
         w = 5 * n
         s = timed(lambda: ctx.nqueens_eval_batch_dev(R, n, rows_d.data_ptr(), cur_d.data_ptr(), cols_ref.data_ptr(),
                                                      ncols_ref.data_ptr(), mc, w, res_d.data_ptr()), 200)
@@ -581,7 +584,8 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info):
         s = (time.perf_counter() - t0) / reps
         out[f"fused_ls_step_host_round_trip_{RR}_restarts"] = {"us_per_call": s * 1e6, "candidates_per_call": RR * min(5 * n, mc * (n - 1)),
                                                                "note": "includes ctypes/numpy marshalling of the Python wrapper"}
-    out["config4_end_to_end_64_restarts_one_gpu"] = config4_end_to_end(ctx, n)
+    if e2e:
+        out["config4_end_to_end_64_restarts_one_gpu"] = config4_end_to_end(ctx, n)
     ctx.set_algo("scan")
     out.update(sched_measurements(ctx, torch, dev, timed, issue_roofline))
     # the HBM figure the rooflines divide by is the vendor's 8 TB/s; this is what a plain device-to-device
@@ -676,7 +680,7 @@ def sched_measurements(ctx, torch, dev, timed, issue_roofline):
         n_scored = int(res.cpu().numpy()[0, 0])
         out[name] = {"neighbours_per_s": n_scored / s, "us_per_launch": s * 1e6, "candidates_per_launch": n_scored,
                      "effective_GBps_at_144B": n_scored * 144 / s / 1e9,
-                     "roofline_eval_kernel_only": issue_roofline("sched_eval32_kernel_exhaustive" if "exhaustive" in name
+                     "roofline_eval_kernel_bound_over_whole_chain_time": issue_roofline("sched_eval32_kernel_exhaustive" if "exhaustive" in name
                                                                  else "sched_eval32_kernel_random65536", s)}
     # the same exhaustive neighbourhood through the host entry that generates the move list on the device:
     # only the 128-byte state and the 32-byte result cross PCIe (round trip incl. sync and the Python wrapper)

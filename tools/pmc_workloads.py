@@ -24,7 +24,7 @@ def main():
         _, cur = ctx.nqueens_col_scores(boards)
         cols = np.tile(np.arange(n, dtype=np.int32), (R, 1))
         ncols = np.full(R, n, dtype=np.int32)
-        for algo, kernel in (("scan", "nq_scan_regs_kernel"), ("table", "nq_table_teams_kernel")):
+        for algo, kernel in (("scan", "nq_scan_regs_kernel"), ("table", "nq_table_pairs_kernel")):
             ctx.set_algo(algo)
             for _ in range(reps):
                 out, _ = ctx.nqueens_eval_batch(boards, cur, cols, ncols, n * (n - 1))

@@ -74,7 +74,8 @@ def main():
     out = {}
     for wname, m in meta.items():
         match = m.get("match", wname)
-        cands = [k for k, e in raw.items() if match in e["kernel"] and k not in used]
+        cands = [k for k, e in raw.items() if match in e["kernel"] and k not in used
+                 and ("grid_blocks" not in m or e["grid_threads"] == m["grid_blocks"] * e["workgroup_size"])]
         if not cands:
             continue
         k = min(cands, key=lambda k: raw[k]["order"])
