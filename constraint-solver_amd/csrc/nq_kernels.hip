@@ -36,6 +36,15 @@
 
 namespace lsamd {
 
+#ifdef LS_NQ_STAMPS
+// Diagnostic build only (tools/table_stamps.py builds its own copy of the library with -DLS_NQ_STAMPS): wall-clock stamps
+// (100 MHz) of the TABLE kernel's phases, written to a buffer no other code reads.  The product build has none of this.
+__device__ unsigned long long g_nq_stamps[1024 * 8];
+#define LS_STAMP(P) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_nq_stamps[blockIdx.x * 8 + (P)] = wall_clock64(); } while (0)
+#else
+#define LS_STAMP(P) do { } while (0)
+#endif
+
 constexpr int NQ_DELTA_BIAS = 1 << 17; // |delta| <= n + 2 <= 32770
 constexpr unsigned long long NQ_KEY_EMPTY = ~0ull;
 
@@ -931,13 +940,15 @@ __device__ __forceinline__ void nq_pairs_unit(const unsigned *s_t16, int n, int 
     const int vbase = 2 * tv + par;
     unsigned m = NQ_KEY32_EMPTY;
     int i = i0;
+    // The per-lane running minimum orders by (count, position in the lane's walk): the position 2 i + {0, 1} is wave-uniform,
+    // so it enters the key as a scalar operand (no per-candidate VGPR arithmetic); v is rebuilt from it once per unit.
 #define LS_PAIR(J)                                                                                     \
-    const unsigned s##J = pR[(i + J) << SH] + pA[(i + J) << SH] + pB[(i + J) << SH];                      \
-    const int v##J = vbase + ((i + J) << (SH + 1));                                                           \
-    const unsigned lo##J = ((s##J << 15) & 0x7fffffffu) | (unsigned)v##J;                              \
-    const unsigned hi##J = ((s##J >> 16) << 15) | (unsigned)(v##J + 1);
+    const unsigned s##J = pR[(i + J) << SH] + pA[(i + J) << SH] + pB[(i + J) << SH];                   \
+    const unsigned lo##J = ((s##J << 15) & 0x7fffffffu) | (unsigned)(2 * (i + J));                     \
+    const unsigned hi##J = ((s##J >> 16) << 15) | (unsigned)(2 * (i + J) + 1);
 #define LS_PAIR_SCORES(J)                                                                              \
     if (WANT_SCORES) {                                                                                 \
+        const int v##J = vbase + ((i + J) << (SH + 1));                                                \
         if (v##J != rc) srow[v##J] = cur + 2ll * ((int)(lo##J >> 15) - conf_old);                      \
         if (v##J + 1 != rc && v##J + 1 < n) srow[v##J + 1] = cur + 2ll * ((int)(hi##J >> 15) - conf_old); \
     }
@@ -959,33 +970,36 @@ __device__ __forceinline__ void nq_pairs_unit(const unsigned *s_t16, int n, int 
             LS_PAIR_SCORES(0)
         }
     }
-    if (par && i0 == 0 && tv == 0) { // odd column: square v = 0 belongs to no pair
-        const unsigned k0 = ((unsigned)t16[0] + (unsigned)t16[oA - c + n] + (unsigned)t16[oB + c]) << 15;
-        m = k0 < m ? k0 : m;
-        if (WANT_SCORES && rc != 0) srow[0] = cur + 2ll * ((int)(k0 >> 15) - conf_old);
+    // position -> v:  v = vbase + 2 TL (pos >> 1) + (pos & 1)
+    auto v_of = [&](unsigned key) { return vbase + (int)(((key & 0x7fffu) >> 1) << (SH + 1)) + (int)(key & 1u); };
+    unsigned k_zero = NQ_KEY32_EMPTY; // odd column: square v = 0 belongs to no pair (lane 0 of the column's first part scores it)
+    if (par && i0 == 0 && tv == 0) {
+        k_zero = ((unsigned)t16[0] + (unsigned)t16[oA - c + n] + (unsigned)t16[oB + c]) << 15;
+        if (WANT_SCORES && rc != 0) srow[0] = cur + 2ll * ((int)(k_zero >> 15) - conf_old);
     }
-    const unsigned noop = ((unsigned)(conf_old + 3) << 15) | (unsigned)rc;
-    if (m == noop) { // this lane's minimum is the tabu square itself: walk again without it
+    const unsigned noop_cnt = (unsigned)(conf_old + 3);
+    if (m != NQ_KEY32_EMPTY && (m >> 15) == noop_cnt && v_of(m) == rc) { // this lane's minimum is the tabu square itself: walk again without it
         m = NQ_KEY32_EMPTY;
         for (int i2 = i0; i2 < i1; i2++) {
             i = i2;
-            if (vbase + (i << (SH + 1)) < n) {
+            const int v0 = vbase + (i << (SH + 1));
+            if (v0 < n) {
                 LS_PAIR(0)
                 if (v0 != rc) m = lo0 < m ? lo0 : m;
                 if (v0 + 1 != rc && v0 + 1 < n) m = hi0 < m ? hi0 : m;
             }
         }
-        if (par && i0 == 0 && tv == 0 && rc != 0) {
-            const unsigned k0 = ((unsigned)t16[0] + (unsigned)t16[oA - c + n] + (unsigned)t16[oB + c]) << 15;
-            m = k0 < m ? k0 : m;
-        }
     }
 #undef LS_PAIR
 #undef LS_PAIR_SCORES
-    if (m != NQ_KEY32_EMPTY) {
-        const int v = (int)(m & 0x7fffu);
-        best = u64min(best, nq_key((int)(m >> 15) - conf_old, nq_key_hi(v > rc ? 1 : 0, c, n, slot), v));
+    int cnt_best = -1, v_best = 0;
+    if (m != NQ_KEY32_EMPTY) { cnt_best = (int)(m >> 15); v_best = v_of(m); }
+    if (k_zero != NQ_KEY32_EMPTY && rc != 0 && (cnt_best < 0 || (int)(k_zero >> 15) <= cnt_best)) { // v = 0 precedes every other v
+        cnt_best = (int)(k_zero >> 15);
+        v_best = 0;
     }
+    if (cnt_best >= 0)
+        best = u64min(best, nq_key(cnt_best - conf_old, nq_key_hi(v_best > rc ? 1 : 0, c, n, slot), v_best));
 }
 
 template <int NT, int TL, bool WANT_SCORES>
@@ -1013,23 +1027,50 @@ __global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts)
     const long long u0 = units * chunk / n_chunks, u1 = units * (chunk + 1) / n_chunks;
     const bool do_partial = rem > 0 && chunk == n_chunks - 1;
     unsigned long long best = NQ_KEY_EMPTY;
+    LS_STAMP(0);
     if (u0 < u1 || do_partial) { // block-uniform
         const int oR1 = n, oA = 2 * n, oB = 4 * n + 2; // u16 indices (all even)
         const int words = (((6 * n + 4) >> 1) + 3) & ~3;
         int4 *s_rec = reinterpret_cast<int4 *>(s_t16 + words);
+        // every global read of the set-up is issued before the first LDS store: the board (NT == 1024: into registers) and
+        // the first pass's slot columns with their rows -- one memory latency instead of three in a row
+        const int slot_lo0 = (int)(u0 / parts);
+        const int slot_hi0 = u0 < u1 ? (int)((u1 - 1) / parts) : slot_lo0 - 1;
+        int pre_c = -1, pre_rc = -1;
+        if (tid < NQ_REC_CAP && slot_lo0 + tid <= slot_hi0) {
+            pre_c = cols[slot_lo0 + tid];
+            pre_rc = (unsigned)pre_c < (unsigned)n ? rows[pre_c] : -1;
+        }
+        constexpr int QV = NT == 1024 ? NQ_TABLE_LDS_MAX_N / 1024 : 1;
+        int qv[QV];
+        if constexpr (NT == 1024) {
+#pragma unroll
+            for (int kk = 0; kk < QV; kk++) {
+                const int j = tid + 1024 * kk;
+                qv[kk] = j < n ? rows[j] : -1;
+            }
+        }
+        LS_STAMP(1);
         for (int i = tid; i < words; i += NT) s_t16[i] = 0;
         __syncthreads();
-        for (int j = tid; j < n; j += NT) {
-            const int q = rows[j];
+        LS_STAMP(2);
+        auto count_queen = [&](int j, int q) {
             if ((unsigned)q < (unsigned)n) {
                 tab16_inc(s_t16, q);
                 if (q > 0) tab16_inc(s_t16, oR1 + q - 1);
                 tab16_inc(s_t16, oA + (q - j + n));
                 tab16_inc(s_t16, oB + (q + j));
             }
+        };
+        if constexpr (NT == 1024) {
+#pragma unroll
+            for (int kk = 0; kk < QV; kk++) count_queen(tid + 1024 * kk, qv[kk]);
+        } else {
+            for (int j = tid; j < n; j += NT) count_queen(j, rows[j]);
         }
         if (tid == 0) atomicAdd(&s_t16[(oR1 + n - 1) >> 1], NQ_PAIR_SENTINEL << (16 * ((oR1 + n - 1) & 1)));
         __syncthreads();
+        LS_STAMP(3);
         const unsigned short *t16 = reinterpret_cast<const unsigned short *>(s_t16);
         const long long cur = WANT_SCORES ? a.cur_scores[restart] : 0;
         const int steps = (n + 2 * TL - 1) >> (SH + 1);    // 2 TL values (TL pairs) per step
@@ -1040,13 +1081,15 @@ __global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts)
             const int pass_hi = pass_lo + NQ_REC_CAP - 1 < slot_hi ? pass_lo + NQ_REC_CAP - 1 : slot_hi;
             __syncthreads(); // the previous pass's records are no longer read
             for (int sl = pass_lo + tid; sl <= pass_hi; sl += NT) {
-                const int c = cols[sl];
-                const int rc = (unsigned)c < (unsigned)n ? rows[c] : -1;
+                const bool pre = pass_lo == slot_lo0; // first pass: loaded up front (NQ_REC_CAP <= NT: one slot per lane)
+                const int c = pre ? pre_c : cols[sl];
+                const int rc = pre ? pre_rc : ((unsigned)c < (unsigned)n ? rows[c] : -1);
                 int conf_old = 0;
                 if ((unsigned)rc < (unsigned)n) conf_old = (int)t16[rc] + (int)t16[oA + rc - c + n] + (int)t16[oB + rc + c] - 3;
                 s_rec[sl - pass_lo] = make_int4(c, (unsigned)rc < (unsigned)n ? rc : -1, conf_old, 0);
             }
             __syncthreads();
+            LS_STAMP(4);
             long long ua = (long long)pass_lo * parts, ub = (long long)(pass_hi + 1) * parts;
             ua = ua < u0 ? u0 : ua;
             ub = ub > u1 ? u1 : ub;
@@ -1086,9 +1129,11 @@ __global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts)
             }
         }
     }
+    LS_STAMP(5);
     best = wave_min_u64(best);
     if (lane == 0) s_best[wib] = best;
     __syncthreads();
+    LS_STAMP(6);
     if (tid == 0) {
         unsigned long long b = s_best[0];
         for (int i = 1; i < NT / 64; i++) b = u64min(b, s_best[i]);
@@ -1599,6 +1644,7 @@ static int launch_table_teams_t(ls_ctx *ctx, const NqArgs &a, long long window)
     const long long by_waves = 32 / (NT / 64);
     per_cu = per_cu > by_waves ? by_waves : per_cu;
     per_cu = per_cu < 1 ? 1 : per_cu;
+    if (ctx->nq_table_variant >= 30) per_cu = 1; // measurement knob: one block per CU (fewer, longer-lived workgroups)
     long long bpr = ((long long)ctx->n_cus * per_cu) / a.n_restarts;
     if (bpr < 1) bpr = 1;
     // work units: whole slots x parts; a unit should keep a team busy for >= 4 steps (of TL values, or TL pairs)
@@ -1821,3 +1867,10 @@ int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long 
 }
 
 } // namespace lsamd
+
+#ifdef LS_NQ_STAMPS
+extern "C" int ls_debug_nq_stamps(unsigned long long *out, int count)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lsamd::g_nq_stamps), (size_t)count * 8);
+}
+#endif

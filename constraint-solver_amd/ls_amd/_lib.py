@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
-SO_PATH = os.path.join(_PKG, "lib", "libls_amd.so")
+SO_PATH = os.environ.get("LS_AMD_LIB") or os.path.join(_PKG, "lib", "libls_amd.so")   # LS_AMD_LIB: a diagnostic build (tools/table_stamps.py)
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "ls_amd.h")
 
 LS_OK = 0
