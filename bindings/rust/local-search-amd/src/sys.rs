@@ -41,6 +41,9 @@ extern "C" {
                               name: *mut c_char, name_cap: c_int) -> c_int;
     pub fn ls_nqueens_eval(ctx: *mut ls_ctx, n: i32, rows: *const i32, cur_score: i64, cols: *const i32, n_cols: i32,
                            window: i64, out: *mut ls_nq_result, scores_out: *mut i64) -> c_int;
+    pub fn ls_nqueens_eval_tabu(ctx: *mut ls_ctx, n: i32, rows: *const i32, cur_score: i64, cols: *const i32, n_cols: i32,
+                                window: i64, tabu_positions: *const i64, n_tabu: i32, out: *mut ls_nq_result,
+                                scores_out: *mut i64) -> c_int;
     pub fn ls_nqueens_eval_batch(ctx: *mut ls_ctx, n_restarts: i32, n: i32, rows: *const i32, cur_scores: *const i64,
                                  cols: *const i32, n_cols: *const i32, max_cols: i32, window: i64,
                                  results: *mut ls_nq_result, scores_out: *mut i64) -> c_int;

@@ -10,8 +10,10 @@
 //   Solution generate_initial_solution(Rng&)                       InitialSolutionGenerator
 //   Score    score(const Solution&)                                 SolutionScoreCalculator
 //   Solution propose_new_starting_solution(current, is_best_in_history, Rng&)   Perturbation
-//   bool     best_of_neighbourhood(current, Rng& ls_rng, window, ScoredSolution& out)
-//            == MoveProposer + tabu filter + score + take + sort + first
+//   bool     best_of_neighbourhood(current, Rng& ls_rng, window, ScoredSolution& out, const History& tabu)
+//            == MoveProposer + tabu filter + score + take + sort + first; `tabu` is LocalSearch's own History: its
+//            set is {current} for every configuration the reference ships (the GPU's built-in rule) and anything
+//            else it holds is handed to the GPU as an exclusion list
 #pragma once
 
 #include <cstdint>
@@ -84,6 +86,7 @@ public:
         return true;
     }
     size_t tabu_size() const { return lookup_.size(); }
+    const std::set<typename P::Solution> &tabu() const { return lookup_; }
     uint64_t iteration_count = 0;
 
 private:
@@ -134,13 +137,13 @@ public:
         for (uint64_t it = 0; it < max_iterations_; it++) {
             history_.seen_solution(current);
             if (P::is_best(current.score)) return current;
-            // :315-325 — the GPU seam.  The evaluator's tabu rule is "candidate == current";
-            // the History above must agree with it (checked: exactly one tabu entry, the current one).
-            if (history_.tabu_size() != 1 || !history_.is_solution_tabu(current.solution))
-                throw std::runtime_error("tabu set is not {current}: unsupported History configuration");
+            // :315-325 — the GPU seam.  The evaluator's built-in tabu rule is "candidate == current"; seen_solution has
+            // just made sure the current solution IS in the set, whatever else a general History keeps there.
+            if (!history_.is_solution_tabu(current.solution))
+                throw std::runtime_error("History invariant broken: the current solution is not tabu");
             SS nb;
             ls_iterations++;
-            if (p_->best_of_neighbourhood(current, rng_, window_size_, nb)) {
+            if (p_->best_of_neighbourhood(current, rng_, window_size_, nb, history_)) {
                 if (nb.score < current.score) {
                     best = nb;
                     no_improvement_for = 0;

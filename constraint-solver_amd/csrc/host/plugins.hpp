@@ -4,6 +4,7 @@
 // every score and every neighbourhood goes through the C ABI to the HIP kernels.
 #pragma once
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -196,6 +197,7 @@ struct NQueensProblem {
 
     NQueensProblem(ls_ctx *c, size_t n, NqBatcher *b = nullptr) : ctx(c), board_size(n), batcher(b) {}
 
+    static const int64_t *rows_dummy() { static const int64_t z = 0; return &z; }
     std::vector<int32_t> pack(const Solution &s) const
     {
         std::vector<int32_t> r(s.size());
@@ -281,12 +283,47 @@ struct NQueensProblem {
     }
 
     // local_search.rs:315-325 for this plug-in: one GPU launch
-    template <class R> bool best_of_neighbourhood(const SS &current, R &rng, size_t window, SS &out)
+    // General History (all_solution_iteration_expiry == 0: the tabu set keeps every visited board, local_search.rs:155-199):
+    // the candidates that equal a tabu board other than the current one, as unfiltered positions k = slot * n + value.
+    // A candidate differs from the current board in exactly one column, so only tabu boards at Hamming distance 1 matter.
+    std::vector<int64_t> tabu_positions(const Solution &cur, const std::vector<int32_t> &cols, const History<NQueensProblem> &tabu) const
+    {
+        std::vector<int64_t> out;
+        const size_t n = cur.size();
+        for (const Solution &t : tabu.tabu()) {
+            if (t.size() != n) continue;
+            size_t diff_col = 0, diffs = 0;
+            for (size_t j = 0; j < n && diffs < 2; j++)
+                if (t[j] != cur[j]) { diff_col = j; diffs++; }
+            if (diffs != 1) continue; // the current board itself (no-ops: always tabu on the device) or too far away
+            for (size_t s = 0; s < cols.size(); s++)
+                if ((size_t)cols[s] == diff_col) out.push_back((int64_t)(s * n) + t[diff_col]);
+        }
+        std::sort(out.begin(), out.end());
+        out.erase(std::unique(out.begin(), out.end()), out.end());
+        return out;
+    }
+
+    template <class R> bool best_of_neighbourhood(const SS &current, R &rng, size_t window, SS &out, const History<NQueensProblem> &tabu)
     {
         const auto T0 = std::chrono::steady_clock::now();
         const std::vector<int32_t> cols = propose_columns(current.solution, rng);
         if (cols.empty()) return false;
         const std::vector<int32_t> rows = pack(current.solution);
+        if (tabu.tabu_size() != 1) { // more than {current} is tabu: exclusion list, one-restart launch (never batched)
+            const std::vector<int64_t> excl = tabu_positions(current.solution, cols, tabu);
+            ls_nq_result res;
+            check_rc(ctx, ls_nqueens_eval_tabu(ctx, (int32_t)rows.size(), rows.data(), current.score, cols.data(), (int32_t)cols.size(),
+                                               (int64_t)window, excl.empty() ? rows_dummy() : excl.data(), (int32_t)excl.size(), &res, nullptr),
+                     "ls_nqueens_eval_tabu");
+            gpu_evals++;
+            neighbours_scored += (uint64_t)res.n_scored;
+            if (res.best_index < 0) return false;
+            out.solution = current.solution;
+            out.solution[(size_t)res.best_col] = res.best_value;
+            out.score = res.best_score;
+            return true; // the winner's column scores are fetched by the next col_scores() call (a cache miss)
+        }
         const auto T1 = std::chrono::steady_clock::now();
         t_prop += std::chrono::duration<double>(T1 - T0).count();
         ls_nq_result res;
@@ -402,9 +439,49 @@ struct SchedProblem {
         }
     }
 
-    bool best_of_neighbourhood(const SS &current, ChaCha20Rng &rng, size_t window, SS &out)
+    static Solution apply_move(const Solution &base, const ls_sched_move &m)
+    {
+        Solution s = base;
+        if (m.type == 0) s[(size_t)m.a] = m.b;
+        else {
+            s[(size_t)m.a] = base[(size_t)m.b];
+            s[(size_t)m.b] = base[(size_t)m.a];
+        }
+        return s;
+    }
+
+    // General History: moves of the stream prefix that lead to a tabu solution other than the current one are marked
+    // LS_SCHED_MOVE_SKIP in a per-call copy of the list (the resident list stays as drawn).
+    bool best_of_neighbourhood_general(const SS &current, ChaCha20Rng &rng, size_t window, SS &out, const History<SchedProblem> &tabu)
+    {
+        size_t want = window + window / 4 + 16;
+        for (;;) {
+            extend_stream(rng, want);
+            std::vector<ls_sched_move> moves(stream.begin(), stream.begin() + (long)want);
+            for (ls_sched_move &m : moves) {
+                const Solution cand = apply_move(current.solution, m);
+                if (cand != current.solution && tabu.is_solution_tabu(cand)) m.type = LS_SCHED_MOVE_SKIP;
+            }
+            ls_sched_result res;
+            check_rc(ctx, ls_sched_eval(ctx, current.solution.data(), moves.data(), (int64_t)moves.size(), (int64_t)window, &res, nullptr, nullptr),
+                     "ls_sched_eval");
+            gpu_evals++;
+            if ((size_t)res.n_scored == window) {
+                neighbours_scored += (uint64_t)res.n_scored;
+                out.solution = apply_move(current.solution, stream[(size_t)res.best_index]);
+                out.score = Score(res.best_hard, res.best_soft);
+                return true;
+            }
+            if (want > 64 * window + (1u << 16))
+                throw std::runtime_error("the random move stream cannot fill the window (the reference would not terminate)");
+            want *= 2;
+        }
+    }
+
+    bool best_of_neighbourhood(const SS &current, ChaCha20Rng &rng, size_t window, SS &out, const History<SchedProblem> &tabu)
     {
         if (window == 0) return false;
+        if (tabu.tabu_size() != 1) return best_of_neighbourhood_general(current, rng, window, out, tabu);
         size_t want = window + window / 4 + 16;
         for (;;) {
             extend_stream(rng, want);

@@ -34,6 +34,9 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
                       ls_nq_result *results_d, long long *scores_out_d, int *next_rows_d);
 int nq_col_scores_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, long long *col_scores_d,
                       long long *scores_d);
+int nq_eval_excl_dev(ls_ctx *ctx, int n, const int *rows_d, const long long *cur_d, const int *cols_d, const int *n_cols_d,
+                     int max_cols, long long window, const long long *excl_d, int n_excl, ls_nq_result *results_d,
+                     long long *scores_out_d);
 bool nq_step_eligible(const ls_ctx *ctx, int n, int max_cols, long long window);
 int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long long *cur, const int *cols,
                 const int *n_cols, int max_cols, long long window, ls_nq_result *results, int *next_rows,
@@ -475,6 +478,51 @@ int ls_nqueens_eval(ls_ctx *ctx, int32_t n, const int32_t *rows, int64_t cur_sco
     return ls_nqueens_eval_batch(ctx, 1, n, rows, &cur_score, cols, &n_cols, n_cols, window, out, scores_out);
 }
 
+int ls_nqueens_eval_tabu(ls_ctx *ctx, int32_t n, const int32_t *rows, int64_t cur_score, const int32_t *cols, int32_t n_cols,
+                         int64_t window, const int64_t *tabu_positions, int32_t n_tabu, ls_nq_result *out, int64_t *scores_out)
+{
+    if (ctx && n_tabu == 0) return ls_nqueens_eval(ctx, n, rows, cur_score, cols, n_cols, window, out, scores_out);
+    LS_BIND(ctx);
+    int rc = nq_check_dims(ctx, 1, n, n_cols, window);
+    if (rc != LS_OK) return rc;
+    LS_REQUIRE(ctx, rows && out && (cols || n_cols == 0) && n_tabu >= 0 && tabu_positions, "null pointer / negative count");
+    for (int i = 0; i < n; i++) LS_REQUIRE(ctx, rows[i] >= 0 && rows[i] < n, "rows[%d] = %d outside [0, %d)", i, rows[i], n);
+    for (int s = 0; s < n_cols; s++) LS_REQUIRE(ctx, cols[s] >= 0 && cols[s] < n, "cols[%d] = %d outside [0, %d)", s, cols[s], n);
+    for (int i = 0; i < n_tabu; i++) {
+        const int64_t k = tabu_positions[i];
+        LS_REQUIRE(ctx, k >= 0 && k < (int64_t)n_cols * n, "tabu_positions[%d] = %lld outside the candidate list", i, (long long)k);
+        LS_REQUIRE(ctx, i == 0 || tabu_positions[i - 1] < k, "tabu_positions must be strictly ascending (entry %d)", i);
+        LS_REQUIRE(ctx, (int)(k % n) != rows[cols[k / n]], "tabu_positions[%d] is a no-op (always tabu; do not list it)", i);
+    }
+    const size_t rows_b = (size_t)n * 4, cols_b = (size_t)n_cols * 4, ex_b = (size_t)n_tabu * 8,
+                 sc_b = scores_out ? (size_t)n_cols * n * 8 : 0;
+    // inputs: cur | n_cols | excl | rows | cols ;  output: result
+    const size_t o_cur = 0, o_nc = 8, o_ex = 256, o_rows = align256(o_ex + ex_b), o_cols = align256(o_rows + rows_b),
+                 in_b = align256(o_cols + cols_b);
+    {
+        hipError_t e = ctx->stage_in.reserve(in_b);
+        if (e == hipSuccess) e = ctx->stage_out.reserve(256);
+        if (e != hipSuccess) return set_err(ctx, LS_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
+    }
+    if (sc_b) LS_RESERVE(ctx, ctx->nq_scores, sc_b);
+    Staging &si = ctx->stage_in, &so = ctx->stage_out;
+    *si.h<long long>(o_cur) = cur_score;
+    *si.h<int>(o_nc) = n_cols;
+    memcpy(si.h<char>(o_ex), tabu_positions, ex_b);
+    memcpy(si.h<char>(o_rows), rows, rows_b);
+    if (cols_b) memcpy(si.h<char>(o_cols), cols, cols_b);
+    LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = nq_eval_excl_dev(ctx, n, si.d<int>(o_rows), si.d<long long>(o_cur), si.d<int>(o_cols), si.d<int>(o_nc), n_cols,
+                          nq_clamp_window(window, n_cols, n), si.d<long long>(o_ex), n_tabu, so.d<ls_nq_result>(0),
+                          sc_b ? ctx->nq_scores.as<long long>() : nullptr);
+    if (rc != LS_OK) return rc;
+    LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, 256, hipMemcpyDeviceToHost, ctx->stream));
+    if (sc_b) LS_HIP(ctx, hipMemcpyAsync(scores_out, ctx->nq_scores.p, sc_b, hipMemcpyDeviceToHost, ctx->stream));
+    LS_SYNC(ctx);
+    *out = *so.h<ls_nq_result>(0);
+    return LS_OK;
+}
+
 int ls_nqueens_col_scores_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_t *rows_d,
                               int64_t *col_scores_d, int64_t *scores_d)
 {
@@ -633,7 +681,7 @@ int ls_sched_eval_batch(ls_ctx *ctx, int32_t n_restarts, const int32_t *states, 
             else if (m.type == 1)
                 LS_REQUIRE(ctx, m.a >= 0 && m.a < S && m.b >= 0 && m.b < S, "move %lld of restart %d: bad SwapDays(%d, %d)",
                            k, r, m.a, m.b);
-            else
+            else if (m.type != LS_SCHED_MOVE_SKIP)
                 return set_err(ctx, LS_ERR_INVALID, "move %lld of restart %d: unknown type %d", k, r, m.type);
         }
     }
@@ -703,7 +751,7 @@ static int sched_check_moves(ls_ctx *ctx, const ls_sched_move *moves, long long 
         else if (m.type == 1)
             LS_REQUIRE(ctx, m.a >= 0 && m.a < S && m.b >= 0 && m.b < S, "move %lld of restart %d: bad SwapDays(%d, %d)", k, r,
                        m.a, m.b);
-        else
+        else if (m.type != LS_SCHED_MOVE_SKIP)
             return set_err(ctx, LS_ERR_INVALID, "move %lld of restart %d: unknown type %d", k, r, m.type);
     }
     return LS_OK;

@@ -38,10 +38,6 @@ namespace {
 int check_params(ls_ctx *ctx, const ls_solver_params *p)
 {
     if (!p) return lsamd::set_err(ctx, LS_ERR_INVALID, "params is NULL");
-    if (p->all_solution_iteration_expiry == 0)
-        return lsamd::set_err(ctx, LS_ERR_UNSUPPORTED,
-                              "all_solution_iteration_expiry == 0 makes the reference's tabu set grow without bound; "
-                              "the GPU path implements tabu == {current} (every configuration the reference ships)");
     if (p->best_solutions_capacity == 0)
         return lsamd::set_err(ctx, LS_ERR_INVALID, "best_solutions_capacity must be >= 1 (the reference would panic)");
     return LS_OK;
@@ -260,6 +256,9 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
         const int R = (int)m->seeds.size();
         const int T = m->n_slots < R ? m->n_slots : R; // slots = host threads; a finished restart's slot takes the next seed
         const bool lockstep = m->mode == LS_MULTI_LOCKSTEP;
+        if (lockstep && m->params.all_solution_iteration_expiry == 0)
+            throw std::runtime_error("a History that keeps more than the current solution tabu (all_solution_iteration_expiry == 0) "
+                                     "issues one-restart launches: use LS_MULTI_FREE_RUNNING");
         NqBatcher batcher(m->ctx, (int32_t)m->board_size, T);
         std::vector<std::string> errors((size_t)T);
         std::vector<uint64_t> ls_it((size_t)R, 0), scored((size_t)R, 0), rounds((size_t)R, 0), launches((size_t)T, 0);

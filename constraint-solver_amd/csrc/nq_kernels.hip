@@ -1282,6 +1282,81 @@ __global__ __launch_bounds__(1024) void nq_col_scores_lds_kernel(const int *rows
     }
 }
 
+// ======================================================= general tabu sets
+// History configurations whose tabu set is more than {current} (all_solution_iteration_expiry == 0: the reference's set
+// grows, local_search.rs:173-195).  The caller passes the unfiltered positions k whose boards are tabu besides the no-ops
+// (sorted, each a real candidate); they are neither scored nor counted, so every later candidate's window rank drops by
+// the number of excluded positions before it.  One lane per position, count tables in global memory; this path serves a
+// configuration no reference example uses and is written for clarity, not speed.  One restart per launch.
+__global__ __launch_bounds__(256) void nq_table_excl_kernel(NqArgs a, const long long *excl, int n_excl, unsigned long long *scored_count)
+{
+    __shared__ unsigned long long s_best[4];
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int n = a.n;
+    const int *__restrict__ rows = a.rows, *__restrict__ cols = a.cols;
+    const int *__restrict__ tR = a.tabs, *__restrict__ tA = tR + n, *__restrict__ tB = tR + 3 * n;
+    int ncols = a.n_cols[0];
+    ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
+    const long long K = nq_k_limit((long long)ncols * n, n, a.window + n_excl); // positions a rank below the window can have
+    const long long cur = a.cur_scores[0];
+    unsigned long long best = NQ_KEY_EMPTY;
+    int scored = 0;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < K; k += (long long)gridDim.x * 256) {
+        const int slot = (int)(k / n), v = (int)(k - (long long)slot * n);
+        const int c = cols[slot];
+        const int rc = (unsigned)c < (unsigned)n ? rows[c] : -1;
+        if ((unsigned)rc >= (unsigned)n || v == rc) continue;
+        int lo = 0, hi = n_excl; // excluded positions before k
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (excl[mid] < k) lo = mid + 1; else hi = mid;
+        }
+        if (lo < n_excl && excl[lo] == k) continue; // tabu: not scored, not counted
+        const long long rank = (long long)slot * (n - 1) + v - (v > rc ? 1 : 0) - lo;
+        if (rank >= a.window) continue;
+        const int conf_old = tR[rc] + tA[rc - c + n] + tB[rc + c] - 3;
+        const int delta = tR[v] + tA[v - c + n] + tB[v + c] - conf_old;
+        best = u64min(best, nq_key(delta, nq_key_hi(v > rc ? 1 : 0, c, n, slot), v));
+        if (a.scores_out) a.scores_out[k] = cur + 2ll * delta;
+        scored++;
+    }
+    best = wave_min_u64(best);
+    scored = wave_sum_i32(scored);
+    if (lane == 0) { s_best[wib] = best; s_cnt[wib] = scored; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long b = u64min(u64min(s_best[0], s_best[1]), u64min(s_best[2], s_best[3]));
+        if (b != NQ_KEY_EMPTY) atomicMin(&a.best_keys[0], b);
+        const int t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (t) atomicAdd(scored_count, (unsigned long long)t);
+    }
+}
+
+__global__ void nq_finalize_excl_kernel(NqArgs a, ls_nq_result *results, unsigned long long *scored_count)
+{
+    const int n = a.n;
+    ls_nq_result out;
+    out.n_scored = (long long)*scored_count;
+    *scored_count = 0;
+    const unsigned long long key = a.best_keys[0];
+    a.best_keys[0] = NQ_KEY_EMPTY;
+    if (key == NQ_KEY_EMPTY || out.n_scored == 0) {
+        out.n_scored = 0; out.best_index = -1; out.best_score = 0; out.best_col = -1; out.best_value = -1;
+    } else {
+        const int slot = (int)(key & 0x7fffu);
+        const int v = (int)((key >> 15) & 0x7fffu);
+        const int colkey = (int)((key >> 30) & 0x7fffu);
+        const int is_up = (int)((key >> 45) & 1u);
+        const int delta = (int)(key >> 46) - NQ_DELTA_BIAS;
+        out.best_index = (long long)slot * n + v;
+        out.best_score = a.cur_scores[0] + 2ll * delta;
+        out.best_col = is_up ? n - 1 - colkey : colkey;
+        out.best_value = v;
+    }
+    results[0] = out;
+}
+
 // ============================================================= fused LS step
 // One LS iteration of one restart in ONE launch, one 1024-thread block per restart (the solver's
 // per-iteration shape: window = 5n => ~5 columns, ~20k candidates, where launch latency, not
@@ -1500,6 +1575,12 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
 }
 
 // ================================================================ launchers
+static long long nq_clamp_k(long long k_all, int n, int max_cols, long long window)
+{
+    if (n > 1 && window / (n - 1) < max_cols) return (window / (n - 1) + 1) * n; // reachable by take(window)
+    return k_all;
+}
+
 static int nq_blocks_per_cu(const void *fn, size_t dyn_lds)
 {
     int nb = 0;
@@ -1791,6 +1872,55 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
         }
     }
     hipLaunchKernelGGL(nq_finalize_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a, results_d, next_rows_d);
+    LS_HIP(ctx, hipGetLastError());
+    ctx->nq_keys_dirty = false;
+    return LS_OK;
+}
+
+// One restart, every pointer in device memory; excl_d: sorted tabu positions (see nq_table_excl_kernel).
+int nq_eval_excl_dev(ls_ctx *ctx, int n, const int *rows_d, const long long *cur_d, const int *cols_d, const int *n_cols_d,
+                     int max_cols, long long window, const long long *excl_d, int n_excl, ls_nq_result *results_d,
+                     long long *scores_out_d)
+{
+    {   // keys: the same invariant as nq_eval_batch_dev (all EMPTY between calls)
+        const void *before = ctx->nq_keys.p;
+        LS_RESERVE(ctx, ctx->nq_keys, 8);
+        if (ctx->nq_keys.p != before || ctx->nq_keys_dirty) {
+            hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((ctx->nq_keys.cap / 8 + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->nq_keys.as<long long>(), -1ll, (long long)(ctx->nq_keys.cap / 8));
+            LS_HIP(ctx, hipGetLastError());
+        }
+        ctx->nq_keys_dirty = true;
+    }
+    LS_RESERVE(ctx, ctx->nq_totals, 8); // the scored-candidate counter (the buffer is shared with ls_nqueens_col_scores: cleared per call)
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->nq_totals.as<long long>(), 0ll, 1ll);
+    LS_HIP(ctx, hipGetLastError());
+    NqArgs a;
+    a.rows = rows_d; a.cur_scores = cur_d; a.cols = cols_d; a.n_cols = n_cols_d;
+    a.n = n; a.n_restarts = 1; a.max_cols = max_cols; a.window = window;
+    a.best_keys = ctx->nq_keys.as<unsigned long long>();
+    a.scores_out = scores_out_d;
+    const long long k_all = (long long)max_cols * n;
+    if (scores_out_d && k_all > 0) {
+        long long g = (k_all + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, scores_out_d, (long long)INT64_MIN, k_all);
+        LS_HIP(ctx, hipGetLastError());
+    }
+    int *tabs = nullptr; int stride = 0;
+    int rc = build_tables(ctx, 1, n, rows_d, &tabs, &stride);
+    if (rc != LS_OK) return rc;
+    a.tabs = tabs; a.tab_stride = stride;
+    if (max_cols > 0 && n > 1) {
+        long long k_max = nq_clamp_k(k_all, n, max_cols, window + n_excl);
+        long long g = (k_max + 255) / 256;
+        const long long cap = (long long)ctx->n_cus * 8;
+        g = g > cap ? cap : (g < 1 ? 1 : g);
+        hipLaunchKernelGGL(nq_table_excl_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, a, excl_d, n_excl,
+                           ctx->nq_totals.as<unsigned long long>());
+        LS_HIP(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(nq_finalize_excl_kernel, dim3(1), dim3(1), 0, ctx->stream, a, results_d, ctx->nq_totals.as<unsigned long long>());
     LS_HIP(ctx, hipGetLastError());
     ctx->nq_keys_dirty = false;
     return LS_OK;

@@ -877,7 +877,8 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
     const long long batches = max_moves > 0 ? (max_moves + 63) / 64 : 1;
     const int split = batches * n_restarts >= 4096 ? 1 : 4; // few batches: spread each over four wavefronts
     long long bpr = (batches * split + 3) / 4;
-    const long long cap = ((long long)ctx->n_cus * 8) / n_restarts;
+    static const int blocks_per_cu = getenv("LS_SCHED_BLOCKS_PER_CU") ? atoi(getenv("LS_SCHED_BLOCKS_PER_CU")) : 8; // measurement knob
+    const long long cap = ((long long)ctx->n_cus * blocks_per_cu) / n_restarts;
     if (bpr > cap) bpr = cap;
     if (bpr < 1) bpr = 1;
     // workspace: k_end[R] | n_scored[R] | part_key[R][bpr] | part_idx[R][bpr] | chunk_counts[R][n_chunks]

@@ -122,6 +122,20 @@ class Context:
         out, scores = self.nqueens_eval_batch(rows, [cur_score], cols, [cols.shape[1]], window, want_scores)
         return out[0], (scores[0] if scores is not None else None)
 
+    def nqueens_eval_tabu(self, rows, cur_score, cols, window, tabu_positions, want_scores=False):
+        """ls_nqueens_eval_tabu: tabu_positions = sorted unfiltered positions of candidates equal to a tabu board other
+        than `rows` (general History)."""
+        rows = _c(rows, np.int32).reshape(-1)
+        cols = _c(cols, np.int32).reshape(-1)
+        tp = _c(tabu_positions, np.int64).reshape(-1)
+        n = len(rows)
+        res = NqResult()
+        scores = np.empty(len(cols) * n, dtype=np.int64) if want_scores else None
+        self._check(self._l.ls_nqueens_eval_tabu(self._h, n, _vp(rows), int(cur_score), _vp(cols), len(cols), int(window),
+                                                 _vp(tp), len(tp), C.byref(res), _vp(scores)))
+        return dict(n_scored=res.n_scored, best_index=res.best_index, best_score=res.best_score, best_col=res.best_col,
+                    best_value=res.best_value), scores
+
     def nqueens_eval_batch_dev(self, n_restarts, n, rows_d, cur_scores_d, cols_d, n_cols_d, max_cols, window,
                                results_d, scores_out_d=None):
         """All arguments are device addresses (ints); asynchronous."""

@@ -69,6 +69,7 @@ SIGNATURES = {
     "ls_ctx_device_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                      C.c_char_p, C.c_int]),
     "ls_nqueens_eval": (C.c_int, [_vp, _i32, _vp, _i64, _vp, _i32, _i64, _vp, _vp]),
+    "ls_nqueens_eval_tabu": (C.c_int, [_vp, _i32, _vp, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp]),
     "ls_nqueens_eval_batch": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
     "ls_nqueens_eval_batch_dev": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
     "ls_nqueens_eval_batch_next": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),

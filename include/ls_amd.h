@@ -166,6 +166,16 @@ int ls_nqueens_eval_batch_next_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n,
                                    int64_t window, ls_nq_result *results_d, int32_t *next_rows_d,
                                    int64_t *next_col_scores_d, int64_t *next_scores_d);
 
+/* ls_nqueens_eval for a History whose tabu set holds more than the current board (all_solution_iteration_expiry == 0:
+ * the reference's set then keeps every visited solution, local-search/src/local_search.rs:155-199; no configuration the
+ * reference ships does this).  tabu_positions: the unfiltered positions k = slot * n + value of the candidates that equal
+ * a tabu board OTHER than `rows` itself (the no-ops are always tabu and need not be listed), strictly ascending, each a
+ * real candidate (value != rows[cols[slot]]).  They are neither scored nor counted: candidates behind them move up in
+ * the window exactly as after the reference's filter (:319-321).  n_tabu == 0 is ls_nqueens_eval. */
+int ls_nqueens_eval_tabu(ls_ctx *ctx, int32_t n, const int32_t *rows, int64_t cur_score, const int32_t *cols,
+                         int32_t n_cols, int64_t window, const int64_t *tabu_positions, int32_t n_tabu,
+                         ls_nq_result *out, int64_t *scores_out);
+
 /* get_col_scores + its sum (examples/nqueens/src/lib.rs:74-87,130-139) for a
  * batch of boards, by occupancy count tables: col_scores[n_restarts][n]
  * (nullable), scores[n_restarts] (nullable).  This is the vector the move
@@ -184,9 +194,15 @@ int ls_nqueens_col_scores_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, const 
  * (the reference stores one more than it scores, lib.rs:407-411);
  * the first n_days_scored are scored (lib.rs:181-192).
  */
+#define LS_SCHED_MOVE_CHANGE_DAY 0
+#define LS_SCHED_MOVE_SWAP_DAYS  1
+#define LS_SCHED_MOVE_SKIP       2  /* not a candidate: the caller found the solution this move leads to in its tabu set
+                                       (a History holding more than the current solution, local_search.rs:155-199);
+                                       neither scored nor counted, exactly like a move that reproduces the current state */
 typedef struct ls_sched_move {
     int32_t type; /* 0 = ChangeDay: day a <- employee index b   (lib.rs:466-470)
-                     1 = SwapDays : days a and b swap employees (lib.rs:471-478) */
+                     1 = SwapDays : days a and b swap employees (lib.rs:471-478)
+                     2 = skip (a, b ignored) */
     int32_t a;
     int32_t b;
 } ls_sched_move;
@@ -278,7 +294,8 @@ typedef struct ls_solver_params {        /* MainArgs, examples/nqueens/src/main.
     uint64_t window_size;
     uint64_t best_solutions_capacity;
     uint64_t all_solutions_capacity;
-    uint64_t all_solution_iteration_expiry;   /* must be >= 1: tabu == {current} */
+    uint64_t all_solution_iteration_expiry;   /* >= 1 (every shipped configuration): tabu == {current}, SURVEY 3.4-1;
+                                                 0: the tabu set grows (served through ls_nqueens_eval_tabu / LS_SCHED_MOVE_SKIP) */
     uint64_t iterated_local_search_max_iterations;
     uint64_t max_allow_no_improvement_for;
 } ls_solver_params;

@@ -400,9 +400,11 @@ class NQueens:
         cols = self.propose_columns(current[1], rng)
         if cols is None:
             return None
-        # the oracle's tabu rule is `candidate == current`; the literal History must agree
-        assert history.lookup == {current[1]}
-        res = orc.nq_neighbourhood(current[1], cols, window, self.formulation, want_scores=False)
+        if history.lookup == {current[1]}:      # every shipped configuration: the tabu set is {current}
+            res = orc.nq_neighbourhood(current[1], cols, window, self.formulation, want_scores=False)
+        else:                                   # general History (all_solution_iteration_expiry == 0): literal HashSet filter
+            assert current[1] in history.lookup
+            res = orc.nq_neighbourhood_tabu(current[1], cols, window, sorted(history.lookup), want_scores=False)
         if res["best_index"] < 0:
             return None
         b = list(current[1])
@@ -445,7 +447,7 @@ class Scheduling:
         return tuple(gen_index(rng, self.E) for _ in range(self.S))
 
     def neighbourhood_first(self, current, rng, window, history):
-        assert history.lookup == {current[1]}
+        assert current[1] in history.lookup        # seen_solution always leaves the current solution in the set
         stream = rng.clone()                       # lib.rs:488 — the proposer never advances LocalSearch's rng
         e = current[1]
         best = None

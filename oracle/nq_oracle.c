@@ -128,6 +128,45 @@ int orc_nq_neighbourhood_literal(const int64_t *rows, int64_t n,
     return 0;
 }
 
+/*
+ * The same pipeline for a GENERAL tabu set (History with all_solution_iteration_expiry == 0 keeps every visited
+ * solution, local-search/src/local_search.rs:155-199): `tabu` holds n_tabu boards of n entries each; a candidate is
+ * dropped iff it equals one of them (is_solution_tabu, :197-199: a HashSet lookup of the whole vector).  The current
+ * board is NOT added implicitly: the caller passes the History's set, which always contains it after seen_solution.
+ */
+int orc_nq_neighbourhood_literal_tabu(const int64_t *rows, int64_t n,
+                                      const int64_t *cols, int64_t n_cols, int64_t window,
+                                      const int64_t *tabu, int64_t n_tabu,
+                                      int64_t *scores_out,
+                                      int64_t *n_scored, int64_t *best_index, int64_t *best_score)
+{
+    int64_t *cand = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    int64_t *best = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    if (!cand || !best) { free(cand); free(best); return -1; }
+    int64_t scored = 0, bi = -1, bs = 0;
+    const int64_t total = n_cols * n;
+    if (scores_out)
+        for (int64_t k = 0; k < total; k++) scores_out[k] = ORC_SKIPPED;
+    for (int64_t k = 0; k < total && scored < window; k++) {
+        memcpy(cand, rows, sizeof(int64_t) * (size_t)n);
+        cand[cols[k / n]] = k % n;
+        int is_tabu = 0;
+        for (int64_t t = 0; t < n_tabu && !is_tabu; t++)
+            is_tabu = lexcmp(cand, tabu + t * n, n) == 0;
+        if (is_tabu) continue;
+        const int64_t s = orc_nq_score(cand, n);
+        if (scores_out) scores_out[k] = s;
+        scored++;
+        if (bi < 0 || s < bs || (s == bs && lexcmp(cand, best, n) < 0)) {
+            bi = k; bs = s;
+            memcpy(best, cand, sizeof(int64_t) * (size_t)n);
+        }
+    }
+    *n_scored = scored; *best_index = bi; *best_score = bs;
+    free(cand); free(best);
+    return 0;
+}
+
 /* conf(c, r) = number of other columns j attacking square (c, r):
  * rows[j]==r or |rows[j]-r| == |j-c|   (the pair test of lib.rs:78-80). */
 static int64_t conf_scan(const int64_t *rows, int64_t n, int64_t c, int64_t r)

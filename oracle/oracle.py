@@ -64,6 +64,12 @@ def _declare(l):
         f = getattr(l, name)
         f.argtypes = [_p64, _i64, _p64, _i64, _i64, _p64, _p64, _p64, _p64]
         f.restype = C.c_int
+    l.orc_nq_neighbourhood_literal_tabu.argtypes = [_p64, _i64, _p64, _i64, _i64, _p64, _i64, _p64, _p64, _p64, _p64]
+    l.orc_nq_neighbourhood_literal_tabu.restype = C.c_int
+    l.orc_sched_neighbourhood_tabu.argtypes = [
+        C.POINTER(SchedInstance), _p64, _i64, C.POINTER(SchedMove), _i64, _i64, _p64, _i64,
+        _p64, _p64, _p64, _p64, _p64, _p64]
+    l.orc_sched_neighbourhood_tabu.restype = C.c_int
     l.orc_nq_baseline_run.argtypes = [_p64, _i64, _p64, _i64, _i64, _p64]
     l.orc_nq_baseline_run.restype = _i64
     l.orc_weekday_from_monday.argtypes = [_i64, _i64, _i64]
@@ -124,6 +130,21 @@ def nq_neighbourhood(rows, cols, window, formulation="literal", want_scores=True
     return dict(n_scored=ns.value, best_index=bi.value, best_score=bs.value, scores=scores)
 
 
+def nq_neighbourhood_tabu(rows, cols, window, tabu_boards, want_scores=True):
+    """lines :315-325 with a GENERAL tabu set (an iterable of boards; the current board is not added implicitly)."""
+    r = _a64(rows)
+    c = _a64(cols)
+    n = len(r)
+    t = _a64([list(b) for b in tabu_boards]).reshape(-1, n) if len(tabu_boards) else np.zeros((0, n), dtype=np.int64)
+    scores = np.empty(len(c) * n, dtype=np.int64) if want_scores else None
+    ns, bi, bs = _i64(0), _i64(0), _i64(0)
+    rc = lib().orc_nq_neighbourhood_literal_tabu(_ptr(r), n, _ptr(c), len(c), int(window), _ptr(t) if len(t) else None, len(t),
+                                                 _ptr(scores) if want_scores else None, C.byref(ns), C.byref(bi), C.byref(bs))
+    if rc != 0:
+        raise RuntimeError(f"oracle nq neighbourhood (tabu) rc={rc}")
+    return dict(n_scored=ns.value, best_index=bi.value, best_score=bs.value, scores=scores)
+
+
 def nq_baseline_run(rows, cols, max_candidates) -> tuple[int, int]:
     r = _a64(rows)
     c = _a64(cols)
@@ -175,6 +196,24 @@ class Sched:
             raise RuntimeError(f"oracle sched neighbourhood rc={rc}")
         return dict(n_scored=ns.value, best_index=bi.value, best_hard=bh.value,
                     best_soft=bs.value, hard=hard, soft=soft)
+
+    def neighbourhood_tabu(self, e, moves, window, tabu_states):
+        """Like neighbourhood() with a GENERAL tabu set (iterable of stored vectors; `e` itself is not added implicitly)."""
+        a = _a64(e)
+        m = _a64(moves).reshape(-1, 3)
+        mv = (SchedMove * len(m))()
+        for i, (t, x, y) in enumerate(m):
+            mv[i].type, mv[i].a, mv[i].b = int(t), int(x), int(y)
+        tb = _a64([list(s) for s in tabu_states]).reshape(-1, len(a)) if len(tabu_states) else np.zeros((0, len(a)), dtype=np.int64)
+        hard = np.empty(len(m), dtype=np.int64)
+        soft = np.empty(len(m), dtype=np.int64)
+        ns, bi, bh, bs = _i64(0), _i64(0), _i64(0), _i64(0)
+        rc = lib().orc_sched_neighbourhood_tabu(
+            C.byref(self.inst), _ptr(a), len(a), mv, len(m), int(window), _ptr(tb) if len(tb) else None, len(tb),
+            _ptr(hard), _ptr(soft), C.byref(ns), C.byref(bi), C.byref(bh), C.byref(bs))
+        if rc != 0:
+            raise RuntimeError(f"oracle sched neighbourhood (tabu) rc={rc}")
+        return dict(n_scored=ns.value, best_index=bi.value, best_hard=bh.value, best_soft=bs.value, hard=hard, soft=soft)
 
     @staticmethod
     def exhaustive_moves(e, employees) -> np.ndarray:

@@ -224,6 +224,57 @@ int orc_sched_neighbourhood(const orc_sched_instance *in, const int64_t *e, int6
     return 0;
 }
 
+/* The same pipeline for a GENERAL tabu set (see orc_nq_neighbourhood_literal_tabu): `tabu` holds n_tabu stored
+ * vectors; a candidate is dropped iff it equals one of them.  The base vector is not added implicitly. */
+int orc_sched_neighbourhood_tabu(const orc_sched_instance *in, const int64_t *e, int64_t n_stored,
+                                 const orc_sched_move *moves, int64_t n_moves, int64_t window,
+                                 const int64_t *tabu, int64_t n_tabu,
+                                 int64_t *hard_out, int64_t *soft_out,
+                                 int64_t *n_scored, int64_t *best_index,
+                                 int64_t *best_hard, int64_t *best_soft)
+{
+    int64_t *cand = (int64_t *)malloc(sizeof(int64_t) * (size_t)n_stored);
+    int64_t *best = (int64_t *)malloc(sizeof(int64_t) * (size_t)n_stored);
+    if (!cand || !best) { free(cand); free(best); return -1; }
+    int64_t scored = 0, bi = -1, bh = 0, bs = 0;
+    for (int64_t k = 0; k < n_moves; k++) {
+        if (hard_out) hard_out[k] = ORC_SKIPPED;
+        if (soft_out) soft_out[k] = ORC_SKIPPED;
+    }
+    for (int64_t k = 0; k < n_moves && scored < window; k++) {
+        memcpy(cand, e, sizeof(int64_t) * (size_t)n_stored);
+        if (moves[k].type == 0) {
+            cand[moves[k].a] = moves[k].b;
+        } else {
+            cand[moves[k].a] = e[moves[k].b];
+            cand[moves[k].b] = e[moves[k].a];
+        }
+        int is_tabu = 0;
+        for (int64_t t = 0; t < n_tabu && !is_tabu; t++)
+            is_tabu = memcmp(cand, tabu + t * n_stored, sizeof(int64_t) * (size_t)n_stored) == 0;
+        if (is_tabu) continue;
+        int64_t h, sft;
+        int rc = orc_sched_score(in, cand, &h, &sft, NULL);
+        if (rc) { free(cand); free(best); return rc; }
+        if (hard_out) hard_out[k] = h;
+        if (soft_out) soft_out[k] = sft;
+        scored++;
+        int better = 0;
+        if (bi < 0) better = 1;
+        else if (h != bh) better = h < bh;
+        else if (sft != bs) better = sft < bs;
+        else {
+            for (int64_t i = 0; i < n_stored; i++) {
+                if (cand[i] != best[i]) { better = cand[i] < best[i]; break; }
+            }
+        }
+        if (better) { bi = k; bh = h; bs = sft; memcpy(best, cand, sizeof(int64_t) * (size_t)n_stored); }
+    }
+    *n_scored = scored; *best_index = bi; *best_hard = bh; *best_soft = bs;
+    free(cand); free(best);
+    return 0;
+}
+
 /*
  * Exhaustive proposer order, lib.rs:526-550: for each STORED day index, walk
  * the ring next_employees (ids ascending, wrapping) starting after the day's

@@ -77,6 +77,14 @@ int ls_nqueens_eval_batch_next(ls_ctx *ctx, int32_t R, int32_t n, const int32_t 
     }
     return LS_OK;
 }
+// general-History entries (plugins.hpp references them; this test never builds a tabu set beyond {current})
+int ls_nqueens_eval_tabu(ls_ctx *ctx, int32_t, const int32_t *, int64_t, const int32_t *, int32_t, int64_t, const int64_t *, int32_t,
+                         ls_nq_result *, int64_t *) { ctx->err = "not in this fake"; return LS_ERR_UNSUPPORTED; }
+int ls_sched_eval(ls_ctx *ctx, const int32_t *, const ls_sched_move *, int64_t, int64_t, ls_sched_result *, int64_t *, int64_t *)
+{ ctx->err = "not in this fake"; return LS_ERR_UNSUPPORTED; }
+int ls_sched_score(ls_ctx *ctx, int32_t, const int32_t *, int64_t *, int64_t *, int64_t *) { ctx->err = "not in this fake"; return LS_ERR_UNSUPPORTED; }
+int ls_sched_moves_upload(ls_ctx *ctx, const ls_sched_move *, int64_t) { ctx->err = "not in this fake"; return LS_ERR_UNSUPPORTED; }
+int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *, int64_t, int64_t, ls_sched_result *) { ctx->err = "not in this fake"; return LS_ERR_UNSUPPORTED; }
 } // extern "C"
 
 using namespace lshost;

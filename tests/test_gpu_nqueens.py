@@ -546,3 +546,44 @@ def test_scan_production_path_own_square_at_share_boundaries(ctx, algo):
     for n_cols, window in ((len(cols), 10 ** 12), (len(cols), 20480), (5, 4 * 4095 + 63), (5, 4 * 4095 + 64),
                            (5, 4 * 4095 + 65), (17, 16 * 4095 + 1), (2, 4095 + 4094), (1, 1), (1, 4095)):
         _check_batch_noscores(ctx, algo, rows[None], cols[None, :n_cols], np.array([n_cols]), window)
+
+
+@pytest.mark.parametrize("n,n_cols", [(8, 2), (33, 4), (200, 6), (1000, 9)])
+def test_general_tabu_set_exclusion_list(ctx, n, n_cols):
+    # History configurations whose tabu set holds more than the current board (all_solution_iteration_expiry == 0,
+    # local_search.rs:155-199): ls_nqueens_eval_tabu takes the candidates that equal another tabu board as positions;
+    # they are neither scored nor counted (later candidates move up in the window).  Oracle: the literal pipeline with a
+    # whole-board HashSet filter.
+    rng = np.random.default_rng(n + n_cols)
+    for trial in range(6):
+        rows = _board(rng, n, "uniform" if trial % 2 else "perm")
+        cols = rng.permutation(n)[:n_cols]
+        if trial >= 3 and n_cols >= 3:
+            cols[2] = cols[0]                                       # duplicated column: both of its slots are affected
+        tabu = [tuple(int(x) for x in rows)]
+        for _ in range(int(rng.integers(1, 12))):                   # visited boards: most at distance 1 in a proposed column
+            b = list(tabu[0])
+            kind = rng.integers(0, 4)
+            c = int(cols[rng.integers(0, n_cols)]) if kind < 3 else int(rng.integers(0, n))
+            b[c] = int(rng.integers(0, n))
+            if kind == 2:
+                b[int(rng.integers(0, n))] = int(rng.integers(0, n))   # distance 2: can never equal a candidate
+            tabu.append(tuple(b))
+        base = tabu[0]
+        positions = sorted({s * n + t[c] for t in tabu[1:] for s, c in enumerate(cols)
+                            if sum(1 for j in range(n) if t[j] != base[j]) == 1 and t[c] != base[c]
+                            and all(t[j] == base[j] for j in range(n) if j != c)})
+        cur = orc.nq_score(rows)
+        for window in (10 ** 9, n_cols * (n - 1) - 3, 2 * (n - 1) + 1, 5):
+            exp = orc.nq_neighbourhood_tabu(rows, cols, window, tabu)
+            got, scores = ctx.nqueens_eval_tabu(rows, cur, cols, window, positions, want_scores=True)
+            assert got["n_scored"] == exp["n_scored"], (trial, window)
+            assert got["best_index"] == exp["best_index"], (trial, window)
+            if exp["best_index"] >= 0:
+                assert got["best_score"] == exp["best_score"]
+            assert np.array_equal(scores, exp["scores"]), (trial, window)
+    import ls_amd
+    with pytest.raises(ls_amd.LsError):
+        ctx.nqueens_eval_tabu([1, 3, 0, 2], 0, [0], 10, [1])            # (col 0, value 1) is the no-op
+    with pytest.raises(ls_amd.LsError):
+        ctx.nqueens_eval_tabu([1, 3, 0, 2], 0, [0], 10, [2, 0])         # not ascending

@@ -164,7 +164,7 @@ def test_errors(ctx):
     with pytest.raises(ls_amd.LsError):
         c2.sched_score(np.full(32, 3, dtype=np.int32))       # employee index out of range
     with pytest.raises(ls_amd.LsError):
-        c2.sched_eval(np.zeros(32, dtype=np.int32), [(2, 0, 0)], 10)   # unknown move type
+        c2.sched_eval(np.zeros(32, dtype=np.int32), [(3, 0, 0)], 10)   # unknown move type (2 = LS_SCHED_MOVE_SKIP is valid)
     with pytest.raises(ls_amd.LsError):
         c2.sched_instance_upload(31, 32, 0, 1, np.array([1 << 40], dtype=np.uint64))  # holiday outside range
     c2.close()
@@ -301,3 +301,34 @@ def test_config5_random_stream_at_launch_size(ctx, window):
         res = ctx.sched_eval_resident(state, len(moves), window)
         assert (res["n_scored"], res["best_index"], res["best_hard"], res["best_soft"]) == \
                (exp["n_scored"], exp["best_index"], exp["best_hard"], exp["best_soft"])
+
+
+def test_skip_moves_for_a_general_tabu_set(ctx):
+    # LS_SCHED_MOVE_SKIP: how a caller whose History keeps more than the current solution tabu
+    # (all_solution_iteration_expiry == 0, local_search.rs:155-199) tells the GPU that a move leads to a tabu solution:
+    # neither scored nor counted.  Oracle: the literal pipeline with a whole-vector tabu set.
+    start, end, n_emp = (2022, 5, 9), (2022, 6, 8), 7
+    rng = np.random.default_rng(8)
+    inst, D, S = _upload(ctx, start, end, n_emp, {2: [5, 6]})
+    for trial in range(5):
+        state = rng.integers(0, n_emp, size=S)
+        moves = _random_moves(rng, 400, D, n_emp, state)
+        cands = []
+        for t, a, b in moves:
+            c = list(state)
+            if t == 0:
+                c[a] = b
+            else:
+                c[a], c[b] = state[b], state[a]
+            cands.append(tuple(int(x) for x in c))
+        tabu = [tuple(int(x) for x in state)] + [cands[i] for i in rng.choice(len(cands), size=25, replace=False)]
+        marked = moves.copy()
+        for i, c in enumerate(cands):
+            if c != tabu[0] and c in set(tabu[1:]):
+                marked[i] = (2, 0, 0)
+        for window in (100, 10 ** 9, 7):
+            exp = inst.neighbourhood_tabu(state, moves, window, tabu)
+            got, hard, soft = ctx.sched_eval(state, marked, window, want_scores=True)
+            assert (got["n_scored"], got["best_index"]) == (exp["n_scored"], exp["best_index"]), (trial, window)
+            assert (got["best_hard"], got["best_soft"]) == (exp["best_hard"], exp["best_soft"])
+            assert np.array_equal(hard, exp["hard"]) and np.array_equal(soft, exp["soft"])

@@ -122,10 +122,17 @@ def test_solver_api_edges(ctx):
     s.execute_round()
     assert s.iteration_info()["current"] == 1
     s.close()
-    bad = dict(p, all_solution_iteration_expiry=0)
+    bad = dict(p, best_solutions_capacity=0)                         # the reference would panic (best set of capacity 0)
     with pytest.raises(ls_amd.LsError) as ei:
         ls_amd.Solver.nqueens(ctx, 8, "42", bad)
-    assert ei.value.code == ls_amd._lib.LS_ERR_UNSUPPORTED
+    assert ei.value.code == ls_amd._lib.LS_ERR_INVALID
+    m = ls_amd.MultiSolver(ctx, 8, ["42", "43"], dict(p, all_solution_iteration_expiry=0), n_slots=2, mode="lockstep")
+    with pytest.raises(ls_amd.LsError):                              # a growing tabu set needs one-restart launches
+        m.run(max_rounds_per_restart=2)
+    m.close()
+    m = ls_amd.MultiSolver(ctx, 8, ["42", "43"], dict(p, all_solution_iteration_expiry=0), n_slots=2, mode="free")
+    m.run(max_rounds_per_restart=3)
+    m.close()
     short = dict(p, iterated_local_search_max_iterations=2)
     s = ls_amd.Solver.nqueens(ctx, 30, "1", short)
     for _ in range(2):
@@ -197,6 +204,39 @@ def test_seeds_stream_through_slots(ctx, mode, n_slots, algo):
     st = m.stats()
     assert st["ls_iterations"] == iters
     m.close()
+
+
+@pytest.mark.parametrize("n,rounds,seed", [(8, 25, "42"), (12, 12, "7"), (30, 5, "abc")])
+def test_general_history_expiry_zero_nqueens(ctx, n, rounds, seed):
+    # all_solution_iteration_expiry == 0: the reference's tabu set keeps every solution LocalSearch visits
+    # (local_search.rs:155-199); no shipped configuration does this, but it is reference behaviour.  The product driver
+    # hands the GPU the tabu boards at Hamming distance 1 as an exclusion list; trajectory = the oracle's literal driver.
+    import ls_amd
+    ctx.set_algo("auto")
+    p = _nq_params(n, expiry=0)
+    p["all_solutions_capacity"] = 50                      # small enough for the size eviction (:173-180) to kick in
+    s = ls_amd.Solver.nqueens(ctx, n, seed, p)
+    o = lo.IteratedLocalSearch(lo.NQueens(n, "literal"), p, seed)
+    assert s.current() == o.current
+    t1, t2 = _trace_product(s, rounds), _trace_oracle(o, rounds)
+    assert t1 == t2
+    assert s.best() == o.get_best_solution()
+    s.close()
+
+
+def test_general_history_expiry_zero_scheduling(ctx):
+    import ls_amd
+    p = dict(lo.SCHED_MAIN_PARAMS)
+    p["all_solution_iteration_expiry"] = 0
+    p["all_solutions_capacity"] = 40
+    p["iterated_local_search_max_iterations"] = 12
+    s = ls_amd.Solver.scheduling(ctx, 31, 0, 7, "42", p)
+    o = lo.IteratedLocalSearch(lo.Scheduling((2022, 5, 9), (2022, 6, 8), 7), p, "42")
+    assert s.current() == o.current
+    t1, t2 = _trace_product(s, 12), _trace_oracle(o, 12)
+    assert t1 == t2
+    assert s.best() == o.get_best_solution()
+    s.close()
 
 
 def test_c_example_program_matches_python_solver(ctx, tmp_path):

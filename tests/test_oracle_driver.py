@@ -125,3 +125,17 @@ def test_winner_only_proposer_is_equivalent_under_the_unchanged_pipeline(n):
         w = list(rows); w[cols[res["best_index"] // n]] = res["best_index"] % n
         got = _literal_pipeline(iter([tuple(w)]), tabu, lambda b: lo.orc.nq_score(b), window)
         assert got == expect == (res["best_score"], tuple(w))
+
+
+def test_general_history_expiry_zero_runs_on_the_oracle_driver():
+    # all_solution_iteration_expiry == 0: nothing is evicted by age, the tabu set grows up to all_solutions_capacity + 1
+    # (local_search.rs:155-199) and the literal HashSet filter is in force; the driver must still solve n = 8
+    p = dict(lo.NQUEENS_MAIN_PARAMS)
+    p.update(window_size=40, all_solution_iteration_expiry=0, all_solutions_capacity=50)
+    o = lo.IteratedLocalSearch(lo.NQueens(8, "literal"), p, "42")
+    biggest = 0
+    for _ in range(25):
+        o.execute_round()
+        biggest = max(biggest, len(o.local_search.history.lookup))
+    assert biggest == 51
+    assert o.get_best_solution()[0] == 0
