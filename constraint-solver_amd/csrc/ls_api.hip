@@ -2,6 +2,8 @@
 // life-cycle, argument validation, host<->device staging.  Kernels live in
 // nq_kernels.hip / sched_kernels.hip.  No CPU fallback exists anywhere in this
 // library: without a HIP device ls_ctx_create fails.
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdarg>
@@ -135,6 +137,7 @@ int ls_ctx_create(int device_id, ls_ctx **out)
     if (const char *v = getenv("LS_NQ_SCAN_VARIANT")) ctx->nq_scan_variant = atoi(v);
     if (const char *v = getenv("LS_NQ_STEP")) ctx->nq_step_mode = atoi(v);
     if (const char *v = getenv("LS_NQ_TABLE_VARIANT")) ctx->nq_table_variant = atoi(v);
+    if (const char *v = getenv("LS_YIELD")) ctx->yield_while_waiting = atoi(v) != 0;
     if (const char *v = getenv("LS_SCHED_ZEROCOPY")) ctx->sched_zero_copy = atoi(v) != 0;
     if (const char *v = getenv("LS_SCHED_FUSED")) ctx->sched_fused = atoi(v) != 0;
     ctx->sched_force_64 = getenv("LS_SCHED_FORCE_64") != nullptr;
@@ -275,6 +278,9 @@ static int wait_done_word(ls_ctx *ctx, const unsigned long long *flag, unsigned 
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
+        // A launch takes >= 10 us: after a short spin give the core to another runnable thread (ls_multi_solver runs
+        // more slots than cores: one slot's host proposer then runs while the other slot's launch is in flight)
+        if (ctx->yield_while_waiting && spins >= 64) sched_yield();
         if ((spins & 0xfff) == 0xfff) {
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (dt > 0.002) { // far beyond any LS step: let the runtime tell whether the launch failed

@@ -129,6 +129,7 @@ struct ls_ctx {
     // nq_keys_dirty is raised while a call is being queued and stays up if it failed half-way: the next call then
     // clears the keys in stream order first.
     bool nq_keys_dirty = false;
+    bool yield_while_waiting = false; // completion-word poll: sched_yield() after a short spin (set by ls_multi_solver when slots > cores; LS_YIELD)
     bool sched_zero_copy = true; // ls_sched_eval_resident: kernels work on the pinned staging blocks directly (LS_SCHED_ZEROCOPY)
     bool sched_fused = true;     // small scheduling launches: locate + eval + reduce in one kernel (LS_SCHED_FUSED)
     bool sched_force_64 = false; // LS_SCHED_FORCE_64: use the full-wavefront scheduling kernel even for <= 32 days

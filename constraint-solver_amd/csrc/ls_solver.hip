@@ -1,8 +1,12 @@
 // ls_solver.hip — C entry points for the whole-solver view (include/ls_amd.h, "whole solver"):
 // the host driver of csrc/host/ wired to the GPU path of this library.  Plain host C++; it is a
 // .hip file only so that the one hipcc invocation style builds everything.
+#include <sched.h>
+
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstring>
 #include <memory>
 #include <new>
 #include <thread>
@@ -41,6 +45,28 @@ int check_params(ls_ctx *ctx, const ls_solver_params *p)
     if (p->best_solutions_capacity == 0)
         return lsamd::set_err(ctx, LS_ERR_INVALID, "best_solutions_capacity must be >= 1 (the reference would panic)");
     return LS_OK;
+}
+
+// Cores this process may really use: the affinity mask, further limited by the cgroup CPU quota when there is one
+// (hardware_concurrency() reports the whole machine inside a container).
+unsigned usable_cores()
+{
+    unsigned cores = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        const int c = CPU_COUNT(&set);
+        if (c > 0) cores = (unsigned)c;
+    }
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long long period = 0;
+        if (fscanf(f, "%31s %lld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const long long q = atoll(quota) / period;
+            if (q >= 1 && (unsigned)q < cores) cores = (unsigned)q;
+        }
+        fclose(f);
+    }
+    return cores < 1 ? 1 : cores;
 }
 
 template <class F> int guarded(ls_ctx *ctx, F &&f)
@@ -232,8 +258,8 @@ int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_r
         }
         m->best.resize((size_t)n_restarts);
         m->have.assign((size_t)n_restarts, 0);
-        const unsigned hw = std::thread::hardware_concurrency(); // a slot is a host thread that spins while its launch runs
-        if (hw >= 2 && (unsigned)m->n_slots > hw) m->n_slots = (int)hw;
+        const unsigned hw = usable_cores(); // a slot is a host thread that polls while its launch runs: one per core by default
+        if ((unsigned)m->n_slots > hw) m->n_slots = (int)hw;
         *out = m.release();
         return LS_OK;
     });
@@ -275,6 +301,11 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
                     own->nq_step_mode = m->ctx->nq_step_mode;
                     ctx = own;
                 }
+                // more slots than cores: a waiting slot yields its core to a slot that has host work to do
+                const unsigned hwc = usable_cores();
+                const bool was_yielding = ctx->yield_while_waiting;
+                if (!lockstep && hwc >= 1 && (unsigned)T > hwc) ctx->yield_while_waiting = true;
+                struct Restore { ls_ctx *c; bool v; ~Restore() { c->yield_while_waiting = v; } } restore{ctx, was_yielding};
                 const ls_solver_params &p = m->params;
                 for (;;) {
                     const int r = next_restart.fetch_add(1);

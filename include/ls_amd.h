@@ -338,7 +338,9 @@ int ls_solver_free(ls_solver *s);
 typedef struct ls_multi_solver ls_multi_solver;
 int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_restarts, const char *const *seeds,
                                    const ls_solver_params *params, ls_multi_solver **out);
-/* n_slots in [1, 256] (default: 16, at most the host's hardware threads), mode as above; call before ls_multi_solver_run. */
+/* n_slots in [1, 256] (default: 16, at most the cores the process may use; ls_multi_solver_configure may ask for more:
+ * a slot whose launch is in flight then lends its core to a slot with host work to do), mode as above; call before
+ * ls_multi_solver_run. */
 int ls_multi_solver_configure(ls_multi_solver *m, int32_t n_slots, int32_t mode);
 int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, double max_seconds);
 int ls_multi_solver_get_best(const ls_multi_solver *m, int32_t restart, int64_t score[2], int64_t *solution,
