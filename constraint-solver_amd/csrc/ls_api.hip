@@ -42,7 +42,7 @@ int nq_eval_excl_dev(ls_ctx *ctx, int n, const int *rows_d, const long long *cur
 bool nq_step_eligible(const ls_ctx *ctx, int n, int max_cols, long long window);
 int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long long *cur, const int *cols,
                 const int *n_cols, int max_cols, long long window, ls_nq_result *results, int *next_rows,
-                long long *next_col_scores, long long *next_totals, const NqStepExtra *extra);
+                long long *next_col_scores, long long *next_totals, const NqStepExtra *extra, const NqStepInline *inl = nullptr);
 // sched_kernels.hip
 int sched_score_dev(ls_ctx *ctx, int n_states, const int *states_d, long long *hard_d, long long *soft_d,
                     long long *terms_d);
@@ -344,8 +344,16 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
     x.done_flag = rs.flag;
     x.done_seq = ++rs.seq;
     x.block_counter = rs.counter.as<unsigned>();
+    NqStepInline inl;
+    inl.valid = 0;
+    if (R == 1 && max_cols <= NQ_STEP_INLINE_COLS) { // the small inputs ride in the kernel arguments: no PCIe read in the kernel
+        inl.valid = 1;
+        inl.cur = cur_scores[0];
+        inl.n_cols = n_cols[0];
+        for (int s = 0; s < max_cols; s++) inl.cols[s] = cols[s];
+    }
     int rc = nq_step_dev(ctx, R, n, si.h<int>(o_rows), si.h<long long>(o_cur), si.h<int>(o_cols), si.h<int>(o_nc), max_cols, win,
-                         so.h<ls_nq_result>(o_res), nullptr, nullptr, nullptr, &x);
+                         so.h<ls_nq_result>(o_res), nullptr, nullptr, nullptr, &x, &inl);
     if (rc != LS_OK) { std::fill(rs.valid.begin(), rs.valid.end(), 0); return rc; }
     rc = wait_done_word(ctx, rs.flag, rs.seq);
     if (rc != LS_OK) { std::fill(rs.valid.begin(), rs.valid.end(), 0); return rc; }

@@ -93,6 +93,18 @@ struct NqStepExtra {
     unsigned *block_counter;      // device word, zero between launches
 };
 
+// One-restart LS step: the per-call inputs that are not the board travel INSIDE the dispatch packet's kernel arguments
+// (which the runtime places in device memory) instead of being read from pinned host memory by the kernel: with the
+// board resident on the device the kernel then starts without a single PCIe read (3.3 us of its 11 us, measured with
+// in-kernel stamps).
+constexpr int NQ_STEP_INLINE_COLS = 224;
+struct NqStepInline {
+    long long cur;
+    int n_cols;
+    int valid; // 0: read cur / n_cols / cols through the NqArgs pointers as before
+    int cols[NQ_STEP_INLINE_COLS];
+};
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Boards the fused LS step keeps on the device between host-pointer calls (LS_NQ_STEP=3): `shadow` is the host's copy

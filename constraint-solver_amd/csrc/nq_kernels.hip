@@ -1374,7 +1374,7 @@ __device__ __forceinline__ void tab16_dec(unsigned *t, int idx) { atomicSub(&t[i
 // PAIRS (even n >= 128): the tables carry the shifted row copy of nq_table_pairs_kernel and the candidates are scored by
 // wavefront teams, two per lane and look-up (nq_pairs_unit); otherwise a flat one-candidate-per-lane walk.
 template <bool PAIRS>
-__global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *results, int *next_rows,
+__global__ __launch_bounds__(1024) void nq_step_kernel(NqStepInline in, NqArgs a, ls_nq_result *results, int *next_rows,
                                                        long long *next_col_scores, long long *next_totals, NqStepExtra x)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[]; // tables (packed u16: R[n] | A[2n] | B[2n], or R | R1 | A[2n+2] | B[2n+2]) | rows[n] | slot records[n_slots]
@@ -1396,15 +1396,18 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
         const int j = tid + 1024 * i;
         rv[i] = j < n ? rows[j] : -1;
     }
-    const int cv = tid < a.max_cols ? cols[tid] : -1; // the launcher guarantees n_slots <= 1024
-    int ncols = a.n_cols[r];
-    const long long cur = tid == 0 ? a.cur_scores[r] : 0;
+    LS_STAMP(0);
+    // the launcher guarantees n_slots <= 1024; `in.valid` (one restart, <= NQ_STEP_INLINE_COLS columns): from the kernel arguments
+    const int cv = tid < a.max_cols ? (in.valid ? in.cols[tid < NQ_STEP_INLINE_COLS ? tid : 0] : cols[tid]) : -1;
+    int ncols = in.valid ? in.n_cols : a.n_cols[r];
+    const long long cur = tid == 0 ? (in.valid ? in.cur : a.cur_scores[r]) : 0;
     for (int i = tid; i < words; i += 1024) s_t16[i] = 0;
 #pragma unroll
     for (int i = 0; i < NQ_STEP_MAX_N / 1024; i++) {
         const int j = tid + 1024 * i;
         if (j < n) s_rows[j] = rv[i];
     }
+    LS_STAMP(1);
     ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
     const long long K = nq_k_limit((long long)ncols * n, n, a.window);
     const int n_slots = (int)((K + n - 1) / n);
@@ -1422,6 +1425,7 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
     }
     if (PAIRS && tid == 0) atomicAdd(&s_t16[(oR1 + n - 1) >> 1], NQ_PAIR_SENTINEL << (16 * ((oR1 + n - 1) & 1)));
     __syncthreads();
+    LS_STAMP(2);
     int my_scored = 0; // this slot's share of n_scored (nq_slot_scored: skipped slots keep their window positions)
     if (tid < n_slots) {
         const int c = cv;
@@ -1435,6 +1439,7 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
     my_scored = wave_sum_i32(my_scored);
     if (lane == 0) s_cnt[wib] = my_scored;
     __syncthreads();
+    LS_STAMP(3);
     unsigned long long best = NQ_KEY_EMPTY;
     if constexpr (PAIRS) {
         // whole slots by wavefront teams (sixteen per block), the slot the window cuts by every lane with per-range loops
@@ -1442,10 +1447,12 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
         if (n_whole > ncols) n_whole = ncols;
         const long long rem = n_whole < ncols ? a.window - n_whole * (n - 1) : 0;
         const int steps = (n + 127) >> 7;
-        int parts = n_whole > 0 && n_whole < 16 ? (int)(16 / n_whole) : 1;
-        parts = parts > (steps >> 1) ? (steps >> 1) : parts;
-        parts = parts < 1 ? 1 : parts;
-        const int per_part = (steps + parts - 1) / parts;
+        // steps per unit: the sixteen wavefronts' fair share, rounded UP to the walk's unroll factor of four (a remainder
+        // step costs a full LDS round trip of its own)
+        int per_part = n_whole > 0 ? (int)((n_whole * steps + 15) / 16) : steps;
+        per_part = (per_part + 3) & ~3;
+        per_part = per_part > steps ? steps : (per_part < 4 ? 4 : per_part);
+        const int parts = (steps + per_part - 1) / per_part;
         const int team = __builtin_amdgcn_readfirstlane(wib);
         const int units = (int)n_whole * parts;
         for (int u = team; u < units; u += 16) {
@@ -1501,47 +1508,54 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
     best = wave_min_u64(best);
     if (lane == 0) s_best[wib] = best;
     __syncthreads();
+    LS_STAMP(4);
+    // Every lane decodes the winner itself (sixteen broadcast LDS reads) instead of waiting for lane 0 to do it and to
+    // patch the tables: the winner board's column scores follow from the OLD tables plus the move's own two squares --
+    // a column j != c loses the old queen's attack and gains the new queen's, column c gets conf(c, v) (its old queen
+    // never counts towards another square of its own column).
+    unsigned long long key = s_best[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) key = u64min(key, s_best[i]);
+    long long n_scored = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) n_scored += s_cnt[i];
+    const bool has_move = key != NQ_KEY_EMPTY && n_scored != 0;
+    int mc = -1, mv = -1, mq = -1; // the move: column, new row, old row (MoveIterator, lib.rs:226-228)
+    if (has_move) {
+        mv = (int)((key >> 15) & 0x7fffu);
+        const int colkey = (int)((key >> 30) & 0x7fffu);
+        mc = ((key >> 45) & 1u) ? n - 1 - colkey : colkey;
+        mq = s_rows[mc];
+    }
     if (tid == 0) {
-        unsigned long long key = s_best[0];
-        for (int i = 1; i < 16; i++) key = u64min(key, s_best[i]);
         ls_nq_result out;
-        out.n_scored = 0;
-        for (int i = 0; i < 16; i++) out.n_scored += s_cnt[i];
-        if (key == NQ_KEY_EMPTY || out.n_scored == 0) {
-            out.n_scored = 0;
-            out.best_index = -1;
-            out.best_score = 0;
-            out.best_col = -1;
-            out.best_value = -1;
+        if (!has_move) {
+            out.n_scored = 0; out.best_index = -1; out.best_score = 0; out.best_col = -1; out.best_value = -1;
         } else {
-            const int slot = (int)(key & 0x7fffu);
-            const int v = (int)((key >> 15) & 0x7fffu);
-            const int colkey = (int)((key >> 30) & 0x7fffu);
-            const int is_up = (int)((key >> 45) & 1u);
-            const int c = is_up ? n - 1 - colkey : colkey;
-            const int delta = (int)(key >> 46) - NQ_DELTA_BIAS;
-            out.best_index = (long long)slot * n + v;
-            out.best_score = cur + 2ll * delta;
-            out.best_col = c;
-            out.best_value = v;
-            // the move (MoveIterator, lib.rs:226-228) on the LDS board and its tables
-            const int q = s_rows[c];
-            tab16_dec(s_t16, q); tab16_dec(s_t16, oA + q - c + n); tab16_dec(s_t16, oB + q + c);
-            tab16_inc(s_t16, v); tab16_inc(s_t16, oA + v - c + n); tab16_inc(s_t16, oB + v + c);
-            if (PAIRS) {
-                if (q > 0) tab16_dec(s_t16, oR1 + q - 1);
-                if (v > 0) tab16_inc(s_t16, oR1 + v - 1);
-            }
-            s_rows[c] = v;
+            out.n_scored = n_scored;
+            out.best_index = (long long)(key & 0x7fffu) * n + mv;
+            out.best_score = cur + 2ll * ((int)(key >> 46) - NQ_DELTA_BIAS);
+            out.best_col = mc;
+            out.best_value = mv;
         }
         results[r] = out;
     }
-    __syncthreads();
+    LS_STAMP(5);
     int local = 0;
     for (int j = tid; j < n; j += 1024) {
-        const int q = s_rows[j];
+        int q = s_rows[j];
         int sc = 0;
-        if ((unsigned)q < (unsigned)n) sc = tab16_get(s_t16, q) + tab16_get(s_t16, oA + q - j + n) + tab16_get(s_t16, oB + q + j) - 3;
+        if (j == mc) {
+            q = mv;
+            sc = tab16_get(s_t16, mv) + tab16_get(s_t16, oA + mv - mc + n) + tab16_get(s_t16, oB + mv + mc); // conf(c, v)
+        } else if ((unsigned)q < (unsigned)n) {
+            sc = tab16_get(s_t16, q) + tab16_get(s_t16, oA + q - j + n) + tab16_get(s_t16, oB + q + j) - 3;
+            if (has_move) {
+                const int dc = j > mc ? j - mc : mc - j;
+                const int dn = q > mv ? q - mv : mv - q, dq = q > mq ? q - mq : mq - q;
+                sc += ((dn == 0) | (dn == dc)) - ((dq == 0) | (dq == dc));
+            }
+        }
         if (next_col_scores) next_col_scores[(long long)r * n + j] = sc;
         if (x.next_cs16) x.next_cs16[(long long)r * n + j] = (unsigned short)sc;
         if (next_rows) next_rows[(long long)r * n + j] = q;
@@ -1558,6 +1572,7 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
             next_totals[r] = t;
         }
     }
+    LS_STAMP(6);
     if (x.done_flag) { // block-uniform
         // Completion word: every block makes its outputs (host memory) visible at system scope, then counts itself;
         // the block that counts last publishes the sequence number.  __syncthreads orders the other wavefronts'
@@ -1565,11 +1580,13 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqArgs a, ls_nq_result *r
         __syncthreads();
         if (tid == 0) {
             __threadfence_system();
-            const unsigned done = __hip_atomic_fetch_add(x.block_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (done == gridDim.x - 1) {
+            if (gridDim.x == 1) { // one restart: nobody else to wait for
+                __hip_atomic_store(x.done_flag, x.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else if (__hip_atomic_fetch_add(x.block_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
                 __hip_atomic_store(x.block_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(x.done_flag, x.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            LS_STAMP(7);
         }
     }
 }
@@ -1969,7 +1986,7 @@ bool nq_step_eligible(const ls_ctx *ctx, int n, int max_cols, long long window)
 // Pointers may be device memory or pinned host memory (each input is read once, each output written once).
 int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long long *cur, const int *cols,
                 const int *n_cols, int max_cols, long long window, ls_nq_result *results, int *next_rows,
-                long long *next_col_scores, long long *next_totals, const NqStepExtra *extra)
+                long long *next_col_scores, long long *next_totals, const NqStepExtra *extra, const NqStepInline *inl)
 {
     NqArgs a;
     a.rows = rows; a.cur_scores = cur; a.cols = cols; a.n_cols = n_cols;
@@ -1990,8 +2007,10 @@ int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long 
     NqStepExtra x;
     if (extra) x = *extra;
     else { x.fresh_mask = ~0ull; x.resident_rows = nullptr; x.next_cs16 = nullptr; x.done_flag = nullptr; x.done_seq = 0; x.block_counter = nullptr; }
-    if (pairs) hipLaunchKernelGGL(nq_step_kernel<true>, dim3(n_restarts), dim3(1024), lds, ctx->stream, a, results, next_rows, next_col_scores, next_totals, x);
-    else hipLaunchKernelGGL(nq_step_kernel<false>, dim3(n_restarts), dim3(1024), lds, ctx->stream, a, results, next_rows, next_col_scores, next_totals, x);
+    static const NqStepInline no_inline = {};
+    const NqStepInline &in = inl && n_restarts == 1 && max_cols <= NQ_STEP_INLINE_COLS ? *inl : no_inline;
+    if (pairs) hipLaunchKernelGGL(nq_step_kernel<true>, dim3(n_restarts), dim3(1024), lds, ctx->stream, in, a, results, next_rows, next_col_scores, next_totals, x);
+    else hipLaunchKernelGGL(nq_step_kernel<false>, dim3(n_restarts), dim3(1024), lds, ctx->stream, in, a, results, next_rows, next_col_scores, next_totals, x);
     LS_HIP(ctx, hipGetLastError());
     return LS_OK;
 }
