@@ -167,8 +167,11 @@ class _ThreadSync:
 
 
 class _DistSync:
-    def __init__(self, dist, torch, red_dev, world):
-        self.dist, self.torch, self.red_dev, self.world = dist, torch, red_dev, world
+    """Ranks are processes (torch.distributed.run): the barrier runs on the job's backend (RCCL under `nccl`); the
+    host-side gather of the result records goes through a gloo group — it is CPU data and needs no GPU transport."""
+
+    def __init__(self, dist, world, object_group=None):
+        self.dist, self.world, self.object_group = dist, world, object_group
 
     def barrier(self):
         if self.world > 1:
@@ -178,7 +181,7 @@ class _DistSync:
         if self.world == 1:
             return [obj]
         out = [None] * self.world
-        self.dist.all_gather_object(out, obj)
+        self.dist.all_gather_object(out, obj, group=self.object_group)
         return out
 
 
@@ -494,8 +497,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")     # several ranks on one device: RCCL refuses duplicate GPUs
-    red_dev = dev if (args.backend == "nccl" and args.all_on_device is None) else torch.device("cpu")
-    sync = _DistSync(dist, torch, red_dev, world)
+    object_group = None
+    if world > 1 and dist.get_backend() != "gloo":
+        object_group = dist.new_group(backend="gloo")
+    sync = _DistSync(dist, world, object_group)
     run_rank(args, rank, world, device, sync,
              "torch.distributed.run, one process per GPU; RCCL for the barrier only, host-side gather" if world > 1 else "single process")
     if world > 1:
@@ -582,8 +587,13 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True):
         for _ in range(reps):
             ctx.nqueens_eval_batch_next(*args_h)
         s = (time.perf_counter() - t0) / reps
-        out[f"fused_ls_step_host_round_trip_{RR}_restarts"] = {"us_per_call": s * 1e6, "candidates_per_call": RR * min(5 * n, mc * (n - 1)),
-                                                               "note": "includes ctypes/numpy marshalling of the Python wrapper"}
+        c = kc.get(f"nq_step_kernel_r{RR}") or {}
+        out[f"fused_ls_step_host_round_trip_{RR}_restarts"] = {
+            "us_per_call": s * 1e6, "candidates_per_call": RR * min(5 * n, mc * (n - 1)),
+            "note": "includes ctypes/numpy marshalling of the Python wrapper",
+            # a latency-bound launch: one 1024-thread block per restart; its issue bounds on the CUs it can occupy are a small
+            # fraction of the kernel time, which is PCIe-free set-up, LDS round trips and the completion word
+            "kernel": {k: c.get(k) for k in ("duration_us", "valu_issue_bound_us", "lds_array_bound_us", "cus_usable", "roofline", "source")} if c else None}
     if e2e:
         out["config4_end_to_end_64_restarts_one_gpu"] = config4_end_to_end(ctx, n)
     ctx.set_algo("scan")

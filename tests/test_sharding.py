@@ -94,3 +94,32 @@ def test_two_rank_gloo_gather_matches_single_process(tmp_path):
         assert o["n_all"] == total
         assert o["best_score"] == exp[0][0] and o["best_restart"] == exp[2]
         assert tuple(o["best_board"]) == exp[1]
+
+
+def test_thread_ranks_barrier_and_gather():
+    # bench.py without a launcher: ranks are host threads of one process (one context + stream per GPU); they meet at
+    # a barrier and at the host-side gather only (no collective on the data path)
+    import importlib.util
+    import threading
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    world = 4
+    sync = bench._ThreadSync(world)
+    got = [None] * world
+
+    def rank(r):
+        recs = [sharding.record(rid, 10 * rid + 3, [rid, 0, 1]) for rid in sharding.shard_restarts(10, world, r)]
+        sync.barrier()
+        parts = sync.all_gather(r, recs)
+        sync.barrier()
+        got[r] = sharding.best_of([x for p in parts for x in p]), sorted(x[2] for p in parts for x in p)
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert all(g == got[0] for g in got)
+    assert got[0][1] == list(range(10)) and got[0][0][2] == 0
