@@ -18,6 +18,7 @@
 
 #include <cstdint>
 #include <deque>
+#include <memory>
 #include <set>
 #include <utility>
 #include <vector>
@@ -51,11 +52,11 @@ public:
     {
         iteration_count++;
         pop_solution_for_age();
-        if (lookup_.count(s.solution)) return;
+        if (lookup_.find(s.solution) != lookup_.end()) return;
         add_solution(s);
     }
     // :197-199
-    bool is_solution_tabu(const typename P::Solution &s) const { return lookup_.count(s) != 0; }
+    bool is_solution_tabu(const typename P::Solution &s) const { return lookup_.find(s) != lookup_.end(); }
     // :201-203
     bool is_best_solution(const SS &s) const { return best_.count(s) != 0; }
     // :205-218
@@ -86,19 +87,33 @@ public:
         return true;
     }
     size_t tabu_size() const { return lookup_.size(); }
-    const std::set<typename P::Solution> &tabu() const { return lookup_; }
+    // visit every tabu solution (general History configurations hand them to the GPU as exclusions)
+    template <class F> void for_each_tabu(F &&f) const
+    {
+        for (const auto &sp : lookup_) f(*sp);
+    }
     uint64_t iteration_count = 0;
 
 private:
-    struct Entry { typename P::Solution solution; uint64_t iteration; };
+    // One heap copy of a visited solution is shared by the deque and the lookup set (the reference clones it twice,
+    // local_search.rs:164-171; at n = 4096 a board is 32 KB and this runs once per LS iteration).
+    using SolPtr = std::shared_ptr<const typename P::Solution>;
+    struct PtrLess {
+        using is_transparent = void;
+        bool operator()(const SolPtr &a, const SolPtr &b) const { return *a < *b; }
+        bool operator()(const SolPtr &a, const typename P::Solution &b) const { return *a < b; }
+        bool operator()(const typename P::Solution &a, const SolPtr &b) const { return a < *b; }
+    };
+    struct Entry { SolPtr solution; uint64_t iteration; };
     void add_solution(const SS &s) // :164-171
     {
         while (all_.size() > all_cap_) { // _pop_solution_for_size :173-180
             lookup_.erase(all_.back().solution);
             all_.pop_back();
         }
-        all_.push_front(Entry{s.solution, iteration_count});
-        lookup_.insert(s.solution);
+        SolPtr sp = std::make_shared<const typename P::Solution>(s.solution);
+        all_.push_front(Entry{sp, iteration_count});
+        lookup_.insert(std::move(sp));
     }
     void pop_solution_for_age() // :182-195 — evicts entries YOUNGER than the expiry (sic)
     {
@@ -115,7 +130,7 @@ private:
     std::set<SS> best_;
     size_t best_cap_, all_cap_;
     std::deque<Entry> all_;
-    std::set<typename P::Solution> lookup_;
+    std::set<SolPtr, PtrLess> lookup_;
     uint64_t expiry_;
 };
 
@@ -151,7 +166,7 @@ public:
                     no_improvement_for++;
                     if (no_improvement_for >= allow_no_improvement_for) break;
                 }
-                current = nb;
+                current = std::move(nb);
             } else {
                 break;
             }

@@ -191,9 +191,15 @@ struct NQueensProblem {
     // column scores of the board the loop will expand next, delivered by the previous neighbourhood's
     // round trip (or by score()): saves one GPU round trip per LS iteration
     mutable Solution cached_board;
+    mutable std::vector<int32_t> cached_rows32;  // cached_board packed for the ABI, kept in step with it
     mutable std::vector<int64_t> cached_cs;
     mutable int64_t cached_total = 0;
     mutable bool cache_valid = false;
+    mutable bool last_lookup_hit = false;        // the board of the last col_scores() call IS cached_board
+    // per-iteration scratch, reused (at n = 4096 a fresh 32 KB vector per LS iteration costs microseconds)
+    std::vector<int64_t> spare_cs;
+    mutable std::vector<uint32_t> conflict_cols_buf;
+    mutable std::vector<double> weights_buf;
 
     NQueensProblem(ls_ctx *c, size_t n, NqBatcher *b = nullptr) : ctx(c), board_size(n), batcher(b) {}
 
@@ -219,9 +225,11 @@ struct NQueensProblem {
     const std::vector<int64_t> &col_scores(const Solution &s, int64_t *total) const
     {
         if (cache_valid && s == cached_board) {
+            last_lookup_hit = true;
             if (total) *total = cached_total;
             return cached_cs;
         }
+        last_lookup_hit = false;
         const_cast<NQueensProblem *>(this)->gpu_col_score_calls++;
         const std::vector<int32_t> rows = pack(s);
         std::vector<int64_t> cs(s.size());
@@ -242,7 +250,8 @@ struct NQueensProblem {
                                          ", total " + std::to_string(tot) + ")");
         }
         if (total) *total = tot;
-        cached_board = s; cached_cs.swap(cs); cached_total = tot; cache_valid = true;
+        cached_board = s; cached_rows32 = rows; cached_cs.swap(cs); cached_total = tot; cache_valid = true;
+        last_lookup_hit = true;
         return cached_cs;
     }
     Score score(const Solution &s) const
@@ -258,8 +267,10 @@ struct NQueensProblem {
     template <class R> std::vector<int32_t> propose_columns(const Solution &start, R &rng) const
     {
         const std::vector<int64_t> &cs = col_scores(start, nullptr);
-        std::vector<uint32_t> conflict_cols;
-        std::vector<double> weights;
+        std::vector<uint32_t> &conflict_cols = conflict_cols_buf;
+        std::vector<double> &weights = weights_buf;
+        conflict_cols.clear();
+        weights.clear();
         for (size_t c = 0; c < cs.size(); c++)
             if (cs[c] != 0) {
                 conflict_cols.push_back((uint32_t)c);
@@ -290,15 +301,15 @@ struct NQueensProblem {
     {
         std::vector<int64_t> out;
         const size_t n = cur.size();
-        for (const Solution &t : tabu.tabu()) {
-            if (t.size() != n) continue;
+        tabu.for_each_tabu([&](const Solution &t) {
+            if (t.size() != n) return;
             size_t diff_col = 0, diffs = 0;
             for (size_t j = 0; j < n && diffs < 2; j++)
                 if (t[j] != cur[j]) { diff_col = j; diffs++; }
-            if (diffs != 1) continue; // the current board itself (no-ops: always tabu on the device) or too far away
+            if (diffs != 1) return; // the current board itself (no-ops: always tabu on the device) or too far away
             for (size_t s = 0; s < cols.size(); s++)
                 if ((size_t)cols[s] == diff_col) out.push_back((int64_t)(s * n) + t[diff_col]);
-        }
+        });
         std::sort(out.begin(), out.end());
         out.erase(std::unique(out.begin(), out.end()), out.end());
         return out;
@@ -309,7 +320,11 @@ struct NQueensProblem {
         const auto T0 = std::chrono::steady_clock::now();
         const std::vector<int32_t> cols = propose_columns(current.solution, rng);
         if (cols.empty()) return false;
-        const std::vector<int32_t> rows = pack(current.solution);
+        // propose_columns has just looked the current board up: it is the cached one (already packed) in the steady state
+        const bool cur_is_cached = last_lookup_hit && cached_rows32.size() == current.solution.size();
+        std::vector<int32_t> packed_now;
+        if (!cur_is_cached) packed_now = pack(current.solution);
+        const std::vector<int32_t> &rows = cur_is_cached ? cached_rows32 : packed_now;
         if (tabu.tabu_size() != 1) { // more than {current} is tabu: exclusion list, one-restart launch (never batched)
             const std::vector<int64_t> excl = tabu_positions(current.solution, cols, tabu);
             ls_nq_result res;
@@ -327,7 +342,8 @@ struct NQueensProblem {
         const auto T1 = std::chrono::steady_clock::now();
         t_prop += std::chrono::duration<double>(T1 - T0).count();
         ls_nq_result res;
-        std::vector<int64_t> next_cs(rows.size());
+        std::vector<int64_t> &next_cs = spare_cs;
+        next_cs.resize(rows.size());
         if (batcher) {
             NqRequest rq;
             rq.kind = 1; rq.rows = rows.data(); rq.cur_score = current.score; rq.cols = cols.data();
@@ -362,7 +378,15 @@ struct NQueensProblem {
         out.solution[(size_t)res.best_col] = res.best_value; // MoveIterator, lib.rs:226-228
         out.score = res.best_score;
         // the loop continues from this board (local_search.rs:335): its column scores came back with the result
-        cached_board = out.solution; cached_cs.swap(next_cs); cached_total = res.best_score; cache_valid = true;
+        if (cur_is_cached) { // cached_board == current.solution: apply the move in place
+            cached_board[(size_t)res.best_col] = res.best_value;
+            cached_rows32[(size_t)res.best_col] = res.best_value;
+        } else {
+            cached_board = out.solution;
+            cached_rows32 = packed_now;
+            cached_rows32[(size_t)res.best_col] = res.best_value;
+        }
+        cached_cs.swap(next_cs); cached_total = res.best_score; cache_valid = true;
         return true;
     }
 

@@ -18,3 +18,13 @@ def test_batcher_failure_paths_under_sanitizers(tmp_path, sanitizer):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", TSAN_OPTIONS="halt_on_error=1")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_weighted_sampler_histogram_selection_equals_selection_sort(tmp_path):
+    # csrc/host/rng.hpp: index_sample_weighted (histogram top-k) vs index_sample_weighted_reference (selection + sort)
+    src = os.path.join(ROOT, "tests", "cpp", "sample_weighted_test.cpp")
+    exe = str(tmp_path / "sample_weighted_test")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-mavx2", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", src, "-o", exe],
+                   check=True, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-2000:], r.stderr[-4000:])
