@@ -35,6 +35,39 @@ int main()
             return 1;
         }
     }
+    // the pre-filter's domain (length >= 64, amount <= length / 2, every weight >= 1): brackets from the cheap log2, pow
+    // only for the keys that can still reach the top
+    for (int rep = 0; rep < 12000; rep++) {
+        const uint32_t L = 64 + (uint32_t)(g.next_u32() % 2400);
+        const uint32_t k = 1 + (uint32_t)(g.next_u32() % (L / 2));
+        std::vector<double> w(L);
+        const int mode = (int)(g.next_u32() % 6);
+        for (uint32_t i = 0; i < L; i++) {
+            switch (mode) {
+            case 0: w[i] = 1 + (g.next_u32() % 8) + 1e-4; break;          // the N-queens proposer's weights
+            case 1: w[i] = 1.0; break;                                    // key == u: ties only where draws tie
+            case 2: w[i] = 1e6 + g.next_u32() % 10; break;                // every key within 1e-5 of 1: the brackets overlap massively
+            case 3: w[i] = 1.0 + 1e-3 * (g.next_u32() % 3); break;        // nearly equal exponents
+            case 4: w[i] = (double)(1 + g.next_u32() % 1000); break;
+            default: w[i] = (i % 7 == 0) ? 1e9 : 2.0001; break;           // a few keys pinned to ~1
+            }
+        }
+        ChaCha20Rng r1 = ChaCha20Rng::from_seed_string(("p" + std::to_string(rep)).c_str());
+        ChaCha20Rng r2 = r1;
+        const auto a = index_sample_weighted_reference(r1, w, k);
+        const auto b = index_sample_weighted(r2, w, k);
+        if (a != b || r1.next_u64() != r2.next_u64()) {
+            printf("FAIL (pre-filter) rep %d (length %u amount %u mode %d)\n", rep, L, k, mode);
+            return 1;
+        }
+    }
+    // the approximation the brackets rest on, on a dense sweep of mantissas and a few exponents
+    for (int e = -53; e <= -1; e += 13)
+        for (int i = 0; i < 2000000; i++) {
+            const double u = std::ldexp(1.0 + (double)i / 2000000.0, e);
+            if (!(u < 1.0)) continue;
+            if (std::fabs(approx_log2_unit(u) - std::log2(u)) > LOG2_APPROX_ERR - 4e-4) { printf("FAIL log2 bound at %a\n", u); return 1; }
+        }
     printf("OK\n");
     return 0;
 }

@@ -113,6 +113,20 @@ def test_sampling_routines_match_oracle():
         assert got == _oracle_script(seed, ops, weights), (trial, ops)
 
 
+def test_weighted_sampler_prefilter_shape_matches_oracle():
+    # the N-queens proposer's shape at n = 4096 (about 1100 conflicting columns, 204 picks): the product's sampler brackets
+    # every key with a cheap log2, evaluates pow() only for the keys that can reach the top 204 and selects by histogram;
+    # the oracle's Python restatement computes every key and sorts.  Same picks, same order, same generator state after.
+    pyr = random.Random(99)
+    for trial in range(6):
+        L = pyr.choice([64, 400, 1100, 1137, 2000])
+        weights = [pyr.randint(1, 9) + 1e-4 for _ in range(L)]
+        seed = bytes(pyr.randrange(256) for _ in range(32))
+        ops = [(9, L, max(1, L // pyr.choice([2, 5, 20]))), (1, 0, 0), (9, L, 1), (0, 0, 0)]
+        got = ls_amd.host_rng_script(seed, ops, weights, cap=1 << 18)
+        assert got == _oracle_script(seed, ops, weights), (trial, L)
+
+
 def test_gen_range_is_in_range_and_covers():
     seed = bytes(range(32))
     vals = ls_amd.host_rng_script(seed, [(2, 3, 9)] * 2000)
