@@ -811,10 +811,11 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
     // (LS_SCHED_ZEROCOPY=0 restores the two staging copies), so the chain is kernels only.
     const bool zc = ctx->sched_zero_copy && n_moves <= 4096; // many blocks re-reading the state over PCIe cost more than the copies
     if (!zc) LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
-    // one-block fused launch on pinned memory: poll a completion word instead of synchronising the stream
-    const bool poll = zc && sched_is_fused_launch(ctx, n_moves);
+    // The result record always goes straight to pinned host memory and its writer publishes a completion word, which
+    // the caller polls instead of synchronising the stream; the state is read in place by the one-block fused launch and
+    // staged through one small copy when thousands of blocks would otherwise read it over PCIe.
     NqResident &rs = ctx->nq_res; // the context's completion word is shared with the N-queens LS step (one call at a time per context)
-    if (poll && !rs.flag) {
+    if (!rs.flag) {
         LS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&rs.flag), 64, hipHostMallocCoherent));
         *rs.flag = 0;
         LS_RESERVE(ctx, rs.counter, 256);
@@ -822,15 +823,10 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
     }
     rc = sched_eval_batch_dev(ctx, 1, zc ? si.h<int>(o_st) : si.d<int>(o_st), ctx->sc_resident_moves.as<ls_sched_move>(),
                               zc ? si.h<long long>(o_nm) : si.d<long long>(o_nm), n_moves, window,
-                              zc ? so.h<ls_sched_result>(0) : so.d<ls_sched_result>(0), nullptr, nullptr,
-                              poll ? rs.flag : nullptr, poll ? ++rs.seq : 0);
+                              so.h<ls_sched_result>(0), nullptr, nullptr, rs.flag, ++rs.seq);
     if (rc != LS_OK) return rc;
-    if (!zc) LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
-    if (poll) {
-        rc = wait_done_word(ctx, rs.flag, rs.seq);
-        if (rc != LS_OK) return rc;
-    } else
-        LS_SYNC(ctx);
+    rc = wait_done_word(ctx, rs.flag, rs.seq);
+    if (rc != LS_OK) return rc;
     *out = *so.h<ls_sched_result>(0);
     return LS_OK;
 }

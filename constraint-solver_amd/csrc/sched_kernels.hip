@@ -201,7 +201,7 @@ struct SchedEvalArgs {
     long long *part_idx; // [n_restarts][blocks_per_restart] and its move index
     long long *hard_out, *soft_out; // nullable [n_restarts][max_moves]
     ls_sched_result *results;       // written by pass 2 itself when blocks_per_restart == 1
-    unsigned long long *done_flag;  // nullable; fused one-restart launch only: host word <- done_seq after the result record
+    unsigned long long *done_flag;  // nullable; one-restart launches only: host word <- done_seq after the result record
     unsigned long long done_seq;
 };
 
@@ -348,6 +348,10 @@ __device__ __forceinline__ void sched_write_result_n(const SchedEvalArgs &a, int
         out.best_soft = (long long)((bk >> 46) & 0xffu);
     }
     a.results[r] = out;
+    if (a.done_flag) { // one-restart launch from the resident entry: the caller polls this word instead of synchronising the stream
+        __threadfence_system();
+        __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 __device__ __forceinline__ void sched_write_result(const SchedEvalArgs &a, int r, u64 bk, long long bi)
@@ -515,10 +519,6 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_kernel(SchedEvalArgs a)
             }
         if (FUSED) {
             sched_write_result_n(a, r, best_key, best_idx, n_scored_f);
-            if (a.done_flag) { // the caller polls this word instead of synchronising the stream (one restart, one block)
-                __threadfence_system();
-                __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
         } else if (a.blocks_per_restart == 1) {
             sched_write_result(a, r, best_key, best_idx);
         } else {
@@ -751,10 +751,6 @@ __global__ __launch_bounds__(64 * NW) void sched_eval32_kernel(SchedEvalArgs a)
             }
         if (FUSED) {
             sched_write_result_n(a, r, best_key, best_idx, n_scored_f);
-            if (a.done_flag) { // the caller polls this word instead of synchronising the stream (one restart, one block)
-                __threadfence_system();
-                __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
         } else if (a.blocks_per_restart == 1) {
             sched_write_result(a, r, best_key, best_idx);
         } else {
@@ -899,7 +895,7 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
     a.chunk_counts = reinterpret_cast<int *>(a.part_idx + parts);
     a.hard_out = hard_out_d; a.soft_out = soft_out_d;
     a.results = results_d;
-    a.done_flag = (n_restarts == 1 && sched_is_fused_launch(ctx, max_moves)) ? done_flag : nullptr;
+    a.done_flag = n_restarts == 1 ? done_flag : nullptr; // exactly one thread of one kernel writes the record of a one-restart launch
     a.done_seq = done_seq;
     const long long total = (long long)n_restarts * max_moves;
     const unsigned fill_grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
