@@ -153,9 +153,8 @@ public:
             history_.seen_solution(current);
             if (P::is_best(current.score)) return current;
             // :315-325 — the GPU seam.  The evaluator's built-in tabu rule is "candidate == current"; seen_solution has
-            // just made sure the current solution IS in the set, whatever else a general History keeps there.
-            if (!history_.is_solution_tabu(current.solution))
-                throw std::runtime_error("History invariant broken: the current solution is not tabu");
+            // just made sure the current solution IS in the set (it was there, or it has been added), whatever else a
+            // general History keeps.
             SS nb;
             ls_iterations++;
             if (p_->best_of_neighbourhood(current, rng_, window_size_, nb, history_)) {

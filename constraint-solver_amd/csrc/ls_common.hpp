@@ -223,16 +223,27 @@ __device__ __forceinline__ int wave_sum_i32(int x)
     return __builtin_amdgcn_readlane(x, 63);
 }
 
+// Minimum over the 64 lanes of a wavefront, returned wave-uniform: the same six DPP steps as wave_sum_i32 (no LDS
+// round trips: a __shfl_xor butterfly costs twelve dependent ds_bpermute operations).
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        unsigned lo = __shfl_xor((unsigned)x, m, 64);
-        unsigned hi = __shfl_xor((unsigned)(x >> 32), m, 64);
-        unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        x = o < x ? o : x;
+#define LS_MIN_STEP(CTRL, ROWMASK)                                                                                   \
+    {                                                                                                                \
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)x, (int)(unsigned)x, CTRL, ROWMASK, 0xf, false);          \
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(x >> 32), (int)(unsigned)(x >> 32), CTRL, ROWMASK, 0xf, false); \
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;                                            \
+        x = o < x ? o : x;                                                                                           \
     }
-    return x;
+    LS_MIN_STEP(LS_DPP_QUAD_1032, 0xf)
+    LS_MIN_STEP(LS_DPP_QUAD_2301, 0xf)
+    LS_MIN_STEP(LS_DPP_ROW_HALF_MIRROR, 0xf)
+    LS_MIN_STEP(LS_DPP_ROW_MIRROR, 0xf)
+    LS_MIN_STEP(LS_DPP_ROW_BCAST15, 0xa)
+    LS_MIN_STEP(LS_DPP_ROW_BCAST31, 0xc)
+#undef LS_MIN_STEP
+    const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 63);
+    const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
+    return ((unsigned long long)rhi << 32) | rlo;
 }
 
 } // namespace lsamd
