@@ -111,6 +111,8 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // of what the device holds, so a call whose board equals it uploads nothing; the kernel leaves the winner board in
 // `dev_rows` and the host applies the same move to the shadow.
 struct NqResident {
+    double t_pre = 0, t_launch = 0, t_wait = 0, t_post = 0; // LS_AMD_TRACE: where a resident LS-step call spends its time
+    unsigned long long calls = 0;
     int n = 0;
     std::vector<int32_t> shadow; // [slots][n]
     std::vector<char> valid;     // [slots]
