@@ -9,6 +9,8 @@ binaries' streams."""
 import hashlib
 import os
 import random
+
+import pytest
 import struct
 
 import numpy as np
@@ -48,6 +50,34 @@ def test_rng_stream_layout():
     # straddling a refill: 63 u32 draws leave one word; the next u64 takes it as the LOW half
     mixed = ls_amd.host_rng_script(seed, [(0, 0, 0)] * 63 + [(1, 0, 0), (0, 0, 0)])
     assert mixed[63] == exp[63] | (exp[64] << 32) and mixed[64] == exp[65]
+
+
+def test_chacha20rng_word_stream_against_openssl():
+    # An implementation neither the product nor the oracle shares: the OpenSSL command-line tool.  Encrypting zeros with
+    # ChaCha20 under the seed as key, counter 0 and a zero nonce yields the keystream; ChaCha20Rng::from_seed (64-bit block
+    # counter 0, stream id 0: the same initial state) must hand out exactly its little-endian 32-bit words, in order, across
+    # several four-block refills -- for the seeds the examples derive from "42", "43", ... (examples/nqueens/src/main.rs:28-39).
+    # Pins the generator core (block function, word order, block sequencing); rand's sampling algorithms on top of it stay
+    # "parity unpinned".
+    import shutil
+    import subprocess
+    if shutil.which("openssl") is None:
+        pytest.skip("no openssl command-line tool")
+    for seed_str in ("42", "43", "105", ""):
+        seed = hashlib.blake2b(seed_str.encode(), digest_size=32).digest()
+        assert ls_amd.host_hash_seed(seed_str) == seed
+        n_words = 16 * 21 + 5                                    # five full refills (64 words each) and a bit
+        r = subprocess.run(["openssl", "enc", "-chacha20", "-K", seed.hex(), "-iv", bytes(16).hex(), "-nosalt", "-nopad"],
+                           input=bytes(4 * n_words + 60), capture_output=True, timeout=60)
+        if r.returncode != 0:
+            pytest.skip("this openssl has no chacha20 stream cipher: " + r.stderr.decode()[:200])
+        ks = r.stdout
+        exp = [int.from_bytes(ks[4 * i:4 * i + 4], "little") for i in range(n_words)]
+        assert ls_amd.host_rng_script(seed, [(0, 0, 0)] * n_words) == exp          # the product's host generator
+        rng = lo.ChaCha20Rng(seed)                                                 # the oracle's restatement
+        assert [rng.next_u32() for _ in range(n_words)] == exp
+        u64 = ls_amd.host_rng_script(seed, [(1, 0, 0)] * (n_words // 2))
+        assert u64 == [exp[2 * i] | (exp[2 * i + 1] << 32) for i in range(n_words // 2)]
 
 
 def _oracle_script(seed, ops, weights):
