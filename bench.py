@@ -596,6 +596,7 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True):
             "kernel": {k: c.get(k) for k in ("duration_us", "valu_issue_bound_us", "lds_array_bound_us", "cus_usable", "roofline", "source")} if c else None}
     if e2e:
         out["config4_end_to_end_64_restarts_one_gpu"] = config4_end_to_end(ctx, n)
+        out.update(single_restart_end_to_end(ctx))
     ctx.set_algo("scan")
     out.update(sched_measurements(ctx, torch, dev, timed, issue_roofline))
     # the HBM figure the rooflines divide by is the vendor's 8 TB/s; this is what a plain device-to-device
@@ -642,6 +643,49 @@ def config4_end_to_end(ctx, n):
                 "mode": "free-running slots (one context per slot), one fused LS-step launch per iteration, boards resident on the device"}
     except Exception as e:  # noqa: BLE001 - a secondary line must not take the bench down
         return {"error": repr(e)}
+
+
+def single_restart_end_to_end(ctx):
+    """BASELINE configs 2, 3 and 5 end to end on one GPU (one restart each, seed "42", the reference's hyper-parameters:
+    examples/nqueens/src/main.rs:129-135, examples/employee-scheduling/src/main.rs:11-31): the reference's ILS driver on
+    the host, every score and neighbourhood on the GPU.  Latency-bound: one launch per LS iteration."""
+    import ls_amd
+
+    def run(s, max_rounds):
+        t0 = time.perf_counter()
+        rounds = 0
+        while not s.is_finished() and rounds < max_rounds:
+            s.execute_round()
+            rounds += 1
+            b = s.best()
+            if b is not None and (b[0] == 0 or b[0] == (0, 0)):
+                break
+        dt = time.perf_counter() - t0
+        st, b = s.stats(), s.best()
+        s.close()
+        return {"seconds": dt, "rounds": rounds, "best_score": None if b is None else b[0], "ls_iterations": st["ls_iterations"],
+                "neighbours_scored": st["neighbours_scored"], "neighbours_per_s": st["neighbours_scored"] / dt,
+                "us_per_ls_iteration": dt / max(1, st["ls_iterations"]) * 1e6}
+
+    out = {}
+    try:
+        ctx.set_algo("auto")
+        nq = dict(local_search_max_iterations=10_000, best_solutions_capacity=32, all_solutions_capacity=100_000,
+                  all_solution_iteration_expiry=10_000, iterated_local_search_max_iterations=10_000, max_allow_no_improvement_for=5)
+        sched = dict(local_search_max_iterations=1_000, window_size=100, best_solutions_capacity=64, all_solutions_capacity=100_000,
+                     all_solution_iteration_expiry=1_000, iterated_local_search_max_iterations=250, max_allow_no_improvement_for=20)
+        out["config2_end_to_end_nq1024_seed42"] = run(ls_amd.Solver.nqueens(ctx, 1024, "42", dict(nq, window_size=5 * 1024)), 10_000)
+        out["config3_end_to_end_sched_example_seed42"] = run(ls_amd.Solver.scheduling(ctx, 31, 0, 7, "42", sched), 250)
+        rng = np.random.default_rng(5)
+        bits = np.zeros(10_000, dtype=np.uint64)
+        for e in range(10_000):
+            for d in rng.choice(31, size=int(rng.integers(0, 4)), replace=False):
+                bits[e] |= np.uint64(1) << np.uint64(d)
+        out["config5_end_to_end_sched10k_window65536_seed42"] = run(
+            ls_amd.Solver.scheduling(ctx, 31, 0, 10_000, "42", dict(sched, window_size=65_536), holiday_bits=bits), 250)
+    except Exception as e:  # noqa: BLE001 - a secondary line must not take the bench down
+        out["single_restart_end_to_end_error"] = repr(e)
+    return out
 
 
 def sched_measurements(ctx, torch, dev, timed, issue_roofline):
