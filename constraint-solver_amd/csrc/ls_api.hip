@@ -50,16 +50,20 @@ int sched_score_dev(ls_ctx *ctx, int n_states, const int *states_d, long long *h
 int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const ls_sched_move *moves_d,
                          const long long *n_moves_d, long long max_moves, long long window,
                          ls_sched_result *results_d, long long *hard_out_d, long long *soft_out_d,
-                         unsigned long long *done_flag = nullptr, unsigned long long done_seq = 0);
+                         unsigned long long *done_flag = nullptr, unsigned long long done_seq = 0,
+                         const int *inline_state_h = nullptr, long long inline_n_moves = 0);
 bool sched_is_fused_launch(const ls_ctx *ctx, long long max_moves);
 int sched_exhaustive_moves_dev(ls_ctx *ctx, int n_restarts, const int *states_d, ls_sched_move *moves_d, long long *n_moves_d);
+int sched_eval_exhaustive_dev(ls_ctx *ctx, int n_restarts, const int *states_d, long long window, ls_sched_result *results_d,
+                              bool *handled, unsigned long long *done_flag = nullptr, unsigned long long done_seq = 0,
+                              const int *inline_state_h = nullptr);
 
 static void for_each_buf(ls_ctx *ctx, void (*f)(DevBuf &))
 {
     DevBuf *bufs[] = {&ctx->nq_rows, &ctx->nq_cur, &ctx->nq_cols, &ctx->nq_ncols, &ctx->nq_results,
                       &ctx->nq_scores, &ctx->nq_keys, &ctx->nq_tabs, &ctx->nq_colscores, &ctx->nq_totals, &ctx->nq_next_rows,
                       &ctx->sc_states, &ctx->sc_moves, &ctx->sc_nmoves, &ctx->sc_results, &ctx->sc_hard,
-                      &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sched.holiday_bits, &ctx->sched.lane_tab,
+                      &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sc_cand_keys, &ctx->sched.holiday_bits, &ctx->sched.lane_tab,
                       &ctx->sc_resident_moves};
     for (DevBuf *b : bufs) f(*b);
 }
@@ -142,6 +146,7 @@ int ls_ctx_create(int device_id, ls_ctx **out)
     if (const char *v = getenv("LS_SCHED_ZEROCOPY")) ctx->sched_zero_copy = atoi(v) != 0;
     if (const char *v = getenv("LS_SCHED_FUSED")) ctx->sched_fused = atoi(v) != 0;
     ctx->sched_force_64 = getenv("LS_SCHED_FORCE_64") != nullptr;
+    if (const char *v = getenv("LS_SCHED_DELTA")) ctx->sched_delta = atoi(v) != 0;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->wave_size = prop.warpSize;
     ctx->clock_khz = prop.clockRate;
@@ -840,13 +845,12 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
     Staging &si = ctx->stage_in, &so = ctx->stage_out;
     *si.h<long long>(o_nm) = n_moves;
     memcpy(si.h<char>(o_st), state, (size_t)S * 4);
-    // The per-iteration inputs are 136 bytes and the output 32: the kernels read / write the pinned blocks directly
-    // (LS_SCHED_ZEROCOPY=0 restores the two staging copies), so the chain is kernels only.
-    const bool zc = ctx->sched_zero_copy && n_moves <= 4096; // many blocks re-reading the state over PCIe cost more than the copies
+    // The per-iteration inputs are 136 bytes and the output 32.  LS_SCHED_ZEROCOPY (default on): the state and n_moves
+    // travel in the kernel arguments -- no copy and no PCIe read by the kernels; off: one staging copy.
+    const bool zc = ctx->sched_zero_copy;
     if (!zc) LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
     // The result record always goes straight to pinned host memory and its writer publishes a completion word, which
-    // the caller polls instead of synchronising the stream; the state is read in place by the one-block fused launch and
-    // staged through one small copy when thousands of blocks would otherwise read it over PCIe.
+    // the caller polls instead of synchronising the stream.
     NqResident &rs = ctx->nq_res; // the context's completion word is shared with the N-queens LS step (one call at a time per context)
     if (!rs.flag) {
         LS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&rs.flag), 64, hipHostMallocCoherent));
@@ -854,9 +858,8 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
         LS_RESERVE(ctx, rs.counter, 256);
         LS_HIP(ctx, hipMemsetAsync(rs.counter.p, 0, 256, ctx->stream));
     }
-    rc = sched_eval_batch_dev(ctx, 1, zc ? si.h<int>(o_st) : si.d<int>(o_st), ctx->sc_resident_moves.as<ls_sched_move>(),
-                              zc ? si.h<long long>(o_nm) : si.d<long long>(o_nm), n_moves, window,
-                              so.h<ls_sched_result>(0), nullptr, nullptr, rs.flag, ++rs.seq);
+    rc = sched_eval_batch_dev(ctx, 1, si.d<int>(o_st), ctx->sc_resident_moves.as<ls_sched_move>(), si.d<long long>(o_nm), n_moves, window,
+                              so.h<ls_sched_result>(0), nullptr, nullptr, rs.flag, ++rs.seq, zc ? state : nullptr, n_moves);
     if (rc != LS_OK) return rc;
     rc = wait_done_word(ctx, rs.flag, rs.seq);
     if (rc != LS_OK) return rc;
@@ -902,12 +905,40 @@ int ls_sched_eval_exhaustive(ls_ctx *ctx, int32_t n_restarts, const int32_t *sta
     const long long per = (long long)S * ctx->sched.n_employees;
     const size_t st_b = (size_t)n_restarts * S * 4, mv_b = (size_t)n_restarts * per * sizeof(ls_sched_move),
                  nm_b = (size_t)n_restarts * 8, res_b = (size_t)n_restarts * sizeof(ls_sched_result);
+    bool handled = false;
+    if (n_restarts == 1 && ctx->sched_delta && ctx->sched_zero_copy) {
+        // one restart (config 5's per-GPU shape): the state travels in the kernel arguments, the result record goes
+        // straight to pinned host memory and its writer publishes the completion word the caller polls
+        hipError_t e = ctx->stage_out.reserve(256);
+        if (e != hipSuccess) return set_err(ctx, LS_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
+        NqResident &rs = ctx->nq_res;
+        if (!rs.flag) {
+            LS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&rs.flag), 64, hipHostMallocCoherent));
+            *rs.flag = 0;
+            LS_RESERVE(ctx, rs.counter, 256);
+            LS_HIP(ctx, hipMemsetAsync(rs.counter.p, 0, 256, ctx->stream));
+        }
+        rc = sched_eval_exhaustive_dev(ctx, 1, nullptr, window, ctx->stage_out.h<ls_sched_result>(0), &handled, rs.flag, ++rs.seq, states);
+        if (rc != LS_OK) return rc;
+        rc = wait_done_word(ctx, rs.flag, rs.seq);
+        if (rc != LS_OK) return rc;
+        *results = *ctx->stage_out.h<ls_sched_result>(0);
+        return LS_OK;
+    }
     LS_RESERVE(ctx, ctx->sc_states, st_b);
-    LS_RESERVE(ctx, ctx->sc_moves, mv_b);
-    LS_RESERVE(ctx, ctx->sc_nmoves, nm_b);
     LS_RESERVE(ctx, ctx->sc_results, res_b);
     LS_HIP(ctx, hipMemcpyAsync(ctx->sc_states.p, states, st_b, hipMemcpyHostToDevice, ctx->stream));
-    // the move list is generated on the device from the state: nothing but the states crosses PCIe
+    // nothing but the states crosses PCIe.  Delta scorer: the candidates are generated inside the scoring kernels ...
+    rc = sched_eval_exhaustive_dev(ctx, n_restarts, ctx->sc_states.as<int>(), window, ctx->sc_results.as<ls_sched_result>(), &handled);
+    if (rc != LS_OK) return rc;
+    if (handled) {
+        LS_HIP(ctx, hipMemcpyAsync(results, ctx->sc_results.p, res_b, hipMemcpyDeviceToHost, ctx->stream));
+        LS_SYNC(ctx);
+        return LS_OK;
+    }
+    // ... wavefront-per-candidate kernels (LS_SCHED_DELTA=0): the move list is written on the device first
+    LS_RESERVE(ctx, ctx->sc_moves, mv_b);
+    LS_RESERVE(ctx, ctx->sc_nmoves, nm_b);
     rc = sched_exhaustive_moves_dev(ctx, n_restarts, ctx->sc_states.as<int>(), ctx->sc_moves.as<ls_sched_move>(),
                                     ctx->sc_nmoves.as<long long>());
     if (rc != LS_OK) return rc;

@@ -11,6 +11,7 @@ struct SchedLaneConst {
     uint64_t mask2;        // bit d+1 if day d+1 is scored                (H2, lib.rs:286-292)
     uint64_t h3mask;       // days compared with day d in a weekend-started 9-window (H3, lib.rs:295-315)
     uint64_t wdmask;       // scored days on day d's weekday; 0 on weekends / unscored lanes (S2, lib.rs:194-218)
+    uint64_t adj;          // every scored day paired with day d by H2 or H3, in either direction (delta scorer)
     int32_t gsize;         // popcount(wdmask)
     int32_t flags;         // bit 0: lane is a scored day; bit 1: first lane of a Mon-Fri weekday group
 };
@@ -42,6 +43,12 @@ inline void sched_build_lane_table(int D, int start_weekday, SchedLaneConst out[
         L.gsize = __builtin_popcountll(L.wdmask);
         L.flags = (scored ? 1 : 0) | ((scored && weekday && d < 7) ? 2 : 0);
         out[d] = L;
+    }
+    for (int d = 0; d < 64; d++) { // the pair relation of H2 / H3, symmetric
+        uint64_t adj = out[d].mask2 | out[d].h3mask;
+        for (int q = 0; q < 64; q++)
+            if ((out[q].mask2 | out[q].h3mask) >> d & 1) adj |= 1ull << q;
+        out[d].adj = adj;
     }
 }
 

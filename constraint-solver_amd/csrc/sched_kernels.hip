@@ -43,6 +43,15 @@ namespace lsamd {
 
 typedef unsigned long long u64;
 
+#ifdef LS_NQ_STAMPS
+// Diagnostic build only (tools/table_stamps.py build; tools/sched_stamps.py): wall-clock stamps (100 MHz) of the delta
+// kernels' phases, written to a buffer no other code reads.  The product build has none of this.
+__device__ unsigned long long g_sc_stamps[1024 * 16];
+#define LS_SC_STAMP(P) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_sc_stamps[blockIdx.x * 16 + (P)] = wall_clock64(); } while (0)
+#else
+#define LS_SC_STAMP(P) do { } while (0)
+#endif
+
 constexpr u64 SC_KEY_EMPTY = ~0ull;
 constexpr int SC_BIG = 1 << 20;
 constexpr int SC_COUNT_CHUNK = 1024; // moves per block in the window-count pass
@@ -191,7 +200,8 @@ struct SchedEvalArgs {
     const long long *n_moves;   // [n_restarts]
     long long max_moves;
     long long window;
-    int n_chunks;        // count-pass blocks per restart
+    int n_chunks;        // count-pass blocks per restart (delta pipeline: chunks of chunk_moves moves)
+    long long chunk_moves; // delta pipeline: moves per block of sched_eval_all_kernel
     int *chunk_counts;   // [n_restarts][n_chunks] non-tabu moves per chunk
     long long *k_end;    // [n_restarts]  first index not scored
     long long *n_scored; // [n_restarts]
@@ -203,7 +213,17 @@ struct SchedEvalArgs {
     ls_sched_result *results;       // written by pass 2 itself when blocks_per_restart == 1
     unsigned long long *done_flag;  // nullable; one-restart launches only: host word <- done_seq after the result record
     unsigned long long done_seq;
+    u64 *cand_keys;                 // delta pipeline: [n_restarts][max_moves] argmin key per candidate (SC_KEY_EMPTY: not a candidate)
+    // one-restart launches may carry their per-call inputs in the kernel arguments (no copy, no PCIe read):
+    int inline_valid;
+    long long inline_n_moves;
+    int inline_state[64];
 };
+
+__device__ __forceinline__ int sched_state_at(const SchedEvalArgs &a, int r, int d)
+{
+    return a.inline_valid ? a.inline_state[d & 63] : a.states[(long long)r * a.in.S + d];
+}
 
 __device__ __forceinline__ bool sched_move_ok(int type, int a, int b, int S, int E)
 {
@@ -214,7 +234,7 @@ __device__ __forceinline__ bool sched_move_ok(int type, int a, int b, int S, int
 
 __device__ __forceinline__ long long sched_nm(const SchedEvalArgs &a, int r)
 {
-    const long long nm = a.n_moves[r];
+    const long long nm = a.inline_valid ? a.inline_n_moves : a.n_moves[r];
     return nm < 0 ? 0 : (nm > a.max_moves ? a.max_moves : nm);
 }
 
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(256) void sched_count_kernel(SchedEvalArgs a)
     __shared__ int s_state[64];
     __shared__ int s_cnt[4];
     const int r = blockIdx.y;
-    if (threadIdx.x < 64) s_state[threadIdx.x] = (int)threadIdx.x < a.in.S ? a.states[(long long)r * a.in.S + threadIdx.x] : -1;
+    if (threadIdx.x < 64) s_state[threadIdx.x] = (int)threadIdx.x < a.in.S ? sched_state_at(a, r, (int)threadIdx.x) : -1;
     __syncthreads();
     const long long nm = sched_nm(a, r);
     const ls_sched_move *mv = a.moves + (long long)r * a.max_moves;
@@ -260,7 +280,7 @@ __global__ __launch_bounds__(256) void sched_locate_kernel(SchedEvalArgs a)
     __shared__ long long s_run, s_found;
     const int r = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x < 64) s_state[threadIdx.x] = (int)threadIdx.x < a.in.S ? a.states[(long long)r * a.in.S + threadIdx.x] : -1;
+    if (threadIdx.x < 64) s_state[threadIdx.x] = (int)threadIdx.x < a.in.S ? sched_state_at(a, r, (int)threadIdx.x) : -1;
     if (threadIdx.x == 0) { s_chunk = -1; s_run = 0; s_found = -1; }
     __syncthreads();
     const long long nm = sched_nm(a, r);
@@ -382,7 +402,7 @@ __device__ __forceinline__ void sched_locate_in_block(const SchedEvalArgs &a, in
     m0.type = -1; m0.a = 0; m0.b = 0;
     if ((long long)threadIdx.x < a.max_moves) m0 = mv[threadIdx.x];
     const long long nm = sched_nm(a, r);
-    if (threadIdx.x < 64) sh.state[threadIdx.x] = (int)threadIdx.x < a.in.S ? a.states[(long long)r * a.in.S + threadIdx.x] : -1;
+    if (threadIdx.x < 64) sh.state[threadIdx.x] = (int)threadIdx.x < a.in.S ? sched_state_at(a, r, (int)threadIdx.x) : -1;
     if (threadIdx.x == 0) sh.found = -1;
     sh.moves[threadIdx.x] = m0;
     __syncthreads();
@@ -431,7 +451,7 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_kernel(SchedEvalArgs a)
     long long best_idx = -1;
     if (wave < n_batches) {
     const SchedLaneConst L = a.in.lane_tab[lane];
-    const int base = lane < S ? (FUSED ? s_fused.state[lane] : a.states[(long long)r * S + lane]) : -1 - lane;
+    const int base = lane < S ? (FUSED ? s_fused.state[lane] : sched_state_at(a, r, lane)) : -1 - lane;
     const u64 eq_base = sched_build_eq(D, base) & L.scored_mask;
     const int hb_base = sched_holiday_bit(a.in, base, lane);
     const ls_sched_move *mv = a.moves + (long long)r * a.max_moves;
@@ -641,7 +661,7 @@ __global__ __launch_bounds__(64 * NW) void sched_eval32_kernel(SchedEvalArgs a)
         L.scored_mask = (unsigned)L64.scored_mask; L.weekend_mask = (unsigned)L64.weekend_mask;
         L.mask2 = (unsigned)L64.mask2; L.h3mask = (unsigned)L64.h3mask; L.wdmask = (unsigned)L64.wdmask;
         L.gsize = L64.gsize; L.flags = L64.flags;
-        const int base = li < S ? (FUSED ? s_fused.state[li] : a.states[(long long)r * S + li]) : -1 - li; // both halves hold the base vector
+        const int base = li < S ? (FUSED ? s_fused.state[li] : sched_state_at(a, r, li)) : -1 - li; // both halves hold the base vector
         unsigned eq_base = 0;
 #pragma unroll
         for (int q = 0; q < 32; q++)
@@ -761,6 +781,602 @@ __global__ __launch_bounds__(64 * NW) void sched_eval32_kernel(SchedEvalArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pass 2, DELTA formulation (the default): one LANE per candidate.  Every term of the score is a sum over
+// employees of a function of the employee's day set (a bitmask over the scored days), or a range over such
+// functions; a candidate changes the day sets of exactly two employees X (the employee of the first edited
+// day) and Y (the new employee of that day):
+//     ChangeDay(p1 <- Y):  X' = X - p1,        Y' = Y + p1        (lib.rs:466-470)
+//     SwapDays(p1, p2):    X' = X - p1 + p2,   Y' = Y - p2 + p1   (lib.rs:471-478; Y = employee of p2)
+// (bits of unscored stored days are never in a set).  Per block, wavefront 0 tabulates the base state once
+// (lane = day): the day set of each day's employee, its H4 / S1 values, holiday bits, and for the three
+// "range" terms the set of values present plus how many employees hold each value.  A lane then computes
+//     H1      holiday bits of the edited days, new - old                                     lib.rs:273-280
+//     H2+H3   popcount(adj[p] & set) for the sets that lose / gain day p (adj = the static pair relation) :286-315
+//     H4, S1  F14 / F7 of X', Y' minus the tabulated values of X, Y; F = number of windows in which the set
+//             holds more than 3 of 14 / 2 of 7 days, by bit-sliced sliding sums over the mask       :318-339
+//     S2      per edited Mon-Fri weekday: the set of per-employee day counts on that weekday with X, Y
+//             replaced; min if it is below the group size                                           :194-218
+//     S3, S4  the sets of day counts / weekend-day counts with X, Y replaced; highest - lowest      :345-365
+// -- about 350 instructions per LANE for <= 32-day schedules, where the wavefront-per-candidate kernels above
+// spend 66 (two candidates per pass) or 135 wavefront instructions per CANDIDATE.
+
+template <typename M> struct SchedMaskOps;
+template <> struct SchedMaskOps<unsigned> {
+    static __device__ __forceinline__ int popc(unsigned x) { return __popc(x); }
+    static __device__ __forceinline__ int lsb(unsigned x) { return __ffs((int)x) - 1; }
+    static __device__ __forceinline__ int msb(unsigned x) { return 31 - __clz((int)x); }
+};
+template <> struct SchedMaskOps<u64> {
+    static __device__ __forceinline__ int popc(u64 x) { return __popcll(x); }
+    static __device__ __forceinline__ int lsb(u64 x) { return __ffsll((long long)x) - 1; }
+    static __device__ __forceinline__ int msb(u64 x) { return 63 - __clzll((long long)x); }
+};
+
+// the base state of one restart, tabulated in LDS
+template <typename M> struct SchedBaseTab {
+    int e[64];             // employee of stored day d (a distinct negative id beyond the stored days)
+    M eq[64];              // scored days worked by the employee of day d
+    M adj[64];             // scored days paired with day d by H2 / H3 (0 for an unscored day)
+    M wd[64];              // scored days on the weekday of day d (0: weekend or unscored)
+    unsigned short g[64];  // F14 | F7 << 8 of eq[d]
+    unsigned char hol[64]; // holiday bit of (employee of day d, day d)
+    // the three range terms: which values are held by at least 1 / 2 / 3 employees
+    u64 tot_b[3];          // bit i: scored-day count i + 1
+    unsigned wk_b[3];      // bit i: i weekend days (among the employees present)
+    unsigned grp_b[7][3];  // weekday residue r, bit i: i + 1 of its days
+    int grp_size[7];       // days of the weekday group (0: weekend residue)
+    int grp_v[7];          // S2 value of the group in the base state
+    M valid7, valid14, weekend;
+    int hard, soft_s1, soft_s2; // base hard score; S1 and S2 of the base state
+};
+
+// number of 7-day / 14-day windows (starting at the bits of valid7 / valid14) in which mask m holds more than
+// 2 / more than 3 days: bit-sliced sliding sums 1 -> 2 -> 4, 3 -> 7 -> 14
+template <typename M>
+__device__ __forceinline__ void sched_window_counts(M m, M valid7, M valid14, int &f7, int &f14)
+{
+    typedef SchedMaskOps<M> O;
+    const M a1 = m >> 1;
+    const M b0 = m ^ a1, b1 = m & a1;                                  // two days from w
+    const M c0 = b0 >> 2, c1 = b1 >> 2;
+    const M t0 = b0 ^ c0, k0 = b0 & c0, x1 = b1 ^ c1;
+    const M t1 = x1 ^ k0, t2 = (b1 & c1) | (k0 & x1);                  // four days from w (0..4)
+    const M e0 = b0 >> 4, e1 = b1 >> 4, m6 = m >> 6;
+    const M d0 = e0 ^ m6, d1 = e1 | (e0 & m6);                         // three days from w + 4 (0..3)
+    const M u0 = t0 ^ d0, k = t0 & d0, y1 = t1 ^ d1;
+    const M u1 = y1 ^ k, u2 = t2 | (t1 & d1) | (k & y1);               // seven days from w (0..7)
+    f7 = O::popc((u2 | (u1 & u0)) & valid7);                           // >= 3
+    const M v0 = u0 >> 7, v1 = u1 >> 7, v2 = u2 >> 7;
+    const M j0 = u0 & v0, z1 = u1 ^ v1;
+    const M j1 = (u1 & v1) | (j0 & z1), z2 = u2 ^ v2;
+    const M x2 = z2 ^ j1, x3 = (u2 & v2) | (j1 & z2);                  // fourteen days from w, bits 2 and 3
+    f14 = O::popc((x2 | x3) & valid14);                                // >= 4
+}
+
+#define LS_DPP_ROW_SHR(n) (0x110 + (n))
+#define LS_DPP_WAVE_SHR1 0x138
+
+// inclusive prefix OR over the lanes of the wavefront
+__device__ __forceinline__ unsigned wave_prefix_or_u32(unsigned x)
+{
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_ROW_SHR(1), 0xf, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_ROW_SHR(2), 0xf, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_ROW_SHR(4), 0xf, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_ROW_SHR(8), 0xf, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_ROW_BCAST15, 0xa, 0xf, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, LS_DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return x;
+}
+
+// every lane contributes one value as a one-hot word (or 0): which values are contributed by >= 1, >= 2, >= 3 lanes.
+// A lane's value is a repeat if an earlier lane has it (exclusive prefix OR), a second repeat if an earlier lane was
+// already a repeat of it -- no atomics, no serialisation on popular values.
+__device__ __forceinline__ void wave_value_sets_u32(unsigned onehot, unsigned &b1, unsigned &b2, unsigned &b3)
+{
+    const unsigned in1 = wave_prefix_or_u32(onehot);
+    const unsigned ex1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)in1, LS_DPP_WAVE_SHR1, 0xf, 0xf, false);
+    const unsigned dup = onehot & ex1;
+    const unsigned in2 = wave_prefix_or_u32(dup);
+    const unsigned ex2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)in2, LS_DPP_WAVE_SHR1, 0xf, 0xf, false);
+    b1 = (unsigned)__builtin_amdgcn_readlane((int)in1, 63);
+    b2 = (unsigned)__builtin_amdgcn_readlane((int)in2, 63);
+    b3 = wave_or_u32(onehot & ex2);
+}
+
+// The table is filled by wavefronts 0, 1 and 2 of the block side by side (lane = day; each derives the day-equality
+// row of its lane first); the caller synchronises the block after.
+//   part 0: per-day rows (employee, day set, pair / weekday masks, H4 | S1 values, holiday bit), base hard score, S1
+//   part 1: S3 / S4 value sets (day counts, weekend-day counts)
+//   part 2: S2 value sets per weekday, group sizes and base values
+template <typename M>
+__device__ __forceinline__ void sched_build_base_tab(const SchedInst &in, int part, int e /* employee of day `lane`; -1 - lane beyond S */,
+                                                     int hol /* holiday bit of (e, lane), gathered by the caller (part 0) */,
+                                                     const SchedLaneConst &L, int lane, SchedBaseTab<M> &T)
+{
+    typedef SchedMaskOps<M> O;
+    const int D = in.D;
+    M eq = 0;
+#pragma unroll
+    for (int q = 0; q < (int)sizeof(M) * 8; q++)
+        if (q < D && e == __builtin_amdgcn_readlane(e, q)) eq |= (M)1 << q;
+    LS_SC_STAMP(8);
+    const bool scored = L.flags & 1;
+    const M low = ((M)1 << (lane & ((int)sizeof(M) * 8 - 1))) - 1;
+    const M weekend = (M)L.weekend_mask, wdm = (M)L.wdmask;
+    const bool rep = scored && (eq & low) == 0; // first scored day of its employee
+    if (part == 0) {
+        const M valid7 = D >= 7 ? (M)(L.scored_mask >> 6) : 0, valid14 = D >= 14 ? (M)(L.scored_mask >> 13) : 0;
+        int f7, f14;
+        sched_window_counts<M>(eq, valid7, valid14, f7, f14);
+        T.e[lane] = e;
+        T.eq[lane] = eq;
+        T.adj[lane] = (M)L.adj;
+        T.wd[lane] = wdm;
+        T.g[lane] = (unsigned short)(f14 | (f7 << 8));
+        T.hol[lane] = (unsigned char)hol;
+        int hard_l = 0, soft_l = 0;
+        if (scored) hard_l = hol + O::popc(eq & (M)(L.mask2 | L.h3mask));
+        if (rep) { hard_l += f14; soft_l = f7; }
+        const int hs = wave_sum_i32(hard_l | (soft_l << 16)); // hard <= 316, S1 <= 58 * 64: 16-bit fields
+        if (lane == 0) {
+            T.valid7 = valid7; T.valid14 = valid14; T.weekend = weekend;
+            T.hard = hs & 0xffff;
+            T.soft_s1 = hs >> 16;
+        }
+    } else if (part == 1) {
+        u64 tot_onehot = 0;
+        unsigned wk_onehot = 0;
+        if (rep) {
+            tot_onehot = 1ull << (O::popc(eq) - 1);
+            wk_onehot = 1u << O::popc(eq & weekend);
+        }
+        unsigned tl[3], th[3] = {0, 0, 0}, wk[3];
+        wave_value_sets_u32((unsigned)tot_onehot, tl[0], tl[1], tl[2]);
+        if (sizeof(M) > 4) wave_value_sets_u32((unsigned)(tot_onehot >> 32), th[0], th[1], th[2]);
+        wave_value_sets_u32(wk_onehot, wk[0], wk[1], wk[2]);
+        if (lane < 3) {
+            const unsigned lo = lane == 0 ? tl[0] : (lane == 1 ? tl[1] : tl[2]), hi = lane == 0 ? th[0] : (lane == 1 ? th[1] : th[2]);
+            T.tot_b[lane] = ((u64)hi << 32) | lo;
+            T.wk_b[lane] = lane == 0 ? wk[0] : (lane == 1 ? wk[1] : wk[2]);
+        }
+    } else {
+        // weekday groups: residue r = lane % 7 occupies bits 10 * (r % 3) .. + 9 of word r / 3
+        const int gr = lane % 7;
+        unsigned g_onehot = 0;
+        if (wdm != 0 && (eq & wdm & low) == 0) g_onehot = 1u << (10 * (gr % 3) + O::popc(eq & wdm) - 1); // first day of its employee on this weekday
+        unsigned g0[3], g1[3], g2[3];
+        wave_value_sets_u32(gr < 3 ? g_onehot : 0, g0[0], g0[1], g0[2]);
+        wave_value_sets_u32(gr >= 3 && gr < 6 ? g_onehot : 0, g1[0], g1[1], g1[2]);
+        wave_value_sets_u32(gr == 6 ? g_onehot : 0, g2[0], g2[1], g2[2]);
+        int v = 0;
+        if (lane < 7) {
+            const int sh = 10 * (lane % 3);
+            unsigned gb[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                gb[i] = ((lane < 3 ? g0[i] : (lane < 6 ? g1[i] : g2[i])) >> sh) & 0x3ffu;
+                T.grp_b[lane][i] = gb[i];
+            }
+            const int gsize = (L.flags & 2) ? L.gsize : 0; // lanes 0..6 are the first days of their residues
+            if (gsize > 0) {
+                const int mn = __ffs((int)gb[0]); // smallest per-employee count on this weekday
+                if (mn < gsize) v = mn;
+            }
+            T.grp_size[lane] = gsize;
+            T.grp_v[lane] = v;
+        }
+        const int s2 = wave_sum_i32(v);
+        if (lane == 0) T.soft_s2 = s2;
+    }
+    LS_SC_STAMP(11);
+}
+
+// the set of values held by the employees after X and Y trade their old values for new ones; b[0..2] = values held by
+// at least 1 / 2 / 3 employees in the base state
+template <typename B>
+__device__ __forceinline__ B sched_replace_values(const B *b, bool hXo, int vXo, bool hYo, int vYo, bool hXn, int vXn, bool hYn, int vYn)
+{
+    B bits = b[0];
+    const bool both = hXo && hYo && vXo == vYo;
+    const B others = both ? b[2] : b[1]; // values that some employee other than X (and Y) holds as well
+    if (hXo && !((others >> vXo) & 1)) bits &= ~((B)1 << vXo);
+    if (hYo && !((others >> vYo) & 1)) bits &= ~((B)1 << vYo);
+    if (hXn) bits |= (B)1 << vXn;
+    if (hYn) bits |= (B)1 << vYn;
+    return bits;
+}
+
+// (hard, soft) of one candidate; o1 / o2 = base employees of p1 / p2, n1 = new employee of p1, hbits = holiday bits
+// of (n1, p1) | (n2, p2) << 1.  Only called for well-formed, non-tabu candidates.
+template <typename M>
+__device__ __forceinline__ void sched_delta_score(const SchedBaseTab<M> &T, int e_lane, int D, bool swap, int p1, int p2, int n1,
+                                                  int hbits, int &hard_out, int &soft_out)
+{
+    typedef SchedMaskOps<M> O;
+    const M bit1 = p1 < D ? (M)1 << p1 : 0, bit2 = (swap && p2 < D) ? (M)1 << p2 : 0;
+    const M mX = T.eq[p1];
+    const int gX = T.g[p1];
+    M mY;
+    int gY;
+    if (swap) {
+        mY = T.eq[p2];
+        gY = T.g[p2];
+    } else {
+        mY = 0; // the day set of an arbitrary employee: compare with every scored day (e_lane: lane d holds day d)
+#pragma unroll
+        for (int d = 0; d < (int)sizeof(M) * 8; d++)
+            if (d < D && __builtin_amdgcn_readlane(e_lane, d) == n1) mY |= (M)1 << d;
+        gY = mY ? T.g[O::lsb(mY)] : 0;
+    }
+    const M mXn = (mX & ~bit1) | bit2, mYn = (mY & ~bit2) | bit1;
+    const M A1 = T.adj[p1], A2 = swap ? T.adj[p2] : 0;
+    int f7X, f14X, f7Y, f14Y;
+    sched_window_counts<M>(mXn, T.valid7, T.valid14, f7X, f14X);
+    sched_window_counts<M>(mYn, T.valid7, T.valid14, f7Y, f14Y);
+    int hard = T.hard + (hbits & 1) - T.hol[p1];
+    if (swap) hard += ((hbits >> 1) & 1) - T.hol[p2];
+    hard += O::popc(A1 & mYn) - O::popc(A1 & mX) + O::popc(A2 & mXn) - O::popc(A2 & mY);
+    hard += f14X + f14Y - (gX & 0xff) - (gY & 0xff);
+    int soft = T.soft_s1 + T.soft_s2 + f7X + f7Y - (gX >> 8) - (gY >> 8);
+    const int cX = O::popc(mX), cY = O::popc(mY), cXn = O::popc(mXn), cYn = O::popc(mYn);
+    const bool hXo = cX > 0, hYo = cY > 0, hXn = cXn > 0, hYn = cYn > 0;
+    {   // S3: day counts (value index = count - 1)
+        const u64 b = sched_replace_values<u64>(T.tot_b, hXo, cX - 1, hYo, cY - 1, hXn, cXn - 1, hYn, cYn - 1);
+        soft += (63 - __clzll((long long)b)) - (__ffsll((long long)b) - 1);
+    }
+    {   // S4: weekend-day counts of the employees present
+        const M wk = T.weekend;
+        const unsigned b = sched_replace_values<unsigned>(T.wk_b, hXo, O::popc(mX & wk), hYo, O::popc(mY & wk), hXn,
+                                                          O::popc(mXn & wk), hYn, O::popc(mYn & wk));
+        soft += (31 - __clz((int)b)) - (__ffs((int)b) - 1);
+    }
+    // S2: the weekday groups of the edited days
+    const M G1 = T.wd[p1], G2 = swap ? T.wd[p2] : 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const M G = i == 0 ? G1 : G2;
+        if (G == 0 || (i == 1 && G == G1)) continue;
+        const int r = (i == 0 ? p1 : p2) % 7;
+        const int a = O::popc(mX & G), b = O::popc(mY & G), an = O::popc(mXn & G), bn = O::popc(mYn & G);
+        const unsigned bits = sched_replace_values<unsigned>(T.grp_b[r], a > 0, a - 1, b > 0, b - 1, an > 0, an - 1,
+                                                             bn > 0, bn - 1);
+        const int mn = __ffs((int)bits);
+        soft += (mn < T.grp_size[r] ? mn : 0) - T.grp_v[r];
+    }
+    hard_out = hard;
+    soft_out = soft;
+}
+
+// one candidate of a delta kernel: its edit, and whether it is a real (well-formed, non-tabu) candidate.
+// Needs only the wavefront's copy of the state (e_lane: lane d holds day d), not the table.
+struct SchedEdit {
+    bool active;
+    bool swap;
+    int p1, p2, ea, eb, new1, new2;
+};
+
+__device__ __forceinline__ SchedEdit sched_edit_of(int e_lane, int S, int E, int type, int ma, int mb)
+{
+    SchedEdit ed;
+    const bool ok = sched_move_ok(type, ma, mb, S, E);
+    ed.swap = type == 1;
+    ed.p1 = ok ? ma : 0;
+    ed.p2 = (ok && type == 1) ? mb : ed.p1;
+    ed.ea = __shfl(e_lane, ed.p1, 64);
+    ed.eb = __shfl(e_lane, ed.p2, 64);
+    // ChangeDay: day a <- employee b (lib.rs:466-470);  SwapDays: a <- e[b], b <- e[a] (:471-478)
+    ed.new1 = type == 0 ? mb : ed.eb;
+    ed.new2 = type == 0 ? mb : ed.ea;
+    ed.active = ok && !(ed.new1 == ed.ea && ed.new2 == ed.eb); // candidate != current (tabu, local_search.rs:319)
+    return ed;
+}
+
+// holiday bits of the edited days under their new employees: a gather from global memory that depends on the move
+// and the state only, so it is issued before the block waits for the table
+__device__ __forceinline__ int sched_edit_hbits(const SchedInst &in, const SchedEdit &ed)
+{
+    if (!ed.active) return 0;
+    return sched_holiday_bit(in, ed.new1, ed.p1) | (sched_holiday_bit(in, ed.new2, ed.p2) << 1);
+}
+
+// the argmin key of an active candidate (and its scores)
+template <typename M>
+__device__ __forceinline__ u64 sched_delta_key(const SchedBaseTab<M> &T, int D, int e_lane, const SchedEdit &ed, int hbits, int &hard,
+                                               int &soft)
+{
+    u64 e1, e2 = (u64)1 << 21; // "no second edit" sorts between lowering and raising edits
+    if (!ed.swap) e1 = sc_edit_key(ed.p1, ed.new1, ed.ea);
+    else {
+        const bool a_first = ed.p1 < ed.p2;
+        e1 = a_first ? sc_edit_key(ed.p1, ed.new1, ed.ea) : sc_edit_key(ed.p2, ed.new2, ed.eb);
+        e2 = a_first ? sc_edit_key(ed.p2, ed.new2, ed.eb) : sc_edit_key(ed.p1, ed.new1, ed.ea);
+    }
+    sched_delta_score<M>(T, e_lane, D, ed.swap, ed.p1, ed.p2, ed.new1, hbits, hard, soft);
+    return ((u64)(unsigned)hard << 54) | ((u64)(unsigned)soft << 46) | (e1 << 23) | e2;
+}
+
+// candidate k of the exhaustive ScheduleMoveProposer (lib.rs:493-559), generated in place: day d = k / E,
+// employee (state[d] + 1 + i) mod E for i = k mod E (the day's current employee last)
+__device__ __forceinline__ void sched_gen_exhaustive(int e_lane, int E, long long k, int &type, int &ma, int &mb)
+{
+    const unsigned d = (unsigned)k / (unsigned)E, i = (unsigned)k - d * (unsigned)E;
+    type = 0;
+    ma = (int)d;
+    mb = (int)(((unsigned)__shfl(e_lane, (int)(d & 63), 64) + 1u + i) % (unsigned)E);
+}
+
+__device__ __forceinline__ void sched_min_key(u64 &bk, long long &bi, u64 ok, long long oi)
+{
+    if (ok < bk || (ok == bk && ok != SC_KEY_EMPTY && oi < bi)) { bk = ok; bi = oi; }
+}
+
+// every lane ends up with the wavefront's minimum (key, index), first index of equal keys: two DPP reductions
+__device__ __forceinline__ void sched_wave_min_key(u64 &best_key, long long &best_idx)
+{
+    const u64 mk = wave_min_u64(best_key);
+    const u64 mi = wave_min_u64(best_key == mk ? (u64)best_idx : ~0ull);
+    best_key = mk;
+    best_idx = mk == SC_KEY_EMPTY ? -1 : (long long)mi;
+}
+
+// block minimum: every wavefront's minimum goes through LDS, wavefront 0 reduces the NW records in its lanes
+// (one LDS read per lane instead of a serial walk by one thread); valid in wavefront 0 afterwards
+template <int NW>
+__device__ __forceinline__ void sched_block_min_key(u64 &key, long long &idx, u64 *s_key, long long *s_idx, int lane, int wib)
+{
+    sched_wave_min_key(key, idx);
+    if (lane == 0) { s_key[wib] = key; s_idx[wib] = idx; }
+    __syncthreads();
+    if (wib == 0) {
+        key = lane < NW ? s_key[lane] : SC_KEY_EMPTY;
+        idx = lane < NW ? s_idx[lane] : -1;
+        sched_wave_min_key(key, idx);
+    }
+}
+
+// Pass 2 after count + locate (per-candidate score dumps), or the whole pipeline in one block per restart (FUSED:
+// move lists of <= 64 * NW entries -- the reference example's window-100 iteration).
+template <typename M, int NW, bool FUSED>
+__global__ __launch_bounds__(64 * NW) void sched_eval_delta_kernel(SchedEvalArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = FUSED ? (int)blockIdx.x : (int)(blockIdx.x % a.n_restarts);
+    const int wave = FUSED ? wib : (int)(blockIdx.x / a.n_restarts) * NW + wib;
+    const int n_waves = FUSED ? NW : (int)(gridDim.x / a.n_restarts) * NW;
+    const int S = a.in.S, D = a.in.D, E = a.in.n_employees;
+    __shared__ SchedFusedShared<FUSED> s_fused;
+    __shared__ SchedBaseTab<M> T;
+    __shared__ u64 s_key[NW];
+    __shared__ long long s_idx[NW];
+    LS_SC_STAMP(0);
+    SchedLaneConst L{};
+    if (wib < 3) L = a.in.lane_tab[lane];
+    long long k_end, n_scored_f = 0;
+    if constexpr (FUSED) sched_locate_in_block<NW>(a, r, s_fused, k_end, n_scored_f); // synchronises the block
+    else k_end = a.k_end[r];
+    const int e_lane = lane < S ? (FUSED ? s_fused.state[lane] : sched_state_at(a, r, lane)) : -1 - lane;
+    const int hol_base = wib == 0 ? sched_holiday_bit(a.in, e_lane, lane) : 0; // in flight until the table build needs it
+    const long long n_batches = (k_end + 63) >> 6;
+    const ls_sched_move *mv = a.moves + (long long)r * a.max_moves;
+    // the first batch's moves, edits and holiday gathers are in flight while wavefront 0 tabulates the base state
+    long long batch = wave;
+    int type = -1, ma = 0, mb = 0;
+    {
+        const long long k = (batch << 6) + lane;
+        if (k < k_end) { const ls_sched_move m = FUSED ? s_fused.moves[FUSED ? k : 0] : mv[k]; type = m.type; ma = m.a; mb = m.b; }
+    }
+    LS_SC_STAMP(1);
+    SchedEdit ed = sched_edit_of(e_lane, S, E, type, ma, mb);
+    int hbits = sched_edit_hbits(a.in, ed);
+    LS_SC_STAMP(2);
+    if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T);
+    LS_SC_STAMP(3);
+    __syncthreads();
+    LS_SC_STAMP(4);
+    u64 best_key = SC_KEY_EMPTY;
+    long long best_idx = -1;
+    while (batch < n_batches) {
+        const long long k = (batch << 6) + lane;
+        if (ed.active) {
+            int hard, soft;
+            const u64 key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft);
+            if (key < best_key) { best_key = key; best_idx = k; } // ascending k per lane: first of equals kept
+            if (a.hard_out) a.hard_out[(long long)r * a.max_moves + k] = hard;
+            if (a.soft_out) a.soft_out[(long long)r * a.max_moves + k] = soft;
+        }
+        batch += n_waves;
+        if (batch < n_batches) {
+            const long long k2 = (batch << 6) + lane;
+            type = -1;
+            if (k2 < k_end) { const ls_sched_move m = FUSED ? s_fused.moves[FUSED ? k2 : 0] : mv[k2]; type = m.type; ma = m.a; mb = m.b; }
+            ed = sched_edit_of(e_lane, S, E, type, ma, mb);
+            hbits = sched_edit_hbits(a.in, ed);
+        }
+    }
+    LS_SC_STAMP(5);
+    sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib);
+    LS_SC_STAMP(6);
+    if (threadIdx.x == 0) {
+        if (FUSED) {
+            sched_write_result_n(a, r, best_key, best_idx, n_scored_f);
+            LS_SC_STAMP(7);
+        } else if (a.blocks_per_restart == 1) {
+            sched_write_result(a, r, best_key, best_idx);
+        } else {
+            const long long slot = (long long)r * a.blocks_per_restart + blockIdx.x / a.n_restarts;
+            a.part_key[slot] = best_key;
+            a.part_idx[slot] = best_idx;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The production pipeline for move lists beyond one block (no per-candidate score dump): TWO launches.
+//   sched_eval_all_kernel   every chunk of a.chunk_moves moves is scored by one block, which records each
+//                           candidate's key, the chunk's number of real (non-tabu) candidates and its minimum
+//                           (key, index) -- where the window ends is not known yet, and scoring a candidate costs
+//                           little more than testing it;
+//   sched_finish_kernel     one block per restart: a prefix scan over the chunk counts finds the chunk in which
+//                           take(window) stops (local_search.rs:319-321); chunks before it contribute their minima,
+//                           the cut chunk its recorded keys up to the window, and the block writes the result.
+// GEN: the candidates are those of the exhaustive proposer, generated in place (no move list in memory).
+template <typename M, int NW, bool GEN>
+__global__ __launch_bounds__(64 * NW) void sched_eval_all_kernel(SchedEvalArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = (int)(blockIdx.x % a.n_restarts), c = (int)(blockIdx.x / a.n_restarts);
+    const int S = a.in.S, D = a.in.D, E = a.in.n_employees;
+    __shared__ SchedBaseTab<M> T;
+    __shared__ u64 s_key[NW];
+    __shared__ long long s_idx[NW];
+    __shared__ int s_cnt[NW];
+    LS_SC_STAMP(0);
+    SchedLaneConst L{};
+    if (wib < 3) L = a.in.lane_tab[lane];
+    const int e_lane = lane < S ? sched_state_at(a, r, lane) : -1 - lane;
+    const int hol_base = wib == 0 ? sched_holiday_bit(a.in, e_lane, lane) : 0; // in flight until the table build needs it
+    const long long nm = GEN ? a.max_moves : sched_nm(a, r);
+    const long long c0 = (long long)c * a.chunk_moves;
+    const long long c1 = c0 + a.chunk_moves < nm ? c0 + a.chunk_moves : nm;
+    const ls_sched_move *mv = GEN ? nullptr : a.moves + (long long)r * a.max_moves;
+    u64 *keys = a.cand_keys + (long long)r * a.max_moves;
+    // the first batch's moves, edits and holiday gathers are in flight while wavefront 0 tabulates the base state
+    long long base = c0 + wib * 64;
+    int type = -1, ma = 0, mb = 0;
+    if constexpr (GEN) {
+        sched_gen_exhaustive(e_lane, E, base + lane, type, ma, mb); // every lane takes part in the shuffle
+        if (base + lane >= c1) type = -1;
+    } else if (base + lane < c1) { const ls_sched_move m = mv[base + lane]; type = m.type; ma = m.a; mb = m.b; }
+    SchedEdit ed = sched_edit_of(e_lane, S, E, type, ma, mb);
+    LS_SC_STAMP(1);
+    int hbits = sched_edit_hbits(a.in, ed);
+    LS_SC_STAMP(2);
+    if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T);
+    LS_SC_STAMP(3);
+    __syncthreads();
+    LS_SC_STAMP(4);
+    u64 best_key = SC_KEY_EMPTY;
+    long long best_idx = -1;
+    int cnt = 0;
+    u64 last_key = SC_KEY_EMPTY;
+    long long last_k = c1;
+    while (base < c1) {
+        const long long k = base + lane;
+        u64 key = SC_KEY_EMPTY;
+        if (ed.active) {
+            int hard, soft;
+            key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft);
+            if (key < best_key) { best_key = key; best_idx = k; }
+            cnt++;
+        }
+        base += 64 * NW;
+        if (base >= c1) { last_key = key; last_k = k; break; } // stored after the block's record: the barrier below would wait for it
+        if (k < c1) keys[k] = key;
+        {
+            type = -1;
+            if constexpr (GEN) {
+                sched_gen_exhaustive(e_lane, E, base + lane, type, ma, mb);
+                if (base + lane >= c1) type = -1;
+            } else if (base + lane < c1) { const ls_sched_move m = mv[base + lane]; type = m.type; ma = m.a; mb = m.b; }
+            ed = sched_edit_of(e_lane, S, E, type, ma, mb);
+            hbits = sched_edit_hbits(a.in, ed);
+        }
+    }
+    LS_SC_STAMP(5);
+    cnt = wave_sum_i32(cnt);
+    if (lane == 0) s_cnt[wib] = cnt;
+    sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib); // synchronises the block
+    if (wib == 0) cnt = wave_sum_i32(lane < NW ? s_cnt[lane] : 0);
+    if (threadIdx.x == 0) {
+        const long long slot = (long long)r * a.n_chunks + c;
+        a.part_key[slot] = best_key;
+        a.part_idx[slot] = best_idx;
+        a.chunk_counts[slot] = cnt;
+    }
+    if (last_k < c1) keys[last_k] = last_key;
+    LS_SC_STAMP(6);
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void sched_finish_kernel(SchedEvalArgs a, bool gen)
+{
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = (int)blockIdx.x;
+    __shared__ u64 s_key[NW];
+    __shared__ long long s_idx[NW];
+    __shared__ int s_wcnt[NW];
+    __shared__ int s_cut;
+    __shared__ long long s_before;
+    const int nch = a.n_chunks;
+    const int *counts = a.chunk_counts + (long long)r * nch;
+    const u64 *pk = a.part_key + (long long)r * nch;
+    const long long *pi = a.part_idx + (long long)r * nch;
+    if (threadIdx.x == 0) { s_cut = -1; s_before = 0; }
+    __syncthreads();
+    u64 best_key = SC_KEY_EMPTY;
+    long long best_idx = -1;
+    long long run = 0; // real candidates in the chunks seen so far
+    if (a.window > 0) {
+        for (int t0 = 0; t0 < nch; t0 += 64 * NW) {
+            const int b = t0 + (int)threadIdx.x;
+            const int cb = b < nch ? counts[b] : 0;
+            int incl = cb;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            if (lane == 63) s_wcnt[wib] = incl;
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int i = 0; i < NW; i++) {
+                if (i < wib) before += s_wcnt[i];
+                total += s_wcnt[i];
+            }
+            const long long through = run + before + incl; // real candidates up to and including chunk b
+            if (b < nch) {
+                if (through <= a.window) sched_min_key(best_key, best_idx, pk[b], pi[b]); // the whole chunk is inside the window
+                else if (through - cb < a.window) { s_cut = b; s_before = through - cb; }  // the window ends inside this chunk
+            }
+            __syncthreads();
+            run += total;
+            if (run >= a.window) break;
+        }
+    }
+    const long long n_scored = a.window <= 0 ? 0 : (run < a.window ? run : a.window);
+    const int cut = s_cut;
+    if (cut >= 0) { // the cut chunk: its recorded keys, up to the window
+        const long long need = a.window - s_before; // 1 <= need < real candidates of the chunk
+        const long long nm = gen ? a.max_moves : sched_nm(a, r);
+        const long long c0 = (long long)cut * a.chunk_moves;
+        const long long c1 = c0 + a.chunk_moves < nm ? c0 + a.chunk_moves : nm;
+        const u64 *keys = a.cand_keys + (long long)r * a.max_moves;
+        long long taken = 0;
+        for (long long base = c0; base < c1 && taken < need; base += 64 * NW) {
+            const long long k = base + threadIdx.x;
+            const u64 key = k < c1 ? keys[k] : SC_KEY_EMPTY;
+            const u64 bal = __ballot(key != SC_KEY_EMPTY);
+            __syncthreads(); // s_wcnt is reused
+            if (lane == 0) s_wcnt[wib] = __popcll(bal);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int i = 0; i < NW; i++) {
+                if (i < wib) before += s_wcnt[i];
+                total += s_wcnt[i];
+            }
+            const long long rank = taken + before + __popcll(bal & ((2ull << lane) - 1)); // 1-based among the real candidates
+            if (key != SC_KEY_EMPTY && rank <= need && key < best_key) { best_key = key; best_idx = k; }
+            taken += total;
+        }
+    }
+    sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib);
+    if (threadIdx.x == 0) sched_write_result_n(a, r, best_key, best_idx, n_scored);
+}
+
 // Pass 3: minimum (key, index) over the per-block minima of pass 2.
 __global__ __launch_bounds__(256) void sched_reduce_kernel(SchedEvalArgs a)
 {
@@ -858,10 +1474,83 @@ bool sched_is_fused_launch(const ls_ctx *ctx, long long max_moves)
     return n_chunks == 1 && batches * 4 <= 2 * SC_FUSED_WAVES && ctx->sched_fused;
 }
 
+// the two-launch delta pipeline (sched_eval_all_kernel + sched_finish_kernel); a holds everything but the workspace
+static int sched_launch_delta_pipeline(ls_ctx *ctx, SchedEvalArgs a, bool gen)
+{
+    constexpr int DW = 8;
+    static const int bpw = getenv("LS_SCHED_DELTA_BPW") ? atoi(getenv("LS_SCHED_DELTA_BPW")) : 1; // batches per wavefront: measurement knob
+    a.chunk_moves = 64LL * DW * (bpw < 1 ? 1 : bpw);
+    const long long nch = a.max_moves > 0 ? (a.max_moves + a.chunk_moves - 1) / a.chunk_moves : 1;
+    if (nch * a.n_restarts > 0x7fffffffLL) return set_err(ctx, LS_ERR_UNSUPPORTED, "max_moves = %lld is too large", a.max_moves);
+    const size_t parts = (size_t)a.n_restarts * (size_t)nch;
+    LS_RESERVE(ctx, ctx->sc_keys, parts * 20);
+    LS_RESERVE(ctx, ctx->sc_cand_keys, (size_t)a.n_restarts * (size_t)(a.max_moves > 0 ? a.max_moves : 1) * 8);
+    a.n_chunks = (int)nch;
+    a.blocks_per_restart = (int)nch;
+    a.split = 1;
+    a.part_key = ctx->sc_keys.as<u64>();
+    a.part_idx = reinterpret_cast<long long *>(a.part_key + parts);
+    a.chunk_counts = reinterpret_cast<int *>(a.part_idx + parts);
+    a.cand_keys = ctx->sc_cand_keys.as<u64>();
+    a.k_end = nullptr;
+    a.n_scored = nullptr;
+    const bool m32 = ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64;
+    const dim3 g1((unsigned)(nch * a.n_restarts)), g2((unsigned)a.n_restarts), b(64 * DW);
+#define LS_LAUNCH2(MT, GEN)                                                                             \
+    {                                                                                                   \
+        hipLaunchKernelGGL((sched_eval_all_kernel<MT, DW, GEN>), g1, b, 0, ctx->stream, a);             \
+        LS_HIP(ctx, hipGetLastError());                                                                 \
+    }
+    if (m32) { if (gen) LS_LAUNCH2(unsigned, true) else LS_LAUNCH2(unsigned, false) }
+    else { if (gen) LS_LAUNCH2(u64, true) else LS_LAUNCH2(u64, false) }
+    hipLaunchKernelGGL((sched_finish_kernel<DW>), g2, b, 0, ctx->stream, a, gen);
+    LS_HIP(ctx, hipGetLastError());
+#undef LS_LAUNCH2
+    return LS_OK;
+}
+
+// the exhaustive proposer's neighbourhood (lib.rs:493-559) of n_restarts states, candidates generated in place
+static void sched_set_inline(const ls_ctx *ctx, SchedEvalArgs &a, const int *inline_state_h, long long inline_n_moves)
+{
+    a.inline_valid = 0;
+    a.inline_n_moves = 0;
+    if (inline_state_h && a.n_restarts == 1) { // one restart: the state (<= 256 bytes) and n_moves travel in the kernel arguments
+        a.inline_valid = 1;
+        a.inline_n_moves = inline_n_moves;
+        for (int d = 0; d < 64; d++) a.inline_state[d] = d < ctx->sched.n_days_stored ? inline_state_h[d] : 0;
+    }
+}
+
+int sched_eval_exhaustive_dev(ls_ctx *ctx, int n_restarts, const int *states_d, long long window, ls_sched_result *results_d,
+                              bool *handled, unsigned long long *done_flag, unsigned long long done_seq, const int *inline_state_h)
+{
+    *handled = false;
+    if (!ctx->sched_delta) return LS_OK; // the caller builds the move list and runs the list pipeline
+    if (ctx->sched.n_employees > 32768)
+        return set_err(ctx, LS_ERR_UNSUPPORTED, "n_employees = %d exceeds the 15-bit argmin key field (32768)",
+                       ctx->sched.n_employees);
+    SchedEvalArgs a{};
+    a.in = make_inst(ctx);
+    a.n_restarts = n_restarts;
+    a.states = states_d;
+    a.moves = nullptr;
+    a.n_moves = nullptr;
+    a.max_moves = (long long)ctx->sched.n_days_stored * ctx->sched.n_employees;
+    a.window = window;
+    a.hard_out = a.soft_out = nullptr;
+    a.results = results_d;
+    a.done_flag = n_restarts == 1 ? done_flag : nullptr;
+    a.done_seq = done_seq;
+    sched_set_inline(ctx, a, inline_state_h, a.max_moves);
+    *handled = true;
+    return sched_launch_delta_pipeline(ctx, a, true);
+}
+
 int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const ls_sched_move *moves_d,
                          const long long *n_moves_d, long long max_moves, long long window,
                          ls_sched_result *results_d, long long *hard_out_d, long long *soft_out_d,
-                         unsigned long long *done_flag, unsigned long long done_seq)
+                         unsigned long long *done_flag, unsigned long long done_seq, const int *inline_state_h,
+                         long long inline_n_moves)
 {
     if (ctx->sched.n_employees > 32768)
         return set_err(ctx, LS_ERR_UNSUPPORTED, "n_employees = %d exceeds the 15-bit argmin key field (32768)",
@@ -871,8 +1560,13 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
         return set_err(ctx, LS_ERR_UNSUPPORTED, "max_moves = %lld is too large", max_moves);
     // one wavefront per batch of 64 candidates, never more blocks than the chip holds at once
     const long long batches = max_moves > 0 ? (max_moves + 63) / 64 : 1;
-    const int split = batches * n_restarts >= 4096 ? 1 : 4; // few batches: spread each over four wavefronts
-    long long bpr = (batches * split + 3) / 4;
+    const bool delta = ctx->sched_delta;
+    const bool m32 = ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64;
+    constexpr int DW = 8; // wavefronts per block of the delta kernel
+    const int split = delta ? 1 : (batches * n_restarts >= 4096 ? 1 : 4); // few batches: spread each over four wavefronts
+    static const int delta_batches_per_wave = getenv("LS_SCHED_DELTA_BPW") ? atoi(getenv("LS_SCHED_DELTA_BPW")) : 1; // measurement knob
+    long long bpr = delta ? (batches + (long long)DW * delta_batches_per_wave - 1) / ((long long)DW * delta_batches_per_wave)
+                          : (batches * split + 3) / 4;
     static const int blocks_per_cu = getenv("LS_SCHED_BLOCKS_PER_CU") ? atoi(getenv("LS_SCHED_BLOCKS_PER_CU")) : 8; // measurement knob
     const long long cap = ((long long)ctx->n_cus * blocks_per_cu) / n_restarts;
     if (bpr > cap) bpr = cap;
@@ -897,6 +1591,11 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
     a.results = results_d;
     a.done_flag = n_restarts == 1 ? done_flag : nullptr; // exactly one thread of one kernel writes the record of a one-restart launch
     a.done_seq = done_seq;
+    a.cand_keys = nullptr;
+    a.chunk_moves = 0;
+    sched_set_inline(ctx, a, inline_state_h, inline_n_moves);
+    if (delta && !hard_out_d && !soft_out_d && !(n_chunks == 1 && batches * 4 <= 2 * SC_FUSED_WAVES && ctx->sched_fused))
+        return sched_launch_delta_pipeline(ctx, a, false);
     const long long total = (long long)n_restarts * max_moves;
     const unsigned fill_grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (hard_out_d && total > 0) {
@@ -911,7 +1610,10 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
         // small launch (the reference's example: window 100): locate + eval + reduce in one block per restart
         a.split = 4;
         a.blocks_per_restart = 1;
-        if (ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64)
+        if (delta) {
+            if (m32) hipLaunchKernelGGL((sched_eval_delta_kernel<unsigned, DW, true>), dim3(n_restarts), dim3(64 * DW), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((sched_eval_delta_kernel<u64, DW, true>), dim3(n_restarts), dim3(64 * DW), 0, ctx->stream, a);
+        } else if (ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64)
             hipLaunchKernelGGL((sched_eval32_kernel<SC_FUSED_WAVES, true>), dim3(n_restarts), dim3(64 * SC_FUSED_WAVES), 0, ctx->stream, a);
         else
             hipLaunchKernelGGL((sched_eval_kernel<SC_FUSED_WAVES, true>), dim3(n_restarts), dim3(64 * SC_FUSED_WAVES), 0, ctx->stream, a);
@@ -924,7 +1626,10 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
     }
     hipLaunchKernelGGL(sched_locate_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a);
     LS_HIP(ctx, hipGetLastError());
-    if (ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64)
+    if (delta) {
+        if (m32) hipLaunchKernelGGL((sched_eval_delta_kernel<unsigned, DW, false>), dim3((unsigned)(bpr * n_restarts)), dim3(64 * DW), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((sched_eval_delta_kernel<u64, DW, false>), dim3((unsigned)(bpr * n_restarts)), dim3(64 * DW), 0, ctx->stream, a);
+    } else if (ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64)
         hipLaunchKernelGGL((sched_eval32_kernel<4, false>), dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
     else
         hipLaunchKernelGGL((sched_eval_kernel<4, false>), dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
@@ -937,3 +1642,10 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
 }
 
 } // namespace lsamd
+
+#ifdef LS_NQ_STAMPS
+extern "C" int ls_debug_sched_stamps(unsigned long long *out, int count)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lsamd::g_sc_stamps), (size_t)count * 8);
+}
+#endif

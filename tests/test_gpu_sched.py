@@ -15,10 +15,19 @@ import oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+# every test runs on the default DELTA scorer (one lane per candidate) and on the wavefront-per-candidate kernels
+@pytest.fixture(scope="module", params=["delta", "wavefront"])
+def ctx(request):
     import ls_amd
-    c = ls_amd.Context(0)
+    old = os.environ.get("LS_SCHED_DELTA")
+    os.environ["LS_SCHED_DELTA"] = "1" if request.param == "delta" else "0"
+    try:
+        c = ls_amd.Context(0)   # the knob is read when the context is created
+    finally:
+        if old is None:
+            del os.environ["LS_SCHED_DELTA"]
+        else:
+            os.environ["LS_SCHED_DELTA"] = old
     yield c
     c.close()
 
@@ -185,13 +194,15 @@ def test_resident_move_list_matches_host_list(ctx):
         ctx.sched_eval_resident(state, 901, 10)
 
 
+@pytest.mark.parametrize("delta", ["1", "0"])
 @pytest.mark.parametrize("fused,zero_copy", [("1", "1"), ("1", "0"), ("0", "1")])
-def test_small_launch_fused_kernel(monkeypatch, fused, zero_copy):
+def test_small_launch_fused_kernel(monkeypatch, fused, zero_copy, delta):
     # move lists of <= 512 entries run locate + eval + reduce as ONE block per restart (LS_SCHED_FUSED, default on);
     # the resident entry hands the kernels the pinned staging blocks directly (LS_SCHED_ZEROCOPY, default on)
     import ls_amd
     monkeypatch.setenv("LS_SCHED_FUSED", fused)
     monkeypatch.setenv("LS_SCHED_ZEROCOPY", zero_copy)
+    monkeypatch.setenv("LS_SCHED_DELTA", delta)
     rng = np.random.default_rng(40 + int(fused) * 2 + int(zero_copy))
     with ls_amd.Context(0) as c:
         for start, end, n_emp in (((2022, 5, 9), (2022, 6, 8), 7),      # half-wavefront kernel (32 stored days)
@@ -332,3 +343,34 @@ def test_skip_moves_for_a_general_tabu_set(ctx):
             assert (got["n_scored"], got["best_index"]) == (exp["n_scored"], exp["best_index"]), (trial, window)
             assert (got["best_hard"], got["best_soft"]) == (exp["best_hard"], exp["best_soft"])
             assert np.array_equal(hard, exp["hard"]) and np.array_equal(soft, exp["soft"])
+
+
+@pytest.mark.parametrize("days,n_emp", [(31, 7), (31, 2), (63, 5)])
+def test_window_cuts_of_the_two_launch_pipeline(ctx, days, n_emp):
+    # production shape (no score dump), move lists beyond one block: sched_eval_all_kernel scores 512-move chunks,
+    # sched_finish_kernel finds the chunk in which take(window) stops and re-scores it up to the window.  Windows
+    # are placed on, just before and just after every chunk's cumulative count of real candidates.
+    start = (2022, 5, 9)
+    end_d = dt.date(*start) + dt.timedelta(days=days - 1)
+    rng = np.random.default_rng(days * 100 + n_emp)
+    inst, D, S = _upload(ctx, start, (end_d.year, end_d.month, end_d.day), n_emp, {0: [0, 3], 1: [5]})
+    R, max_moves = 3, 1700
+    states = rng.integers(0, n_emp, size=(R, S))
+    moves = np.stack([_random_moves(rng, max_moves, D, n_emp, states[r]) for r in range(R)])
+    n_moves = np.array([1700, 1025, 513])
+    full = [inst.neighbourhood(states[r], moves[r, :n_moves[r]], 10 ** 9) for r in range(R)]
+    real = [(full[r]["hard"] != orc.SKIPPED) for r in range(R)]
+    windows = {0, 1, 2, 10 ** 9}
+    for r in range(R):
+        cum = np.cumsum(real[r])
+        for edge in range(512, n_moves[r] + 512, 512):
+            c = int(cum[min(edge, n_moves[r]) - 1])
+            windows.update({c - 1, c, c + 1})
+        windows.update({int(cum[-1]) - 1, int(cum[-1]), int(cum[-1]) + 1})
+    for window in sorted(w for w in windows if w >= 0):
+        out, _, _ = ctx.sched_eval_batch(states, moves, n_moves, window)
+        for r in range(R):
+            exp = inst.neighbourhood(states[r], moves[r, :n_moves[r]], window)
+            assert (out[r]["n_scored"], out[r]["best_index"]) == (exp["n_scored"], exp["best_index"]), (window, r)
+            if exp["best_index"] >= 0:
+                assert (out[r]["best_hard"], out[r]["best_soft"]) == (exp["best_hard"], exp["best_soft"]), (window, r)
