@@ -734,8 +734,8 @@ def sched_measurements(ctx, torch, dev, timed, issue_roofline):
         n_scored = int(res.cpu().numpy()[0, 0])
         out[name] = {"neighbours_per_s": n_scored / s, "us_per_launch": s * 1e6, "candidates_per_launch": n_scored,
                      "effective_GBps_at_144B": n_scored * 144 / s / 1e9,
-                     "roofline_eval_kernel_bound_over_whole_chain_time": issue_roofline("sched_eval32_kernel_exhaustive" if "exhaustive" in name
-                                                                 else "sched_eval32_kernel_random65536", s)}
+                     "roofline_eval_kernel_bound_over_whole_chain_time": issue_roofline("sched_eval_all_kernel_exhaustive_list" if "exhaustive" in name
+                                                                 else "sched_eval_all_kernel_random65536", s)}
     # the same exhaustive neighbourhood through the host entry that generates the move list on the device:
     # only the 128-byte state and the 32-byte result cross PCIe (round trip incl. sync and the Python wrapper)
     ctx.sched_eval_exhaustive(state_np, 10 ** 9)

@@ -63,7 +63,7 @@ static void for_each_buf(ls_ctx *ctx, void (*f)(DevBuf &))
     DevBuf *bufs[] = {&ctx->nq_rows, &ctx->nq_cur, &ctx->nq_cols, &ctx->nq_ncols, &ctx->nq_results,
                       &ctx->nq_scores, &ctx->nq_keys, &ctx->nq_tabs, &ctx->nq_colscores, &ctx->nq_totals, &ctx->nq_next_rows,
                       &ctx->sc_states, &ctx->sc_moves, &ctx->sc_nmoves, &ctx->sc_results, &ctx->sc_hard,
-                      &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sc_cand_keys, &ctx->sched.holiday_bits, &ctx->sched.lane_tab,
+                      &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sc_cand_keys, &ctx->sc_ticket, &ctx->sched.holiday_bits, &ctx->sched.lane_tab,
                       &ctx->sc_resident_moves};
     for (DevBuf *b : bufs) f(*b);
 }
@@ -147,6 +147,7 @@ int ls_ctx_create(int device_id, ls_ctx **out)
     if (const char *v = getenv("LS_SCHED_FUSED")) ctx->sched_fused = atoi(v) != 0;
     ctx->sched_force_64 = getenv("LS_SCHED_FORCE_64") != nullptr;
     if (const char *v = getenv("LS_SCHED_DELTA")) ctx->sched_delta = atoi(v) != 0;
+    if (const char *v = getenv("LS_SCHED_ONE_LAUNCH")) ctx->sched_one_launch = atoi(v) != 0;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->wave_size = prop.warpSize;
     ctx->clock_khz = prop.clockRate;

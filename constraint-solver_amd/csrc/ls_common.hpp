@@ -147,6 +147,8 @@ struct ls_ctx {
     bool sched_zero_copy = true; // ls_sched_eval_resident: kernels work on the pinned staging blocks directly (LS_SCHED_ZEROCOPY)
     bool sched_fused = true;     // small scheduling launches: locate + eval + reduce in one kernel (LS_SCHED_FUSED)
     bool sched_delta = true;     // LS_SCHED_DELTA: lane-per-candidate delta scorer (0: the wavefront-per-candidate kernels)
+    bool sched_one_launch = false; // LS_SCHED_ONE_LAUNCH=1: the last block of the delta pipeline's scoring launch does the finish step itself
+                                   // (measured slower than the second launch: every block pays a barrier + agent-scope release)
     bool sched_force_64 = false; // LS_SCHED_FORCE_64: use the full-wavefront scheduling kernel even for <= 32 days
     int nq_table_variant = 24; // TABLE family (LS_NQ_TABLE_VARIANT): 0 per-range kernel; 1/2/4 column teams of 256 lanes per block;
                                // 11/12/14 the same with two candidates per lane and LDS look-up (even n >= 512); 21/22/24 (default)
@@ -161,7 +163,7 @@ struct ls_ctx {
     // persistent workspaces (grow-only)
     lsamd::DevBuf nq_rows, nq_cur, nq_cols, nq_ncols, nq_results, nq_scores, nq_keys, nq_tabs,
         nq_colscores, nq_totals, nq_next_rows;
-    lsamd::DevBuf sc_states, sc_moves, sc_nmoves, sc_results, sc_hard, sc_soft, sc_keys, sc_terms, sc_cand_keys;
+    lsamd::DevBuf sc_states, sc_moves, sc_nmoves, sc_results, sc_hard, sc_soft, sc_keys, sc_terms, sc_cand_keys, sc_ticket;
     lsamd::SchedInstance sched;
     lsamd::DevBuf sc_resident_moves; // ls_sched_moves_upload
     lsamd::Staging stage_in, stage_out;

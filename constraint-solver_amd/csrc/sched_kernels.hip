@@ -213,6 +213,7 @@ struct SchedEvalArgs {
     ls_sched_result *results;       // written by pass 2 itself when blocks_per_restart == 1
     unsigned long long *done_flag;  // nullable; one-restart launches only: host word <- done_seq after the result record
     unsigned long long done_seq;
+    unsigned *ticket;               // delta pipeline, one launch: [n_restarts] blocks done so far (zero between launches)
     u64 *cand_keys;                 // delta pipeline: [n_restarts][max_moves] argmin key per candidate (SC_KEY_EMPTY: not a candidate)
     // one-restart launches may carry their per-call inputs in the kernel arguments (no copy, no PCIe read):
     int inline_valid;
@@ -1222,6 +1223,10 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_delta_kernel(SchedEvalArgs
 //                           take(window) stops (local_search.rs:319-321); chunks before it contribute their minima,
 //                           the cut chunk its recorded keys up to the window, and the block writes the result.
 // GEN: the candidates are those of the exhaustive proposer, generated in place (no move list in memory).
+template <int NW> struct SchedFinishShared;
+template <int NW>
+__device__ __forceinline__ void sched_finish_block(const SchedEvalArgs &a, bool gen, int r, SchedFinishShared<NW> &sh);
+
 template <typename M, int NW, bool GEN>
 __global__ __launch_bounds__(64 * NW) void sched_eval_all_kernel(SchedEvalArgs a)
 {
@@ -1298,19 +1303,45 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_all_kernel(SchedEvalArgs a
     }
     if (last_k < c1) keys[last_k] = last_key;
     LS_SC_STAMP(6);
+    if (a.ticket) {
+        // ONE launch: the block that finishes last (a ticket per restart) does the finish step itself.  Release: the
+        // barrier waits for every wavefront's stores, thread 0's agent-scope fence writes them back before the ticket.
+        __shared__ SchedFinishShared<NW> s_fin;
+        __shared__ int s_last;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(a.ticket + r, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = t == (unsigned)a.n_chunks - 1;
+            if (s_last) a.ticket[r] = 0; // for the next launch
+        }
+        __syncthreads();
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            sched_finish_block<NW>(a, GEN, r, s_fin);
+        }
+        LS_SC_STAMP(7);
+    }
 }
 
+template <int NW> struct SchedFinishShared {
+    u64 key[NW];
+    long long idx[NW];
+    int wcnt[NW];
+    int cut;
+    long long before;
+};
+
+// the finish step of restart r by one block of NW wavefronts (see above)
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void sched_finish_kernel(SchedEvalArgs a, bool gen)
+__device__ __forceinline__ void sched_finish_block(const SchedEvalArgs &a, bool gen, int r, SchedFinishShared<NW> &sh)
 {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = (int)blockIdx.x;
-    __shared__ u64 s_key[NW];
-    __shared__ long long s_idx[NW];
-    __shared__ int s_wcnt[NW];
-    __shared__ int s_cut;
-    __shared__ long long s_before;
+    u64 *s_key = sh.key;
+    long long *s_idx = sh.idx;
+    int *s_wcnt = sh.wcnt;
+    int &s_cut = sh.cut;
+    long long &s_before = sh.before;
     const int nch = a.n_chunks;
     const int *counts = a.chunk_counts + (long long)r * nch;
     const u64 *pk = a.part_key + (long long)r * nch;
@@ -1375,6 +1406,13 @@ __global__ __launch_bounds__(64 * NW) void sched_finish_kernel(SchedEvalArgs a, 
     }
     sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib);
     if (threadIdx.x == 0) sched_write_result_n(a, r, best_key, best_idx, n_scored);
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void sched_finish_kernel(SchedEvalArgs a, bool gen)
+{
+    __shared__ SchedFinishShared<NW> sh;
+    sched_finish_block<NW>(a, gen, (int)blockIdx.x, sh);
 }
 
 // Pass 3: minimum (key, index) over the per-block minima of pass 2.
@@ -1501,10 +1539,25 @@ static int sched_launch_delta_pipeline(ls_ctx *ctx, SchedEvalArgs a, bool gen)
         hipLaunchKernelGGL((sched_eval_all_kernel<MT, DW, GEN>), g1, b, 0, ctx->stream, a);             \
         LS_HIP(ctx, hipGetLastError());                                                                 \
     }
+    const bool one_launch = ctx->sched_one_launch;
+    a.ticket = nullptr;
+    if (one_launch) {
+        const size_t before = ctx->sc_ticket.cap;
+        LS_RESERVE(ctx, ctx->sc_ticket, (size_t)a.n_restarts * 4);
+        if (ctx->sc_ticket.cap != before) { // a fresh buffer: zero it in stream order; every launch leaves it zero again
+            const long long words = (long long)(ctx->sc_ticket.cap / 4);
+            hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->sc_ticket.as<int>(), 0, words);
+            LS_HIP(ctx, hipGetLastError());
+        }
+        a.ticket = ctx->sc_ticket.as<unsigned>();
+    }
     if (m32) { if (gen) LS_LAUNCH2(unsigned, true) else LS_LAUNCH2(unsigned, false) }
     else { if (gen) LS_LAUNCH2(u64, true) else LS_LAUNCH2(u64, false) }
-    hipLaunchKernelGGL((sched_finish_kernel<DW>), g2, b, 0, ctx->stream, a, gen);
-    LS_HIP(ctx, hipGetLastError());
+    if (!one_launch) {
+        hipLaunchKernelGGL((sched_finish_kernel<DW>), g2, b, 0, ctx->stream, a, gen);
+        LS_HIP(ctx, hipGetLastError());
+    }
 #undef LS_LAUNCH2
     return LS_OK;
 }

@@ -15,19 +15,23 @@ import oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-# every test runs on the default DELTA scorer (one lane per candidate) and on the wavefront-per-candidate kernels
-@pytest.fixture(scope="module", params=["delta", "wavefront"])
+# every test runs on the default DELTA scorer (one lane per candidate; long move lists in two launches), on its
+# one-launch form (the last block finishes) and on the wavefront-per-candidate kernels
+@pytest.fixture(scope="module", params=["delta", "delta-one-launch", "wavefront"])
 def ctx(request):
     import ls_amd
-    old = os.environ.get("LS_SCHED_DELTA")
-    os.environ["LS_SCHED_DELTA"] = "1" if request.param == "delta" else "0"
+    knobs = {"LS_SCHED_DELTA": "0" if request.param == "wavefront" else "1",
+             "LS_SCHED_ONE_LAUNCH": "1" if request.param == "delta-one-launch" else "0"}
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
     try:
-        c = ls_amd.Context(0)   # the knob is read when the context is created
+        c = ls_amd.Context(0)   # the knobs are read when the context is created
     finally:
-        if old is None:
-            del os.environ["LS_SCHED_DELTA"]
-        else:
-            os.environ["LS_SCHED_DELTA"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     yield c
     c.close()
 

@@ -63,8 +63,17 @@ def main():
         state = rng.integers(0, E, size=(1, S)).astype(np.int32)
         for _ in range(reps):
             r0 = ctx.sched_eval_exhaustive(state, 10 ** 9)[0]
-        meta["sched_eval32_kernel_exhaustive"] = dict(candidates_per_launch=int(r0["n_scored"]), workload="10 000 employees, exhaustive 32 x 10 000",
-                                                      match="sched_eval32_kernel<4, false>", grid_hint="large")
+        blocks_ex = (S * E + 511) // 512
+        meta["sched_eval_all_kernel_exhaustive"] = dict(candidates_per_launch=int(r0["n_scored"]),
+                                                        workload="10 000 employees, exhaustive 32 x 10 000, candidates generated in the kernel",
+                                                        match="sched_eval_all_kernel<unsigned int, 8, true>", grid_blocks=blocks_ex)
+        ex = ctx.sched_exhaustive_moves(state)[0]
+        for _ in range(reps):
+            r2 = ctx.sched_eval(state[0], ex, 10 ** 9)[0]
+        assert r2 == r0, (r2, r0)
+        meta["sched_eval_all_kernel_exhaustive_list"] = dict(candidates_per_launch=int(r2["n_scored"]),
+                                                             workload="10 000 employees, exhaustive 32 x 10 000 as a move list in HBM",
+                                                             match="sched_eval_all_kernel<unsigned int, 8, false>", grid_blocks=blocks_ex)
         mv = np.zeros((70_000, 3), dtype=np.int32)
         for i in range(len(mv)):
             if rng.integers(0, 5) == 0:
@@ -75,8 +84,28 @@ def main():
         ctx.sched_moves_upload(mv)
         for _ in range(reps):
             r1 = ctx.sched_eval_resident(state[0], len(mv), 65_536)
-        meta["sched_eval32_kernel_random65536"] = dict(candidates_per_launch=int(r1["n_scored"]), workload="10 000 employees, random stream, window 65 536",
-                                                       match="sched_eval32_kernel<4, false>", grid_hint="small")
+        # the scoring launch covers the whole resident list (where the window ends is found afterwards)
+        meta["sched_eval_all_kernel_random65536"] = dict(candidates_per_launch=int(r1["n_scored"]), workload="10 000 employees, random stream of 70 000 moves, window 65 536",
+                                                         match="sched_eval_all_kernel<unsigned int, 8, false>", grid_blocks=(len(mv) + 511) // 512)
+        meta["sched_finish_kernel_random65536"] = dict(candidates_per_launch=int(r1["n_scored"]), workload="finish step of the launch above",
+                                                       match="sched_finish_kernel<8>", grid_blocks=1)
+        # config 3: the reference example's LS iteration -- 512 resident moves, window 100, one fused block
+        D3, S3, E3 = 31, 32, 7
+        ctx.sched_instance_upload(D3, S3, 0, E3)
+        mv3 = np.zeros((512, 3), dtype=np.int32)
+        for i in range(len(mv3)):
+            if rng.integers(0, 5) == 0:
+                mv3[i] = (0, rng.integers(0, D3), rng.integers(0, E3))
+            else:
+                a, b = rng.choice(D3, size=2, replace=False)
+                mv3[i] = (1, a, b)
+        ctx.sched_moves_upload(mv3)
+        st3 = rng.integers(0, E3, size=S3).astype(np.int32)
+        for _ in range(reps):
+            r3 = ctx.sched_eval_resident(st3, 512, 100)
+        meta["sched_eval_delta_kernel_fused_window100"] = dict(candidates_per_launch=int(r3["n_scored"]),
+                                                               workload="example instance, 512 resident moves, window 100: one fused block",
+                                                               match="sched_eval_delta_kernel<unsigned int, 8, true>", grid_blocks=1)
     print("PMC_WORKLOADS " + json.dumps(meta))
 
 
