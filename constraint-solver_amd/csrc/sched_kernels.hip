@@ -3,6 +3,11 @@
 // examples/employee-scheduling/src/lib.rs (scorer :261-375, helpers :149-222,
 // moves :464-479 / :526-550).
 //
+// Two families.  The DEFAULT is the delta scorer further down (sched_eval_delta_kernel, sched_eval_all_kernel,
+// sched_finish_kernel: one LANE per candidate, terms as functions of per-employee day sets).  The first half of the
+// file is the wavefront-per-candidate family (LS_SCHED_DELTA=0; ls_sched_score and the count / locate passes of score
+// dumps always use it):
+//
 // One wavefront scores one candidate at a time; lane d holds day d (<= 64 stored days).
 // Every constraint term is a function of the day-equality matrix
 //   eq[d] = bitmask over scored days q with employee(q) == employee(d)
