@@ -378,3 +378,42 @@ def test_window_cuts_of_the_two_launch_pipeline(ctx, days, n_emp):
             assert (out[r]["n_scored"], out[r]["best_index"]) == (exp["n_scored"], exp["best_index"]), (window, r)
             if exp["best_index"] >= 0:
                 assert (out[r]["best_hard"], out[r]["best_soft"]) == (exp["best_hard"], exp["best_soft"]), (window, r)
+
+
+@pytest.mark.parametrize("start,days,stored,n_emp", [
+    ((2022, 5, 9), 1, 2, 3), ((2022, 5, 9), 2, 3, 1), ((2022, 5, 9), 6, 7, 2), ((2022, 5, 9), 7, 8, 3),
+    ((2022, 5, 14), 8, 9, 2), ((2022, 5, 15), 13, 14, 3), ((2022, 5, 9), 14, 15, 4), ((2022, 5, 13), 15, 16, 2),
+    ((2022, 5, 9), 32, 32, 3), ((2022, 5, 10), 32, 33, 5), ((2022, 5, 14), 33, 34, 40), ((2022, 5, 11), 64, 64, 6),
+])
+def test_neighbourhood_odd_shapes(ctx, start, days, stored, n_emp):
+    # short and long date ranges, stored == scored and stored == scored + 1, one employee, more employees than days,
+    # moves that touch the stored-but-unscored last entry: per-candidate scores (score-dump chain), the production
+    # pipelines (fused block / two launches, no dump) and the exhaustive proposer, all against the oracle
+    end_d = dt.date(*start) + dt.timedelta(days=days - 1)
+    rng = np.random.default_rng(days * 1000 + stored * 10 + n_emp)
+    hol = {e: [int(d) for d in range(days) if rng.random() < 0.15] for e in range(min(n_emp, 8))}
+    inst, D, S = _upload(ctx, start, (end_d.year, end_d.month, end_d.day), n_emp, hol, n_stored=stored)
+    assert (D, S) == (days, stored)
+    for trial, n_moves in enumerate((37, 512, 700, 1500)):
+        state = rng.integers(0, n_emp if trial % 2 == 0 else min(n_emp, 2), size=S)
+        mv = np.zeros((n_moves, 3), dtype=np.int64)
+        for i in range(n_moves):
+            if rng.integers(0, 2) == 0 or S < 2:
+                mv[i] = (0, rng.integers(0, S), rng.integers(0, n_emp))        # may edit the unscored entry
+            else:
+                a, b = rng.choice(S, size=2, replace=False)
+                mv[i] = (1, a, b)
+        for window in (10 ** 9, int(rng.integers(1, n_moves + 1))):
+            exp = inst.neighbourhood(state, mv, window)
+            got, hard, soft = ctx.sched_eval(state, mv, window, want_scores=True)
+            assert np.array_equal(hard, exp["hard"]) and np.array_equal(soft, exp["soft"]), (n_moves, window)
+            assert (got["n_scored"], got["best_index"]) == (exp["n_scored"], exp["best_index"])
+            got2, _, _ = ctx.sched_eval(state, mv, window)
+            assert got2 == got, (n_moves, window)
+        ex = orc.Sched.exhaustive_moves(state, range(n_emp))
+        for window in (10 ** 9, max(1, len(ex) // 3)):
+            exp = inst.neighbourhood(state, ex, window)
+            got = ctx.sched_eval_exhaustive(state, window)[0]
+            assert (got["n_scored"], got["best_index"]) == (exp["n_scored"], exp["best_index"]), window
+            if exp["best_index"] >= 0:
+                assert (got["best_hard"], got["best_soft"]) == (exp["best_hard"], exp["best_soft"])
