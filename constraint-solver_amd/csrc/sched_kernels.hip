@@ -3,8 +3,8 @@
 // examples/employee-scheduling/src/lib.rs (scorer :261-375, helpers :149-222,
 // moves :464-479 / :526-550).
 //
-// Two families.  The DEFAULT is the delta scorer further down (sched_eval_delta_kernel, sched_eval_all_kernel,
-// sched_finish_kernel: one LANE per candidate, terms as functions of per-employee day sets).  The first half of the
+// Two families.  The DEFAULT is the delta scorer further down (sched_eval_small_kernel, sched_eval_all_kernel,
+// sched_finish_kernel, sched_eval_delta_kernel for score dumps: one LANE per candidate, terms as functions of per-employee day sets).  The first half of the
 // file is the wavefront-per-candidate family (LS_SCHED_DELTA=0; ls_sched_score and the count / locate passes of score
 // dumps always use it):
 //
@@ -1141,46 +1141,37 @@ __device__ __forceinline__ void sched_block_min_key(u64 &key, long long &idx, u6
     }
 }
 
-// Pass 2 after count + locate (per-candidate score dumps), or the whole pipeline in one block per restart (FUSED:
-// move lists of <= 64 * NW entries -- the reference example's window-100 iteration).
-template <typename M, int NW, bool FUSED>
+// Pass 2 after count + locate: the chain that serves per-candidate score dumps of long move lists.
+template <typename M, int NW>
 __global__ __launch_bounds__(64 * NW) void sched_eval_delta_kernel(SchedEvalArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = FUSED ? (int)blockIdx.x : (int)(blockIdx.x % a.n_restarts);
-    const int wave = FUSED ? wib : (int)(blockIdx.x / a.n_restarts) * NW + wib;
-    const int n_waves = FUSED ? NW : (int)(gridDim.x / a.n_restarts) * NW;
+    const int r = (int)(blockIdx.x % a.n_restarts);
+    const int wave = (int)(blockIdx.x / a.n_restarts) * NW + wib;
+    const int n_waves = (int)(gridDim.x / a.n_restarts) * NW;
     const int S = a.in.S, D = a.in.D, E = a.in.n_employees;
-    __shared__ SchedFusedShared<FUSED> s_fused;
     __shared__ SchedBaseTab<M> T;
     __shared__ u64 s_key[NW];
     __shared__ long long s_idx[NW];
-    LS_SC_STAMP(0);
     SchedLaneConst L{};
     if (wib < 3) L = a.in.lane_tab[lane];
-    long long k_end, n_scored_f = 0;
-    if constexpr (FUSED) sched_locate_in_block<NW>(a, r, s_fused, k_end, n_scored_f); // synchronises the block
-    else k_end = a.k_end[r];
-    const int e_lane = lane < S ? (FUSED ? s_fused.state[lane] : sched_state_at(a, r, lane)) : -1 - lane;
+    const long long k_end = a.k_end[r];
+    const int e_lane = lane < S ? sched_state_at(a, r, lane) : -1 - lane;
     const int hol_base = wib == 0 ? sched_holiday_bit(a.in, e_lane, lane) : 0; // in flight until the table build needs it
     const long long n_batches = (k_end + 63) >> 6;
     const ls_sched_move *mv = a.moves + (long long)r * a.max_moves;
-    // the first batch's moves, edits and holiday gathers are in flight while wavefront 0 tabulates the base state
+    // the first batch's moves, edits and holiday gathers are in flight while wavefronts 0..2 tabulate the base state
     long long batch = wave;
     int type = -1, ma = 0, mb = 0;
     {
         const long long k = (batch << 6) + lane;
-        if (k < k_end) { const ls_sched_move m = FUSED ? s_fused.moves[FUSED ? k : 0] : mv[k]; type = m.type; ma = m.a; mb = m.b; }
+        if (k < k_end) { const ls_sched_move m = mv[k]; type = m.type; ma = m.a; mb = m.b; }
     }
-    LS_SC_STAMP(1);
     SchedEdit ed = sched_edit_of(e_lane, S, E, type, ma, mb);
     int hbits = sched_edit_hbits(a.in, ed);
-    LS_SC_STAMP(2);
     if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T);
-    LS_SC_STAMP(3);
     __syncthreads();
-    LS_SC_STAMP(4);
     u64 best_key = SC_KEY_EMPTY;
     long long best_idx = -1;
     while (batch < n_batches) {
@@ -1196,25 +1187,80 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_delta_kernel(SchedEvalArgs
         if (batch < n_batches) {
             const long long k2 = (batch << 6) + lane;
             type = -1;
-            if (k2 < k_end) { const ls_sched_move m = FUSED ? s_fused.moves[FUSED ? k2 : 0] : mv[k2]; type = m.type; ma = m.a; mb = m.b; }
+            if (k2 < k_end) { const ls_sched_move m = mv[k2]; type = m.type; ma = m.a; mb = m.b; }
             ed = sched_edit_of(e_lane, S, E, type, ma, mb);
             hbits = sched_edit_hbits(a.in, ed);
         }
     }
-    LS_SC_STAMP(5);
     sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib);
-    LS_SC_STAMP(6);
     if (threadIdx.x == 0) {
-        if (FUSED) {
-            sched_write_result_n(a, r, best_key, best_idx, n_scored_f);
-            LS_SC_STAMP(7);
-        } else if (a.blocks_per_restart == 1) {
+        if (a.blocks_per_restart == 1) {
             sched_write_result(a, r, best_key, best_idx);
         } else {
             const long long slot = (long long)r * a.blocks_per_restart + blockIdx.x / a.n_restarts;
             a.part_key[slot] = best_key;
             a.part_idx[slot] = best_idx;
         }
+    }
+}
+
+// Move lists of at most 64 * NW entries (the reference example's window-100 iteration): ONE block per restart does the
+// whole pipeline.  Each lane loads its own move; whether it is a real candidate follows from the move and the state
+// alone, so the ballots that place take(window) (local_search.rs:319-321) are written before the block waits for the
+// table, and the same barrier publishes both: two barriers in all (table + counts, block minimum).
+template <typename M, int NW>
+__global__ __launch_bounds__(64 * NW) void sched_eval_small_kernel(SchedEvalArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = (int)blockIdx.x;
+    const int S = a.in.S, D = a.in.D, E = a.in.n_employees;
+    __shared__ SchedBaseTab<M> T;
+    __shared__ u64 s_key[NW];
+    __shared__ long long s_idx[NW];
+    __shared__ int s_wcnt[NW];
+    LS_SC_STAMP(0);
+    SchedLaneConst L{};
+    if (wib < 3) L = a.in.lane_tab[lane];
+    const int e_lane = lane < S ? sched_state_at(a, r, lane) : -1 - lane;
+    const int hol_base = wib == 0 ? sched_holiday_bit(a.in, e_lane, lane) : 0; // in flight until the table build needs it
+    const long long nm = sched_nm(a, r);
+    const long long k = threadIdx.x;
+    int type = -1, ma = 0, mb = 0;
+    if (k < nm) { const ls_sched_move m = a.moves[(long long)r * a.max_moves + k]; type = m.type; ma = m.a; mb = m.b; }
+    LS_SC_STAMP(1);
+    const SchedEdit ed = sched_edit_of(e_lane, S, E, type, ma, mb);
+    const u64 bal = __ballot(ed.active);
+    if (lane == 0) s_wcnt[wib] = __popcll(bal);
+    const int hbits = sched_edit_hbits(a.in, ed);
+    LS_SC_STAMP(2);
+    if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T);
+    LS_SC_STAMP(3);
+    __syncthreads();
+    LS_SC_STAMP(4);
+    int before = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        if (i < wib) before += s_wcnt[i];
+        total += s_wcnt[i];
+    }
+    const long long rank = before + __popcll(bal & ((2ull << lane) - 1)); // 1-based among the real candidates
+    u64 best_key = SC_KEY_EMPTY;
+    long long best_idx = -1;
+    if (ed.active && rank <= a.window) {
+        int hard, soft;
+        best_key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft);
+        best_idx = k;
+        if (a.hard_out) a.hard_out[(long long)r * a.max_moves + k] = hard;
+        if (a.soft_out) a.soft_out[(long long)r * a.max_moves + k] = soft;
+    }
+    LS_SC_STAMP(5);
+    sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib);
+    LS_SC_STAMP(6);
+    if (threadIdx.x == 0) {
+        const long long n_scored = a.window <= 0 ? 0 : (total < a.window ? total : a.window);
+        sched_write_result_n(a, r, best_key, best_idx, n_scored);
+        LS_SC_STAMP(7);
     }
 }
 
@@ -1298,8 +1344,11 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_all_kernel(SchedEvalArgs a
     LS_SC_STAMP(5);
     cnt = wave_sum_i32(cnt);
     if (lane == 0) s_cnt[wib] = cnt;
+    LS_SC_STAMP(12);
     sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib); // synchronises the block
+    LS_SC_STAMP(13);
     if (wib == 0) cnt = wave_sum_i32(lane < NW ? s_cnt[lane] : 0);
+    LS_SC_STAMP(14);
     if (threadIdx.x == 0) {
         const long long slot = (long long)r * a.n_chunks + c;
         a.part_key[slot] = best_key;
@@ -1669,8 +1718,8 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
         a.split = 4;
         a.blocks_per_restart = 1;
         if (delta) {
-            if (m32) hipLaunchKernelGGL((sched_eval_delta_kernel<unsigned, DW, true>), dim3(n_restarts), dim3(64 * DW), 0, ctx->stream, a);
-            else hipLaunchKernelGGL((sched_eval_delta_kernel<u64, DW, true>), dim3(n_restarts), dim3(64 * DW), 0, ctx->stream, a);
+            if (m32) hipLaunchKernelGGL((sched_eval_small_kernel<unsigned, DW>), dim3(n_restarts), dim3(64 * DW), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((sched_eval_small_kernel<u64, DW>), dim3(n_restarts), dim3(64 * DW), 0, ctx->stream, a);
         } else if (ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64)
             hipLaunchKernelGGL((sched_eval32_kernel<SC_FUSED_WAVES, true>), dim3(n_restarts), dim3(64 * SC_FUSED_WAVES), 0, ctx->stream, a);
         else
@@ -1685,8 +1734,8 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
     hipLaunchKernelGGL(sched_locate_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a);
     LS_HIP(ctx, hipGetLastError());
     if (delta) {
-        if (m32) hipLaunchKernelGGL((sched_eval_delta_kernel<unsigned, DW, false>), dim3((unsigned)(bpr * n_restarts)), dim3(64 * DW), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((sched_eval_delta_kernel<u64, DW, false>), dim3((unsigned)(bpr * n_restarts)), dim3(64 * DW), 0, ctx->stream, a);
+        if (m32) hipLaunchKernelGGL((sched_eval_delta_kernel<unsigned, DW>), dim3((unsigned)(bpr * n_restarts)), dim3(64 * DW), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((sched_eval_delta_kernel<u64, DW>), dim3((unsigned)(bpr * n_restarts)), dim3(64 * DW), 0, ctx->stream, a);
     } else if (ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64)
         hipLaunchKernelGGL((sched_eval32_kernel<4, false>), dim3((unsigned)(bpr * n_restarts)), dim3(256), 0, ctx->stream, a);
     else

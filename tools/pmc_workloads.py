@@ -103,9 +103,9 @@ def main():
         st3 = rng.integers(0, E3, size=S3).astype(np.int32)
         for _ in range(reps):
             r3 = ctx.sched_eval_resident(st3, 512, 100)
-        meta["sched_eval_delta_kernel_fused_window100"] = dict(candidates_per_launch=int(r3["n_scored"]),
+        meta["sched_eval_small_kernel_window100"] = dict(candidates_per_launch=int(r3["n_scored"]),
                                                                workload="example instance, 512 resident moves, window 100: one fused block",
-                                                               match="sched_eval_delta_kernel<unsigned int, 8, true>", grid_blocks=1)
+                                                               match="sched_eval_small_kernel<unsigned int, 8>", grid_blocks=1)
     print("PMC_WORKLOADS " + json.dumps(meta))
 
 

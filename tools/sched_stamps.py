@@ -45,12 +45,12 @@ with ls_amd.Context(0) as ctx:
             st = stamps(lib, 1)[0]
             acc.append((st - st[0]) / 100.0)
     acc = np.median(np.array(acc), axis=0)
-    names = ["entry", "window located, state + moves in LDS", "holiday gathers issued", "base table built (wavefront 0)",
+    names = ["entry", "state + move loaded", "edit, ballot, holiday gathers issued", "base table built (wavefront 0)",
              "block synchronised", "candidates scored", "block minimum", "result + completion word published"]
     print("fused one-block launch, 512 moves, window 100 (us since entry, thread 0):")
     for nm, t in zip(names, acc):
         print(f"  {nm:44s} {t:6.2f}")
-    print("  inside the table build (stamps 8..13):", " ".join(f"{t:.2f}" for t in acc[8:14]))
+    print("  inside the table build (stamps 8, 11):", " ".join(f"{acc[i]:.2f}" for i in (8, 11)))
     # (b) eval_all
     D, S, E = 31, 32, 10_000
     bits = np.zeros(E, dtype=np.uint64)
@@ -76,4 +76,5 @@ with ls_amd.Context(0) as ctx:
               f"last block end {(st[:, 6].max() - t0) / 100.0:.2f} us; median per-block phase times (us since block entry):")
         for i, nm in enumerate(names):
             print(f"  {nm:44s} {np.median(rel[:, i]):6.2f}")
-        print("  inside the table build (stamps 8..13):", " ".join(f"{np.median(rel[:, i]):.2f}" for i in range(8, 14)))
+        print("  inside the table build (stamps 8, 11):", " ".join(f"{np.median(rel[:, i]):.2f}" for i in (8, 11)))
+        print("  inside the record phase (stamps 12..14: wave count, block minimum, block count):", " ".join(f"{np.median(rel[:, i]):.2f}" for i in (12, 13, 14)))
