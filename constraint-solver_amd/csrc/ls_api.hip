@@ -147,6 +147,7 @@ int ls_ctx_create(int device_id, ls_ctx **out)
     if (const char *v = getenv("LS_SCHED_FUSED")) ctx->sched_fused = atoi(v) != 0;
     ctx->sched_force_64 = getenv("LS_SCHED_FORCE_64") != nullptr;
     if (const char *v = getenv("LS_SCHED_DELTA")) ctx->sched_delta = atoi(v) != 0;
+    if (const char *v = getenv("LS_NQ_HOST_CS")) ctx->nq_host_cs = atoi(v) != 0;
     if (const char *v = getenv("LS_SCHED_ONE_LAUNCH")) ctx->sched_one_launch = atoi(v) != 0;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->wave_size = prop.warpSize;
@@ -297,6 +298,74 @@ static void widen_u16(const unsigned short *src, int64_t *dst, int n)
     for (int j = 0; j < n; j++) dst[j] = src[j];
 }
 
+// Column scores of the board after ONE queen moved (column mc: row mq -> mv), from the scores before the move
+// (get_col_scores, examples/nqueens/src/lib.rs:74-87): a column j != mc loses the old queen's attack and gains the new
+// queen's; column mc gets the number of columns attacking its new square.  `rows` is the board BEFORE the move.
+// O(n) on the host instead of 2n bytes over PCIe and a pass of the step kernel.
+__attribute__((target("avx2"))) static void nq_cs_after_move_avx2(const int32_t *rows, int32_t *cs, int n, int mc, int mv, int mq)
+{
+    const __m256i vmc = _mm256_set1_epi32(mc), vmv = _mm256_set1_epi32(mv), vmq = _mm256_set1_epi32(mq);
+    __m256i idx = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7), cnt = _mm256_setzero_si256();
+    const __m256i eight = _mm256_set1_epi32(8);
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        const __m256i q = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(rows + j));
+        const __m256i dc = _mm256_abs_epi32(_mm256_sub_epi32(idx, vmc));
+        const __m256i dn = _mm256_abs_epi32(_mm256_sub_epi32(q, vmv)), dq = _mm256_abs_epi32(_mm256_sub_epi32(q, vmq));
+        // all-ones (-1) where the square is attacked
+        const __m256i hn = _mm256_or_si256(_mm256_cmpeq_epi32(dn, _mm256_setzero_si256()), _mm256_cmpeq_epi32(dn, dc));
+        const __m256i hq = _mm256_or_si256(_mm256_cmpeq_epi32(dq, _mm256_setzero_si256()), _mm256_cmpeq_epi32(dq, dc));
+        __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(cs + j));
+        c = _mm256_add_epi32(_mm256_sub_epi32(c, hn), hq); // c + [hn] - [hq]
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(cs + j), c);
+        cnt = _mm256_sub_epi32(cnt, hn);
+        idx = _mm256_add_epi32(idx, eight);
+    }
+    int32_t lanes[8];
+    _mm256_storeu_si256(reinterpret_cast<__m256i *>(lanes), cnt);
+    int total = 0;
+    for (int i = 0; i < 8; i++) total += lanes[i];
+    for (; j < n; j++) {
+        const int q = rows[j], dc = j > mc ? j - mc : mc - j;
+        const int dn = q > mv ? q - mv : mv - q, dq = q > mq ? q - mq : mq - q;
+        const int hn = (dn == 0) | (dn == dc), hq = (dq == 0) | (dq == dc);
+        cs[j] += hn - hq;
+        total += hn;
+    }
+    // column mc itself: its old queen (q = mq, dc = 0) counted hn = [mq == mv] = 0 and hq = 1 above; replace the entry
+    cs[mc] = total;
+}
+
+static void nq_cs_after_move(const int32_t *rows, int32_t *cs, int n, int mc, int mv, int mq)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) { nq_cs_after_move_avx2(rows, cs, n, mc, mv, mq); return; }
+    int total = 0;
+    for (int j = 0; j < n; j++) {
+        const int q = rows[j], dc = j > mc ? j - mc : mc - j;
+        const int dn = q > mv ? q - mv : mv - q, dq = q > mq ? q - mq : mq - q;
+        const int hn = (dn == 0) | (dn == dc), hq = (dq == 0) | (dq == dc);
+        cs[j] += hn - hq;
+        total += hn;
+    }
+    cs[mc] = total;
+}
+
+__attribute__((target("avx2"))) static void widen_i32_avx2(const int32_t *src, int64_t *dst, int n)
+{
+    int j = 0;
+    for (; j + 4 <= n; j += 4)
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(dst + j), _mm256_cvtepi32_epi64(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + j))));
+    for (; j < n; j++) dst[j] = src[j];
+}
+
+static void widen_i32(const int32_t *src, int64_t *dst, int n)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) { widen_i32_avx2(src, dst, n); return; }
+    for (int j = 0; j < n; j++) dst[j] = src[j];
+}
+
 // Wait for a kernel's completion word (coherent host memory) instead of synchronising the stream: the poll sees the
 // word a PCIe write after the kernel's last store, a stream synchronisation costs a runtime round trip on top.
 // Falls back to the stream (and reports its error) if the word does not arrive.
@@ -341,7 +410,9 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
     if (rs.n != n || (int)rs.valid.size() < R) { // geometry changed: nothing on the device can be reused
         rs.n = n;
         rs.valid.assign((size_t)R, 0);
+        rs.cs_valid.assign((size_t)R, 0);
         rs.shadow.resize((size_t)R * n);
+        rs.cs.resize((size_t)R * n);
         LS_RESERVE(ctx, rs.dev_rows, (size_t)R * n * 4);
     }
     const size_t rows_b = (size_t)R * n * 4, cur_b = (size_t)R * 8, cols_b = (size_t)R * max_cols * 4, nc_b = (size_t)R * 4,
@@ -355,7 +426,9 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
         if (e != hipSuccess) return set_err(ctx, LS_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
     }
     Staging &si = ctx->stage_in, &so = ctx->stage_out;
-    unsigned long long fresh = 0;
+    // A board that is not the one left by the previous call is uploaded; its column scores then come from the kernel.
+    // Otherwise the host keeps them itself: cs(winner board) follows from cs(board) and the move in O(n) (ctx->nq_host_cs).
+    unsigned long long fresh = 0, want_cs = 0;
     for (int r = 0; r < R; r++) {
         const int32_t *src = rows + (size_t)r * n;
         int32_t *sh = rs.shadow.data() + (size_t)r * n;
@@ -363,8 +436,11 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
             memcpy(si.h<char>(o_rows) + (size_t)r * n * 4, src, (size_t)n * 4);
             memcpy(sh, src, (size_t)n * 4);
             rs.valid[(size_t)r] = 1;
+            rs.cs_valid[(size_t)r] = 0;
             if (r < 64) fresh |= 1ull << r;
         }
+        if (!cs_b) rs.cs_valid[(size_t)r] = 0; // nobody keeps the scores across this call
+        if (cs_b && r < 64 && !(rs.cs_valid[(size_t)r] && ctx->nq_host_cs)) want_cs |= 1ull << r;
     }
     memcpy(si.h<char>(o_cur), cur_scores, cur_b);
     if (cols_b) memcpy(si.h<char>(o_cols), cols, cols_b);
@@ -373,6 +449,7 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
     x.fresh_mask = fresh;
     x.resident_rows = rs.dev_rows.as<int>();
     x.next_cs16 = cs_b ? so.h<unsigned short>(o_cs) : nullptr;
+    x.want_cs_mask = want_cs;
     x.done_flag = rs.flag;
     x.done_seq = ++rs.seq;
     x.block_counter = rs.counter.as<unsigned>();
@@ -394,10 +471,21 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
     const auto T3 = trace ? std::chrono::steady_clock::now() : T0;
     memcpy(results, so.h<char>(o_res), res_b);
     for (int r = 0; r < R; r++) {
-        if (results[r].best_index >= 0) rs.shadow[(size_t)r * n + (size_t)results[r].best_col] = results[r].best_value; // the device applied it
+        int32_t *sh = rs.shadow.data() + (size_t)r * n, *cs = rs.cs.data() + (size_t)r * n;
+        const bool moved = results[r].best_index >= 0;
+        const int mc = moved ? results[r].best_col : 0, mv = moved ? results[r].best_value : 0;
         if (cs_b) {
-            widen_u16(so.h<unsigned short>(o_cs) + (size_t)r * n, next_col_scores + (size_t)r * n, n);
+            if (r >= 64 || ((want_cs >> r) & 1ull)) { // from the kernel; remembered for the next call
+                const unsigned short *k16 = so.h<unsigned short>(o_cs) + (size_t)r * n;
+                widen_u16(k16, next_col_scores + (size_t)r * n, n);
+                for (int j = 0; j < n; j++) cs[j] = k16[j];
+                rs.cs_valid[(size_t)r] = r < 64;
+            } else {
+                if (moved) nq_cs_after_move(sh, cs, n, mc, mv, sh[mc]);
+                widen_i32(cs, next_col_scores + (size_t)r * n, n);
+            }
         }
+        if (moved) sh[mc] = mv; // the device applied it
     }
     if (trace) {
         const auto T4 = std::chrono::steady_clock::now();
@@ -443,6 +531,9 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
         if (e == hipSuccess) e = ctx->stage_out.reserve(out_b);
         if (e != hipSuccess) return set_err(ctx, LS_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
     }
+    const long long win = nq_clamp_window(window, max_cols, n);
+    if (!sc_b && ctx->nq_step_mode >= 3 && n_restarts <= 64 && nq_step_eligible(ctx, n, max_cols, win)) // packs its own (smaller) blocks
+        return nq_host_step_resident(ctx, n_restarts, n, rows, cur_scores, cols, n_cols, max_cols, win, results, next_col_scores);
     if (cs_b) LS_RESERVE(ctx, ctx->nq_next_rows, rows_b);
     if (sc_b) LS_RESERVE(ctx, ctx->nq_scores, sc_b);
     Staging &si = ctx->stage_in, &so = ctx->stage_out;
@@ -450,9 +541,6 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
     memcpy(si.h<char>(o_rows), rows, rows_b);
     if (cols_b) memcpy(si.h<char>(o_cols), cols, cols_b);
     memcpy(si.h<char>(o_nc), n_cols, nc_b);
-    const long long win = nq_clamp_window(window, max_cols, n);
-    if (!sc_b && ctx->nq_step_mode >= 3 && n_restarts <= 64 && nq_step_eligible(ctx, n, max_cols, win))
-        return nq_host_step_resident(ctx, n_restarts, n, rows, cur_scores, cols, n_cols, max_cols, win, results, next_col_scores);
     if (!sc_b && ctx->nq_step_mode > 0 && nq_step_eligible(ctx, n, max_cols, win)) {
         // One LS step per restart in one launch.  Mode 2: the kernel reads the pinned staging block and writes
         // the pinned result block directly (each byte crosses PCIe once, no copy dispatches in the chain).

@@ -1527,6 +1527,11 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqStepInline in, NqArgs a
         mc = ((key >> 45) & 1u) ? n - 1 - colkey : colkey;
         mq = s_rows[mc];
     }
+    // One-restart launches that publish a completion word and write nothing else to host memory (the resident route
+    // with host-kept column scores): thread 0 writes the record with write-through (system-scope) stores, waits for
+    // their acknowledgement and then stores the word -- no block barrier and no system-scope release (an L2 write-back).
+    const bool lean_publish = x.done_flag != nullptr && gridDim.x == 1 && !next_col_scores && !next_rows && !next_totals &&
+                              !(x.next_cs16 != nullptr && (r >= 64 || ((x.want_cs_mask >> r) & 1ull)));
     if (tid == 0) {
         ls_nq_result out;
         if (!has_move) {
@@ -1538,11 +1543,26 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqStepInline in, NqArgs a
             out.best_col = mc;
             out.best_value = mv;
         }
-        results[r] = out;
+        if (lean_publish) {
+            long long *dst = reinterpret_cast<long long *>(results + r);
+            __hip_atomic_store(dst + 0, out.n_scored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dst + 1, out.best_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dst + 2, out.best_score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dst + 3, (long long)(((unsigned long long)(unsigned)out.best_value << 32) | (unsigned)out.best_col),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            results[r] = out;
+        }
     }
     LS_STAMP(5);
     int local = 0;
-    for (int j = tid; j < n; j += 1024) {
+    // The full pass over the columns (winner board + its column scores) is skipped when the caller keeps the column
+    // scores itself (resident route: the host updates its copy from the move, O(n) there) and the board is already
+    // resident -- then only the moved queen is written.
+    const bool want_cs16 = x.next_cs16 != nullptr && (r >= 64 || ((x.want_cs_mask >> r) & 1ull));
+    const bool full_pass = next_col_scores || next_rows || next_totals || want_cs16 || (x.resident_rows && !from_resident);
+    if (!full_pass && x.resident_rows && has_move && tid == 0) x.resident_rows[(long long)r * n + mc] = mv;
+    for (int j = tid; j < (full_pass ? n : 0); j += 1024) {
         int q = s_rows[j];
         int sc = 0;
         if (j == mc) {
@@ -1557,7 +1577,7 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqStepInline in, NqArgs a
             }
         }
         if (next_col_scores) next_col_scores[(long long)r * n + j] = sc;
-        if (x.next_cs16) x.next_cs16[(long long)r * n + j] = (unsigned short)sc;
+        if (want_cs16) x.next_cs16[(long long)r * n + j] = (unsigned short)sc;
         if (next_rows) next_rows[(long long)r * n + j] = q;
         if (x.resident_rows) x.resident_rows[(long long)r * n + j] = q;
         local += sc;
@@ -1573,7 +1593,13 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqStepInline in, NqArgs a
         }
     }
     LS_STAMP(6);
-    if (x.done_flag) { // block-uniform
+    if (lean_publish) { // block-uniform
+        if (tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the record (and the moved queen) have been acknowledged
+            __hip_atomic_store(x.done_flag, x.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            LS_STAMP(7);
+        }
+    } else if (x.done_flag) { // block-uniform
         // Completion word: every block makes its outputs (host memory) visible at system scope, then counts itself;
         // the block that counts last publishes the sequence number.  __syncthreads orders the other wavefronts'
         // stores before thread 0's release fence.
@@ -2006,7 +2032,7 @@ int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long 
     const size_t lds = (tab_words + (((size_t)n + 3) & ~(size_t)3) + 4 * (size_t)slots) * 4;
     NqStepExtra x;
     if (extra) x = *extra;
-    else { x.fresh_mask = ~0ull; x.resident_rows = nullptr; x.next_cs16 = nullptr; x.done_flag = nullptr; x.done_seq = 0; x.block_counter = nullptr; }
+    else { x.fresh_mask = ~0ull; x.resident_rows = nullptr; x.next_cs16 = nullptr; x.want_cs_mask = ~0ull; x.done_flag = nullptr; x.done_seq = 0; x.block_counter = nullptr; }
     static const NqStepInline no_inline = {};
     const NqStepInline &in = inl && n_restarts == 1 && max_cols <= NQ_STEP_INLINE_COLS ? *inl : no_inline;
     if (pairs) hipLaunchKernelGGL(nq_step_kernel<true>, dim3(n_restarts), dim3(1024), lds, ctx->stream, in, a, results, next_rows, next_col_scores, next_totals, x);

@@ -366,12 +366,16 @@ def test_fused_step_kernel_matches_oracle(monkeypatch, mode):
                 assert np.array_equal(nxt[r], cs), (n, r)
 
 
-def test_fused_step_resident_boards_follow_any_call_sequence():
+@pytest.mark.parametrize("host_cs", ["1", "0"])
+def test_fused_step_resident_boards_follow_any_call_sequence(monkeypatch, host_cs):
     # LS_NQ_STEP=3 keeps every restart's winner board on the device and uploads a board only when the caller's differs
     # from it.  Whatever the caller does next -- continue from the winner (local_search.rs:335), jump to an unrelated
     # board (perturbation, iterated_local_search.rs:192-194), change the batch size or the board size, repeat a call --
-    # each call must equal a stateless evaluation.
+    # each call must equal a stateless evaluation.  LS_NQ_HOST_CS=1 (default): while a board stays resident the HOST
+    # keeps its column scores (updated from each move in O(n)) and the kernel skips that pass; 0: the kernel writes
+    # them every call.
     import ls_amd
+    monkeypatch.setenv("LS_NQ_HOST_CS", host_cs)
     rng = np.random.default_rng(333)
     with ls_amd.Context(0) as c:
         def call(rows, cols, n_cols, window):
@@ -404,6 +408,9 @@ def test_fused_step_resident_boards_follow_any_call_sequence():
             # an empty neighbourhood leaves the resident board as it is
             call(rows, np.zeros((R, 1), dtype=np.int64), np.zeros(R, dtype=np.int64), window)
             call(rows, np.stack([rng.permutation(n)[:mc] for _ in range(R)]), np.full(R, mc), window)
+            # a long run of continued calls: the host-kept column scores must not drift
+            for it in range(40):
+                rows = call(rows, np.stack([rng.permutation(n)[:mc] for _ in range(R)]), rng.integers(0, mc + 1, size=R), window)
 
 
 def test_fused_step_device_entry(ctx):
