@@ -373,10 +373,19 @@ __device__ __forceinline__ void sched_write_result_n(const SchedEvalArgs &a, int
         out.best_hard = (long long)(bk >> 54);
         out.best_soft = (long long)((bk >> 46) & 0xffu);
     }
-    a.results[r] = out;
-    if (a.done_flag) { // one-restart launch from the resident entry: the caller polls this word instead of synchronising the stream
-        __threadfence_system();
-        __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.done_flag) {
+        // one-restart launch from a resident entry: the record is the kernel's only output and lives in pinned host
+        // memory; the caller polls the completion word instead of synchronising the stream.  Write-through
+        // (system-scope) stores, their acknowledgement, then the word: no system-scope release (an L2 write-back).
+        long long *dst = reinterpret_cast<long long *>(a.results + r);
+        __hip_atomic_store(dst + 0, out.n_scored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + 1, out.best_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + 2, out.best_hard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + 3, out.best_soft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+        a.results[r] = out;
     }
 }
 
