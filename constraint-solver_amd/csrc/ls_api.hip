@@ -374,8 +374,9 @@ static int wait_done_word(ls_ctx *ctx, const unsigned long long *flag, unsigned 
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; spins++) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return LS_OK;
+        if (ctx->wait_hook) ctx->wait_hook(ctx->wait_hook_arg); // another restart of this thread gets the core meanwhile
 #if defined(__x86_64__)
-        __builtin_ia32_pause();
+        else __builtin_ia32_pause();
 #endif
         // A launch takes >= 10 us: after a short spin give the core to another runnable thread (ls_multi_solver runs
         // more slots than cores: one slot's host proposer then runs while the other slot's launch is in flight)

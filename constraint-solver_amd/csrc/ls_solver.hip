@@ -2,8 +2,10 @@
 // the host driver of csrc/host/ wired to the GPU path of this library.  Plain host C++; it is a
 // .hip file only so that the one hipcc invocation style builds everything.
 #include <sched.h>
+#include <ucontext.h>
 
 #include <atomic>
+#include <functional>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -32,7 +34,7 @@ struct ls_multi_solver {
     std::vector<std::string> seeds;
     std::vector<ScoredSolution<NQueensProblem>> best;
     std::vector<int> have;
-    int n_slots = 16;                 // restarts in flight at once (host threads); further seeds queue behind them
+    int n_slots = 16;                 // restarts in flight at once (create: 4 per usable core); further seeds queue behind them
     int mode = LS_MULTI_FREE_RUNNING; // LS_MULTI_FREE_RUNNING: a context per slot; LS_MULTI_LOCKSTEP: one batched launch per step
     uint64_t ls_iterations = 0, neighbours_scored = 0, gpu_launches = 0, rounds = 0;
 };
@@ -49,6 +51,73 @@ int check_params(ls_ctx *ctx, const ls_solver_params *p)
 
 // Cores this process may really use: the affinity mask, further limited by the cgroup CPU quota when there is one
 // (hardware_concurrency() reports the whole machine inside a container).
+// Cooperative fibres: several restarts share one host thread.  A restart that waits for its launch (wait_done_word's
+// hook) hands the thread to the next restart, whose host work (proposer, History) then runs during the wait -- with one
+// restart per thread the core idles for half of every LS iteration.  Plain ucontext: a fibre only ever switches inside
+// that hook, never inside a runtime call.
+class FiberGroup {
+public:
+    explicit FiberGroup(size_t stack_bytes = 1 << 20) : stack_bytes_(stack_bytes) {}
+    void add(std::function<void()> fn) { fibers_.emplace_back(new Fiber{{}, std::unique_ptr<char[]>(new char[stack_bytes_]), false, std::move(fn)}); }
+    // runs every fibre to completion on the calling thread
+    void run()
+    {
+        if (fibers_.empty()) return;
+        for (auto &f : fibers_) {
+            getcontext(&f->uc);
+            f->uc.uc_stack.ss_sp = f->stack.get();
+            f->uc.uc_stack.ss_size = stack_bytes_;
+            f->uc.uc_link = nullptr;
+            makecontext(&f->uc, reinterpret_cast<void (*)()>(&FiberGroup::trampoline), 2, (unsigned)((uintptr_t)this >> 32),
+                        (unsigned)((uintptr_t)this & 0xffffffffu));
+        }
+        cur_ = 0;
+        swapcontext(&main_, &fibers_[0]->uc);
+    }
+    // called by the running fibre: give the thread to the next unfinished fibre, come back when the others yield
+    void yield()
+    {
+        const int nxt = next_alive(cur_);
+        if (nxt < 0 || nxt == cur_) return;
+        const int prev = cur_;
+        cur_ = nxt;
+        swapcontext(&fibers_[(size_t)prev]->uc, &fibers_[(size_t)nxt]->uc);
+    }
+    static void yield_hook(void *self) { static_cast<FiberGroup *>(self)->yield(); }
+
+private:
+    struct Fiber {
+        ucontext_t uc;
+        std::unique_ptr<char[]> stack;
+        bool done;
+        std::function<void()> fn;
+    };
+    int next_alive(int from) const
+    {
+        const int n = (int)fibers_.size();
+        for (int i = 1; i <= n; i++) {
+            const int j = (from + i) % n;
+            if (!fibers_[(size_t)j]->done) return j;
+        }
+        return -1;
+    }
+    static void trampoline(unsigned hi, unsigned lo)
+    {
+        FiberGroup *g = reinterpret_cast<FiberGroup *>(((uintptr_t)hi << 32) | lo);
+        Fiber &f = *g->fibers_[(size_t)g->cur_];
+        f.fn(); // catches everything itself
+        f.done = true;
+        const int nxt = g->next_alive(g->cur_);
+        if (nxt < 0) setcontext(&g->main_);
+        g->cur_ = nxt;
+        setcontext(&g->fibers_[(size_t)nxt]->uc);
+    }
+    size_t stack_bytes_;
+    std::vector<std::unique_ptr<Fiber>> fibers_;
+    ucontext_t main_;
+    int cur_ = -1;
+};
+
 unsigned usable_cores()
 {
     unsigned cores = std::thread::hardware_concurrency();
@@ -258,8 +327,10 @@ int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_r
         }
         m->best.resize((size_t)n_restarts);
         m->have.assign((size_t)n_restarts, 0);
-        const unsigned hw = usable_cores(); // a slot is a host thread that polls while its launch runs: one per core by default
-        if ((unsigned)m->n_slots > hw) m->n_slots = (int)hw;
+        // default: four restarts in flight per usable core -- free-running slots beyond the cores share threads as
+        // cooperative fibres, so a slot's host work runs while another slot's launch is in flight
+        const unsigned hw = usable_cores();
+        m->n_slots = (int)(4 * hw > 256 ? 256 : (4 * hw < 1 ? 1 : 4 * hw));
         *out = m.release();
         return LS_OK;
     });
@@ -268,8 +339,13 @@ int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_r
 int ls_multi_solver_configure(ls_multi_solver *m, int32_t n_slots, int32_t mode)
 {
     if (!m) return LS_ERR_INVALID;
-    if (n_slots < 1 || n_slots > 256 || (mode != LS_MULTI_LOCKSTEP && mode != LS_MULTI_FREE_RUNNING))
-        return lsamd::set_err(m->ctx, LS_ERR_INVALID, "ls_multi_solver_configure: n_slots %d (1..256), mode %d", n_slots, mode);
+    if (n_slots < 0 || n_slots > 256 || (mode != LS_MULTI_LOCKSTEP && mode != LS_MULTI_FREE_RUNNING))
+        return lsamd::set_err(m->ctx, LS_ERR_INVALID, "ls_multi_solver_configure: n_slots %d (0..256), mode %d", n_slots, mode);
+    if (n_slots == 0) { // the mode's default: lockstep slots are host threads, free-running slots may share them
+        const unsigned hw = usable_cores();
+        const unsigned want = mode == LS_MULTI_LOCKSTEP ? hw : 4 * hw;
+        n_slots = (int)(want > 256 ? 256 : (want < 1 ? 1 : want));
+    }
     m->n_slots = n_slots;
     m->mode = mode;
     return LS_OK;
@@ -291,7 +367,7 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
         std::atomic<int> next_restart{0};
         std::atomic<bool> stop{false};
         const auto t0 = std::chrono::steady_clock::now();
-        auto worker = [&](int t) {
+        auto worker = [&](int t, FiberGroup *group) {
             ls_ctx *own = nullptr;
             try {
                 ls_ctx *ctx = m->ctx;
@@ -301,11 +377,12 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
                     own->nq_step_mode = m->ctx->nq_step_mode;
                     ctx = own;
                 }
-                // more slots than cores: a waiting slot yields its core to a slot that has host work to do
-                const unsigned hwc = usable_cores();
-                const bool was_yielding = ctx->yield_while_waiting;
-                if (!lockstep && hwc >= 1 && (unsigned)T > hwc) ctx->yield_while_waiting = true;
-                struct Restore { ls_ctx *c; bool v; ~Restore() { c->yield_while_waiting = v; } } restore{ctx, was_yielding};
+                // more slots than host threads: a waiting slot hands its thread to a slot that has host work to do
+                struct Restore {
+                    ls_ctx *c; void (*h)(void *); void *a;
+                    ~Restore() { c->wait_hook = h; c->wait_hook_arg = a; }
+                } restore{ctx, ctx->wait_hook, ctx->wait_hook_arg};
+                if (group) { ctx->wait_hook = &FiberGroup::yield_hook; ctx->wait_hook_arg = group; }
                 const ls_solver_params &p = m->params;
                 for (;;) {
                     const int r = next_restart.fetch_add(1);
@@ -348,8 +425,17 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
             batcher.thread_done();
             if (own) (void)ls_ctx_destroy(own);
         };
+        // free-running slots beyond the host's cores share threads as cooperative fibres (slot t on thread t mod n_threads)
+        const int hwc = (int)usable_cores();
+        const int n_threads = (!lockstep && hwc >= 1 && T > hwc) ? hwc : T;
         std::vector<std::thread> threads;
-        for (int t = 0; t < T; t++) threads.emplace_back(worker, t);
+        for (int th = 0; th < n_threads; th++)
+            threads.emplace_back([&, th]() {
+                if (n_threads == T) { worker(th, nullptr); return; }
+                FiberGroup group;
+                for (int t = th; t < T; t += n_threads) group.add([&, t]() { worker(t, &group); });
+                group.run();
+            });
         for (auto &t : threads) t.join();
         for (const std::string &e : errors)
             if (!e.empty()) throw std::runtime_error(e);

@@ -350,7 +350,7 @@ class MultiSolver:
                                                           C.byref(p), C.byref(h)))
         self._h = h
         if n_slots is not None or mode is not None:
-            ctx._check(self._l.ls_multi_solver_configure(h, int(n_slots or 16), self.MODES[mode or "free"]))
+            ctx._check(self._l.ls_multi_solver_configure(h, int(n_slots or 0), self.MODES[mode or "free"]))
 
     def run(self, max_rounds_per_restart=2 ** 62, max_seconds=0.0):
         self._ctx._check(self._l.ls_multi_solver_run(self._h, int(max_rounds_per_restart), float(max_seconds)))

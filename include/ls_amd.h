@@ -324,7 +324,7 @@ int ls_solver_free(ls_solver *s);
 
 /* Many independent restarts on one GPU (the reference's only multi-seed convention is
  * consecutive seed strings, examples/nqueens/src/main.rs:167).  Each restart is a complete, unchanged solver
- * on a host thread; n_slots of them are in flight at once and a finished restart's slot takes the next seed of
+ * on a host thread (or fibre); n_slots of them are in flight at once and a finished restart's slot takes the next seed of
  * the list, so the GPU stays fed while restarts need very different numbers of iterations.  The result of
  * every restart is identical to running it alone with ls_solver_*.  Two ways to serve the slots' GPU requests:
  *   LS_MULTI_FREE_RUNNING  (default) every slot owns a context (stream + pinned staging block) on the same device
@@ -338,9 +338,9 @@ int ls_solver_free(ls_solver *s);
 typedef struct ls_multi_solver ls_multi_solver;
 int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_restarts, const char *const *seeds,
                                    const ls_solver_params *params, ls_multi_solver **out);
-/* n_slots in [1, 256] (default: 16, at most the cores the process may use; ls_multi_solver_configure may ask for more:
- * a slot whose launch is in flight then lends its core to a slot with host work to do), mode as above; call before
- * ls_multi_solver_run. */
+/* n_slots in [1, 256], or 0 for the mode's default (default: four per core the process may use; free-running slots beyond the cores share host
+ * threads as cooperative fibres: a slot whose launch is in flight lends its thread to a slot with host work to do;
+ * lockstep slots are one host thread each), mode as above; call before ls_multi_solver_run. */
 int ls_multi_solver_configure(ls_multi_solver *m, int32_t n_slots, int32_t mode);
 int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, double max_seconds);
 int ls_multi_solver_get_best(const ls_multi_solver *m, int32_t restart, int64_t score[2], int64_t *solution,

@@ -2,6 +2,8 @@
 plug-ins, every score and neighbourhood on the GPU) against the oracle's independent Python
 restatement with the literal CPU neighbourhood pipeline: same seed => identical trajectory
 (current and best score after every round) and identical final solutions."""
+import os
+
 import numpy as np
 import pytest
 
@@ -203,6 +205,34 @@ def test_seeds_stream_through_slots(ctx, mode, n_slots, algo):
     assert [m.best(r) for r in range(len(seeds))] == singles
     st = m.stats()
     assert st["ls_iterations"] == iters
+    m.close()
+
+
+@pytest.mark.parametrize("algo", ["auto", "scan"])
+def test_more_slots_than_cores_share_threads_as_fibres(ctx, algo):
+    # free-running slots beyond the host's cores run as cooperative fibres, several restarts per thread, switching in the
+    # completion-word wait: every restart must still equal its single-solver run
+    import ls_amd
+    ctx.set_algo(algo)
+    n, rounds = 40, 4
+    n_seeds = 53                                           # the GPU box gives a process 16 cores
+    seeds = [str(s) for s in range(500, 500 + n_seeds)]
+    p = _nq_params(n)
+    singles, iters = [], 0
+    for seed in seeds:
+        s = ls_amd.Solver.nqueens(ctx, n, seed, p)
+        for _ in range(rounds):
+            s.execute_round()
+            b = s.best()
+            if b is not None and b[0] == 0:
+                break
+        singles.append(s.best())
+        iters += s.stats()["ls_iterations"]
+        s.close()
+    m = ls_amd.MultiSolver(ctx, n, seeds, p, n_slots=n_seeds, mode="free")
+    m.run(max_rounds_per_restart=rounds)
+    assert [m.best(r) for r in range(len(seeds))] == singles
+    assert m.stats()["ls_iterations"] == iters
     m.close()
 
 

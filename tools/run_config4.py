@@ -21,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--board-size", "--n", dest="n", type=int, default=4096)
     ap.add_argument("--restarts-per-gpu", type=int, default=8, help="seeds per GPU (64 on one GPU = the whole of config 4)")
-    ap.add_argument("--slots", type=int, default=16, help="restarts in flight at once; further seeds queue behind them")
+    ap.add_argument("--slots", type=int, default=0, help="restarts in flight at once (0: library default, four per usable core); further seeds queue behind them")
     ap.add_argument("--mode", default="free", choices=["lockstep", "free"])
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--rounds", type=int, default=10_000)
