@@ -148,6 +148,7 @@ int ls_ctx_create(int device_id, ls_ctx **out)
     ctx->sched_force_64 = getenv("LS_SCHED_FORCE_64") != nullptr;
     if (const char *v = getenv("LS_SCHED_DELTA")) ctx->sched_delta = atoi(v) != 0;
     if (const char *v = getenv("LS_NQ_HOST_CS")) ctx->nq_host_cs = atoi(v) != 0;
+    if (const char *v = getenv("LS_NQ_RESIDENT_TABS")) ctx->nq_resident_tabs = atoi(v) != 0;
     if (const char *v = getenv("LS_SCHED_ONE_LAUNCH")) ctx->sched_one_launch = atoi(v) != 0;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->wave_size = prop.warpSize;
@@ -177,6 +178,7 @@ int ls_ctx_destroy(ls_ctx *ctx)
                 ctx->nq_res.t_pre / ctx->nq_res.calls * 1e6, ctx->nq_res.t_launch / ctx->nq_res.calls * 1e6, ctx->nq_res.t_wait / ctx->nq_res.calls * 1e6,
                 ctx->nq_res.t_post / ctx->nq_res.calls * 1e6);
     ctx->nq_res.dev_rows.release();
+    ctx->nq_res.dev_tabs.release();
     ctx->nq_res.counter.release();
     if (ctx->nq_res.flag) (void)hipHostFree(ctx->nq_res.flag);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -415,6 +417,10 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
         rs.shadow.resize((size_t)R * n);
         rs.cs.resize((size_t)R * n);
         LS_RESERVE(ctx, rs.dev_rows, (size_t)R * n * 4);
+        // the step kernel's table layout (nq_step_dev picks the paired layout for even n >= 128): 6n + 4 or 5n + 1 u16
+        const bool pairs = (n & 1) == 0 && n >= 128 && ctx->nq_table_variant >= 10;
+        rs.tab_words = pairs ? ((((6 * n + 4) >> 1) + 3) & ~3) : ((((5 * n + 1) >> 1) + 3) & ~3);
+        LS_RESERVE(ctx, rs.dev_tabs, (size_t)R * rs.tab_words * 4);
     }
     const size_t rows_b = (size_t)R * n * 4, cur_b = (size_t)R * 8, cols_b = (size_t)R * max_cols * 4, nc_b = (size_t)R * 4,
                  res_b = (size_t)R * sizeof(ls_nq_result), cs_b = next_col_scores ? (size_t)R * n * 2 : 0;
@@ -449,6 +455,8 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
     NqStepExtra x;
     x.fresh_mask = fresh;
     x.resident_rows = rs.dev_rows.as<int>();
+    x.resident_tabs = ctx->nq_resident_tabs ? rs.dev_tabs.as<unsigned>() : nullptr;
+    x.tab_words = rs.tab_words;
     x.next_cs16 = cs_b ? so.h<unsigned short>(o_cs) : nullptr;
     x.want_cs_mask = want_cs;
     x.done_flag = rs.flag;

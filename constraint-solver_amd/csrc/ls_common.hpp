@@ -87,6 +87,8 @@ struct Staging {
 struct NqStepExtra {
     unsigned long long fresh_mask; // bit r set: restart r's board comes from a.rows; clear: from resident_rows (n_restarts <= 64)
     int *resident_rows;           // [n_restarts][n] device copy; receives the winner board
+    unsigned *resident_tabs;      // nullable [n_restarts][tab_words] the count tables of the resident boards (packed u16, the kernel's LDS layout)
+    int tab_words;                // stride of resident_tabs in 32-bit words
     unsigned short *next_cs16;    // [n_restarts][n]
     unsigned long long want_cs_mask; // bit r set: restart r's column scores are written to next_cs16 (r >= 64: always)
     unsigned long long *done_flag; // host word <- done_seq once every block's outputs are visible to the host
@@ -120,6 +122,8 @@ struct NqResident {
     std::vector<int32_t> cs;     // [slots][n] column scores of the shadow boards (what the last call returned)
     std::vector<char> cs_valid;  // [slots]
     DevBuf dev_rows;             // [slots][n]
+    DevBuf dev_tabs;             // [slots][tab_words] count tables of the resident boards, patched by every step
+    int tab_words = 0;
     DevBuf counter;              // completion-word block counter (one u32, zero between launches)
     unsigned long long *flag = nullptr; // hipHostMalloc'd coherent word the kernel publishes done_seq to
     unsigned long long seq = 0;
@@ -151,6 +155,7 @@ struct ls_ctx {
     bool yield_while_waiting = false; // completion-word poll: sched_yield() after a short spin (set by ls_multi_solver when slots > cores; LS_YIELD)
     bool sched_zero_copy = true; // ls_sched_eval_resident: kernels work on the pinned staging blocks directly (LS_SCHED_ZEROCOPY)
     bool sched_fused = true;     // small scheduling launches: locate + eval + reduce in one kernel (LS_SCHED_FUSED)
+    bool nq_resident_tabs = true; // LS_NQ_RESIDENT_TABS: the resident LS step keeps the count tables on the device and patches them (0: rebuilt every call)
     bool nq_host_cs = true;      // LS_NQ_HOST_CS: the resident LS step keeps the column scores on the host (0: the kernel writes them every call)
     bool sched_delta = true;     // LS_SCHED_DELTA: lane-per-candidate delta scorer (0: the wavefront-per-candidate kernels)
     bool sched_one_launch = false; // LS_SCHED_ONE_LAUNCH=1: the last block of the delta pipeline's scoring launch does the finish step itself

@@ -1396,12 +1396,34 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqStepInline in, NqArgs a
         const int j = tid + 1024 * i;
         rv[i] = j < n ? rows[j] : -1;
     }
+    // The count tables of a resident board live next to it on the device (every step patches them with its move's
+    // eight entries): they are loaded with the board instead of being rebuilt (zero + 4 LDS atomics per column + a barrier).
+    const bool tabs_resident = from_resident && x.resident_tabs != nullptr && x.tab_words == words;
+    constexpr int TAB_VEC = (((6 * NQ_STEP_MAX_N + 4) >> 1) + 3) / 4 / 1024 + 1; // uint4 loads per thread at most
+    uint4 tv[TAB_VEC];
+    if (tabs_resident) {
+        const uint4 *gt = reinterpret_cast<const uint4 *>(x.resident_tabs + (long long)r * x.tab_words);
+#pragma unroll
+        for (int i = 0; i < TAB_VEC; i++) {
+            const int w4 = tid + 1024 * i;
+            tv[i] = w4 < (words >> 2) ? gt[w4] : make_uint4(0, 0, 0, 0);
+        }
+    }
     LS_STAMP(0);
     // the launcher guarantees n_slots <= 1024; `in.valid` (one restart, <= NQ_STEP_INLINE_COLS columns): from the kernel arguments
     const int cv = tid < a.max_cols ? (in.valid ? in.cols[tid < NQ_STEP_INLINE_COLS ? tid : 0] : cols[tid]) : -1;
     int ncols = in.valid ? in.n_cols : a.n_cols[r];
     const long long cur = tid == 0 ? (in.valid ? in.cur : a.cur_scores[r]) : 0;
-    for (int i = tid; i < words; i += 1024) s_t16[i] = 0;
+    if (tabs_resident) {
+        uint4 *st = reinterpret_cast<uint4 *>(s_t16);
+#pragma unroll
+        for (int i = 0; i < TAB_VEC; i++) {
+            const int w4 = tid + 1024 * i;
+            if (w4 < (words >> 2)) st[w4] = tv[i];
+        }
+    } else {
+        for (int i = tid; i < words; i += 1024) s_t16[i] = 0;
+    }
 #pragma unroll
     for (int i = 0; i < NQ_STEP_MAX_N / 1024; i++) {
         const int j = tid + 1024 * i;
@@ -1413,18 +1435,20 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqStepInline in, NqArgs a
     const int n_slots = (int)((K + n - 1) / n);
     __syncthreads();
     const int oR1 = n, oA = PAIRS ? 2 * n : n, oB = PAIRS ? 4 * n + 2 : 3 * n;
+    if (!tabs_resident) { // block-uniform
 #pragma unroll
-    for (int i = 0; i < NQ_STEP_MAX_N / 1024; i++) {
-        const int j = tid + 1024 * i, q = rv[i];
-        if (j < n && (unsigned)q < (unsigned)n) {
-            tab16_inc(s_t16, q);
-            if (PAIRS && q > 0) tab16_inc(s_t16, oR1 + q - 1);
-            tab16_inc(s_t16, oA + (q - j + n));
-            tab16_inc(s_t16, oB + (q + j));
+        for (int i = 0; i < NQ_STEP_MAX_N / 1024; i++) {
+            const int j = tid + 1024 * i, q = rv[i];
+            if (j < n && (unsigned)q < (unsigned)n) {
+                tab16_inc(s_t16, q);
+                if (PAIRS && q > 0) tab16_inc(s_t16, oR1 + q - 1);
+                tab16_inc(s_t16, oA + (q - j + n));
+                tab16_inc(s_t16, oB + (q + j));
+            }
         }
+        if (PAIRS && tid == 0) atomicAdd(&s_t16[(oR1 + n - 1) >> 1], NQ_PAIR_SENTINEL << (16 * ((oR1 + n - 1) & 1)));
+        __syncthreads();
     }
-    if (PAIRS && tid == 0) atomicAdd(&s_t16[(oR1 + n - 1) >> 1], NQ_PAIR_SENTINEL << (16 * ((oR1 + n - 1) & 1)));
-    __syncthreads();
     LS_STAMP(2);
     int my_scored = 0; // this slot's share of n_scored (nq_slot_scored: skipped slots keep their window positions)
     if (tid < n_slots) {
@@ -1552,6 +1576,28 @@ __global__ __launch_bounds__(1024) void nq_step_kernel(NqStepInline in, NqArgs a
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
             results[r] = out;
+        }
+    }
+    if (x.resident_tabs != nullptr && r < 64 && x.tab_words == words) { // block-uniform
+        unsigned *gtab = x.resident_tabs + (long long)r * x.tab_words;
+        if (!tabs_resident) { // a fresh board: its tables (before the move) go to the device copy first
+            uint4 *gt = reinterpret_cast<uint4 *>(gtab);
+            const uint4 *st = reinterpret_cast<const uint4 *>(s_t16);
+            for (int w4 = tid; w4 < (words >> 2); w4 += 1024) gt[w4] = st[w4];
+            __syncthreads(); // the stores are acknowledged before any lane patches the same words
+        }
+        if (has_move && tid < 8) { // the old queen leaves (tid 0..3), the new one arrives (4..7): row, shifted row copy, two diagonals
+            const int q = tid < 4 ? mq : mv, what = tid & 3;
+            int idx = -1;
+            if (what == 0) idx = q;
+            else if (what == 1) idx = (PAIRS && q > 0) ? oR1 + q - 1 : -1;
+            else if (what == 2) idx = oA + (q - mc + n);
+            else idx = oB + (q + mc);
+            if (idx >= 0) {
+                const unsigned one = 1u << (16 * (idx & 1));
+                if (tid < 4) atomicSub(&gtab[idx >> 1], one); // the count includes the old queen: no borrow
+                else atomicAdd(&gtab[idx >> 1], one);
+            }
         }
     }
     LS_STAMP(5);
@@ -2032,7 +2078,7 @@ int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long 
     const size_t lds = (tab_words + (((size_t)n + 3) & ~(size_t)3) + 4 * (size_t)slots) * 4;
     NqStepExtra x;
     if (extra) x = *extra;
-    else { x.fresh_mask = ~0ull; x.resident_rows = nullptr; x.next_cs16 = nullptr; x.want_cs_mask = ~0ull; x.done_flag = nullptr; x.done_seq = 0; x.block_counter = nullptr; }
+    else { x.fresh_mask = ~0ull; x.resident_rows = nullptr; x.resident_tabs = nullptr; x.tab_words = 0; x.next_cs16 = nullptr; x.want_cs_mask = ~0ull; x.done_flag = nullptr; x.done_seq = 0; x.block_counter = nullptr; }
     static const NqStepInline no_inline = {};
     const NqStepInline &in = inl && n_restarts == 1 && max_cols <= NQ_STEP_INLINE_COLS ? *inl : no_inline;
     if (pairs) hipLaunchKernelGGL(nq_step_kernel<true>, dim3(n_restarts), dim3(1024), lds, ctx->stream, in, a, results, next_rows, next_col_scores, next_totals, x);

@@ -366,16 +366,18 @@ def test_fused_step_kernel_matches_oracle(monkeypatch, mode):
                 assert np.array_equal(nxt[r], cs), (n, r)
 
 
-@pytest.mark.parametrize("host_cs", ["1", "0"])
-def test_fused_step_resident_boards_follow_any_call_sequence(monkeypatch, host_cs):
+@pytest.mark.parametrize("host_cs,resident_tabs", [("1", "1"), ("0", "1"), ("1", "0")])
+def test_fused_step_resident_boards_follow_any_call_sequence(monkeypatch, host_cs, resident_tabs):
     # LS_NQ_STEP=3 keeps every restart's winner board on the device and uploads a board only when the caller's differs
     # from it.  Whatever the caller does next -- continue from the winner (local_search.rs:335), jump to an unrelated
     # board (perturbation, iterated_local_search.rs:192-194), change the batch size or the board size, repeat a call --
     # each call must equal a stateless evaluation.  LS_NQ_HOST_CS=1 (default): while a board stays resident the HOST
     # keeps its column scores (updated from each move in O(n)) and the kernel skips that pass; 0: the kernel writes
-    # them every call.
+    # them every call.  LS_NQ_RESIDENT_TABS=1 (default): the count tables of a resident board stay on the device too and
+    # every step patches them with its move; 0: rebuilt from the board every call.
     import ls_amd
     monkeypatch.setenv("LS_NQ_HOST_CS", host_cs)
+    monkeypatch.setenv("LS_NQ_RESIDENT_TABS", resident_tabs)
     rng = np.random.default_rng(333)
     with ls_amd.Context(0) as c:
         def call(rows, cols, n_cols, window):
