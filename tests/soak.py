@@ -130,6 +130,21 @@ def sched_case(ctx):
     got2, _, _ = ctx.sched_eval(state, moves, window)
     if got2 != got:
         fail("sched: debug and production paths differ", D=D, S=S, E=E, state=state, moves=moves, window=window)
+    # resident move list (the solver's per-iteration entry) and, for small employee counts, the exhaustive proposer
+    ctx.sched_moves_upload(moves)
+    got3 = ctx.sched_eval_resident(state, n_moves, window)
+    if got3 != {k: got[k] for k in got3}:
+        fail("sched: resident entry differs", D=D, S=S, E=E, state=state, moves=moves, window=window, got=got3)
+    if E <= 40:
+        ex = orc.Sched.exhaustive_moves(state, range(E))
+        wx = int(rng.choice([1, rng.integers(1, len(ex) + 2), 10 ** 12]))
+        expx = inst.neighbourhood(state, ex, wx)
+        gotx = ctx.sched_eval_exhaustive(state, wx)[0]
+        if (gotx["n_scored"], gotx["best_index"]) != (expx["n_scored"], expx["best_index"]) or \
+                (expx["best_index"] >= 0 and (gotx["best_hard"], gotx["best_soft"]) != (expx["best_hard"], expx["best_soft"])):
+            fail("sched exhaustive", D=D, S=S, E=E, wd=start_wd, hol=hol, state=state, window=wx, got=gotx,
+                 exp={k: expx[k] for k in ("n_scored", "best_index", "best_hard", "best_soft")})
+        stats["sched_candidates"] += expx["n_scored"]
     stats["sched"] += 1
     stats["sched_candidates"] += exp["n_scored"]
 
