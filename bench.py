@@ -579,13 +579,23 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True):
     ctx.set_algo("auto")
     cols_h, ncols_h = cols_ref.cpu().numpy(), ncols_ref.cpu().numpy()
     for RR in (1, R):
-        args_h = (boards[:RR], cur_np[:RR], cols_h[:RR], ncols_h[:RR], 5 * n)
+        # the solver's steady state: every call continues from the previous winner (board, count tables and column
+        # scores stay resident on the device / host); the board update below is part of the timed loop
+        b_h, c_h = boards[:RR].copy(), np.array(cur_np[:RR]).copy()
+
+        def step():
+            out_h, _ = ctx.nqueens_eval_batch_next(b_h, c_h, cols_h[:RR], ncols_h[:RR], 5 * n)
+            for rr in range(RR):
+                if out_h[rr]["best_index"] >= 0:
+                    b_h[rr, out_h[rr]["best_col"]] = out_h[rr]["best_value"]
+                    c_h[rr] = out_h[rr]["best_score"]
+
         for _ in range(200):     # also lets the clocks settle after the heavy launches above
-            ctx.nqueens_eval_batch_next(*args_h)
+            step()
         reps = 1000
         t0 = time.perf_counter()
         for _ in range(reps):
-            ctx.nqueens_eval_batch_next(*args_h)
+            step()
         s = (time.perf_counter() - t0) / reps
         c = kc.get(f"nq_step_kernel_r{RR}") or {}
         out[f"fused_ls_step_host_round_trip_{RR}_restarts"] = {
