@@ -154,7 +154,7 @@ public:
 
 private:
     // One 32-bit lane per block (compiler vector extension).  A refill consumes four blocks (BlockRng's 64-word
-    // buffer); where the host has AVX2, eight blocks are produced at once and the second four wait in ahead_ --
+    // buffer); where the host has AVX2 / AVX-512, eight / sixteen blocks are produced at once and the later ones wait in ahead_ --
     // the word sequence is that of chacha20_block called block by block (tests/test_host_rng.py compares them).
 #define LS_CHACHA_LANES(L, OUT)                                                                      \
     typedef uint32_t vL __attribute__((vector_size(4 * L)));                                        \
@@ -185,9 +185,15 @@ private:
     void blocks4(uint32_t *out) { LS_CHACHA_LANES(4, out) }
 #if defined(__x86_64__)
     __attribute__((target("avx2"))) void blocks8(uint32_t *out) { LS_CHACHA_LANES(8, out) }
-    static bool have_avx2() // LS_HOST_NO_AVX2=1 forces the four-lane path (tests run both)
+    __attribute__((target("avx512f"))) void blocks16(uint32_t *out) { LS_CHACHA_LANES(16, out) } // rotates are single vprold
+    static bool have_avx2() // LS_HOST_NO_AVX2=1 forces the four-lane path (tests run all three)
     {
         static const bool v = __builtin_cpu_supports("avx2") && std::getenv("LS_HOST_NO_AVX2") == nullptr;
+        return v;
+    }
+    static bool have_avx512() // LS_HOST_NO_AVX512=1 forces the eight-lane path
+    {
+        static const bool v = have_avx2() && __builtin_cpu_supports("avx512f") && std::getenv("LS_HOST_NO_AVX512") == nullptr;
         return v;
     }
 #endif
@@ -195,29 +201,39 @@ private:
 #undef LS_CHACHA_LANES
     void generate_and_set(size_t idx)
     {
-        if (have_ahead_) {
-            std::memcpy(buf_, ahead_, sizeof buf_);
-            have_ahead_ = false;
+        if (ahead_left_ > 0) {
+            std::memcpy(buf_, ahead_ + 64 * ahead_pos_, sizeof buf_);
+            ahead_pos_++;
+            ahead_left_--;
         } else {
 #if defined(__x86_64__)
-            if (have_avx2()) {
+            if (have_avx512()) { // sixteen blocks at once: four refills
+                uint32_t tmp[256];
+                blocks16(tmp);
+                std::memcpy(buf_, tmp, sizeof buf_);
+                std::memcpy(ahead_, tmp + 64, 3 * sizeof buf_);
+                ahead_pos_ = 0;
+                ahead_left_ = 3;
+            } else if (have_avx2()) {
                 uint32_t tmp[128];
                 blocks8(tmp);
                 std::memcpy(buf_, tmp, sizeof buf_);
-                std::memcpy(ahead_, tmp + 64, sizeof ahead_);
-                have_ahead_ = true;
+                std::memcpy(ahead_, tmp + 64, sizeof buf_);
+                ahead_pos_ = 0;
+                ahead_left_ = 1;
             } else
 #endif
                 blocks4(buf_);
         }
-        counter_ += 4; // blocks handed to buf_ so far (ahead_ holds blocks counter_ .. counter_ + 3 when have_ahead_)
+        counter_ += 4; // blocks handed to buf_ so far (ahead_ holds the blocks from counter_ on: 4 * ahead_left_ of them)
         index_ = idx;
     }
     uint32_t key_[8];
     uint64_t counter_ = 0;
     uint32_t buf_[64];
-    uint32_t ahead_[64];
-    bool have_ahead_ = false;
+    uint32_t ahead_[192];
+    int ahead_pos_ = 0, ahead_left_ = 0; // refills (64 words each) waiting in ahead_
+
     size_t index_ = 64;
 };
 
@@ -479,11 +495,18 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, co
     bool prefilter = length >= 64 && (uint64_t)amount * 2 <= length;
     us.resize(length);
     ys.resize(length);
+    // 1 / w for small integer weights (column scores) from a table of the very same quotients: a division less per key
+    static const std::vector<double> inv_small = [] {
+        std::vector<double> t(1024);
+        for (int k = 0; k < 1024; k++) t[(size_t)k] = 1.0 / (double)k;
+        return t;
+    }();
     for (uint32_t i = 0; i < length; i++) {
         const double w = weights[i];
         if (!(w >= 0.0)) throw std::runtime_error("invalid weight");
         us[i] = rng.gen_f64();
-        ys[i] = 1.0 / w;
+        const int wi = w < 1024.0 ? (int)w : -1;
+        ys[i] = (wi >= 0 && (double)wi == w) ? inv_small[(size_t)wi] : 1.0 / w;
         prefilter = prefilter && w >= 1.0;
     }
     if (!prefilter) {

@@ -166,15 +166,16 @@ def test_gen_range_is_in_range_and_covers():
 
 
 def test_rng_stream_without_avx2_lookahead():
-    # the refill has two code paths (AVX2: eight blocks at once with a look-ahead buffer; otherwise four): same words
+    # the refill has three code paths (AVX-512: sixteen blocks at once with a look-ahead buffer; AVX2: eight; otherwise
+    # four): same words, including u64 draws that straddle a refill (the odd u32 draw shifts the phase)
     import subprocess
     import sys
     code = ("import sys; sys.path.insert(0, %r); import hashlib, ls_amd;"
             "seed = hashlib.blake2b(b'42', digest_size=32).digest();"
-            "print(ls_amd.host_rng_script(seed, [(0, 0, 0)] * 300 + [(1, 0, 0)] * 100))") % os.path.dirname(ls_amd.__path__[0])
+            "print(ls_amd.host_rng_script(seed, ([(0, 0, 0)] * 300 + [(1, 0, 0)] * 100 + [(0, 0, 0)]) * 5))") % os.path.dirname(ls_amd.__path__[0])
     outs = []
-    for extra in ({}, {"LS_HOST_NO_AVX2": "1"}):
+    for extra in ({}, {"LS_HOST_NO_AVX512": "1"}, {"LS_HOST_NO_AVX2": "1"}):
         env = dict(os.environ, **extra)
         outs.append(subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True, text=True,
                                    timeout=120).stdout)
-    assert outs[0] == outs[1] and len(outs[0]) > 1000
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 1000
