@@ -108,7 +108,10 @@ inline void chacha20_block(const uint32_t key[8], uint32_t w12, uint32_t w13, ui
     for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
 }
 
-// rand_chacha::ChaCha20Rng over rand_core::block::BlockRng: 4 blocks (64 words) per refill.
+// rand_chacha::ChaCha20Rng over rand_core::block::BlockRng.  BlockRng hands out the words of consecutive ChaCha20
+// blocks in order -- next_u32 one word, next_u64 two consecutive words (low first), also across its 64-word buffer
+// boundary (rand_core block.rs: the index == len - 1 case) -- so the generator is the continuous word stream of the
+// block function, and this class keeps a position in that stream plus a pool of the blocks around it.
 class ChaCha20Rng {
 public:
     ChaCha20Rng() { std::memset(key_, 0, sizeof key_); }
@@ -125,38 +128,31 @@ public:
         blake2b_256(s.data(), s.size(), d);
         return ChaCha20Rng(d);
     }
-    uint32_t next_u32()
-    {
-        if (index_ >= 64) generate_and_set(0);
-        return buf_[index_++];
-    }
-    // BlockRng::next_u64: two consecutive words, low first; straddles a refill when one word is left
+    uint32_t next_u32() { return word(pos_++); }
     uint64_t next_u64()
     {
-        const size_t len = 64;
-        if (index_ < len - 1) {
-            const uint64_t lo = buf_[index_], hi = buf_[index_ + 1];
-            index_ += 2;
-            return (hi << 32) | lo;
-        } else if (index_ >= len) {
-            generate_and_set(2);
-            return ((uint64_t)buf_[1] << 32) | buf_[0];
-        } else {
-            const uint64_t x = buf_[len - 1];
-            generate_and_set(1);
-            const uint64_t y = buf_[0];
-            return (y << 32) | x;
-        }
+        const uint64_t lo = word(pos_), hi = word(pos_ + 1);
+        pos_ += 2;
+        return (hi << 32) | lo;
     }
     // Standard f64: 53 random bits scaled into [0, 1)
     double gen_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
-    uint64_t words_drawn() const { return counter_ * 16 - (64 - (index_ > 64 ? 64 : index_)); }
+    uint64_t words_drawn() const { return pos_; }
 
 private:
-    // One 32-bit lane per block (compiler vector extension).  A refill consumes four blocks (BlockRng's 64-word
-    // buffer); where the host has AVX2 / AVX-512, eight / sixteen blocks are produced at once and the later ones wait in ahead_ --
-    // the word sequence is that of chacha20_block called block by block (tests/test_host_rng.py compares them).
-#define LS_CHACHA_LANES(L, OUT)                                                                      \
+    // word k of the stream = word k mod 16 of block k / 16.  The pool holds pool_blocks_ consecutive blocks from
+    // pool_first_ on, WORD-MAJOR (pool_[w * 16 + b] = word w of block pool_first_ + b): that is how the lanes of the
+    // vectorised block function lie, so a refill stores its sixteen vectors as they are -- no transposition.
+    uint32_t word(uint64_t k)
+    {
+        const uint64_t blk = k >> 4;
+        if (blk - pool_first_ >= pool_blocks_) refill(blk);
+        return pool_[(size_t)(k & 15) * 16 + (size_t)(blk - pool_first_)];
+    }
+    // One 32-bit lane per block (compiler vector extension): four blocks at a time, eight with AVX2, sixteen with
+    // AVX-512 (single-instruction rotates).  The word sequence is that of chacha20_block called block by block
+    // (tests/test_host_rng.py compares the three paths and pins the stream to OpenSSL's ChaCha20).
+#define LS_CHACHA_LANES(L)                                                                           \
     typedef uint32_t vL __attribute__((vector_size(4 * L)));                                        \
     vL s[16], x[16];                                                                                 \
     const uint32_t sigma[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};                  \
@@ -164,7 +160,7 @@ private:
     for (int i = 0; i < 8; i++) s[4 + i] = vL{} + key_[i];                                           \
     s[12] = vL{}; s[13] = vL{}; s[14] = vL{}; s[15] = vL{};                                          \
     for (int b = 0; b < L; b++) {                                                                    \
-        const uint64_t c = counter_ + (uint64_t)b;                                                   \
+        const uint64_t c = first + (uint64_t)b;                                                      \
         s[12][b] = (uint32_t)c;                                                                      \
         s[13][b] = (uint32_t)(c >> 32);                                                              \
     }                                                                                                \
@@ -175,17 +171,17 @@ private:
     }                                                                                                \
     for (int i = 0; i < 16; i++) {                                                                   \
         const vL o = x[i] + s[i];                                                                    \
-        for (int b = 0; b < L; b++) (OUT)[16 * b + i] = o[b];                                        \
+        std::memcpy(pool_ + 16 * i, &o, sizeof o);                                                   \
     }
 #define LS_QR(a, b, c, d)                                                            \
     x[a] += x[b]; x[d] = ((x[d] ^ x[a]) << 16) | ((x[d] ^ x[a]) >> 16);              \
     x[c] += x[d]; x[b] = ((x[b] ^ x[c]) << 12) | ((x[b] ^ x[c]) >> 20);              \
     x[a] += x[b]; x[d] = ((x[d] ^ x[a]) << 8) | ((x[d] ^ x[a]) >> 24);               \
     x[c] += x[d]; x[b] = ((x[b] ^ x[c]) << 7) | ((x[b] ^ x[c]) >> 25);
-    void blocks4(uint32_t *out) { LS_CHACHA_LANES(4, out) }
+    void blocks4(uint64_t first) { LS_CHACHA_LANES(4) }
 #if defined(__x86_64__)
-    __attribute__((target("avx2"))) void blocks8(uint32_t *out) { LS_CHACHA_LANES(8, out) }
-    __attribute__((target("avx512f"))) void blocks16(uint32_t *out) { LS_CHACHA_LANES(16, out) } // rotates are single vprold
+    __attribute__((target("avx2"))) void blocks8(uint64_t first) { LS_CHACHA_LANES(8) }
+    __attribute__((target("avx512f"))) void blocks16(uint64_t first) { LS_CHACHA_LANES(16) }
     static bool have_avx2() // LS_HOST_NO_AVX2=1 forces the four-lane path (tests run all three)
     {
         static const bool v = __builtin_cpu_supports("avx2") && std::getenv("LS_HOST_NO_AVX2") == nullptr;
@@ -199,42 +195,21 @@ private:
 #endif
 #undef LS_QR
 #undef LS_CHACHA_LANES
-    void generate_and_set(size_t idx)
+    void refill(uint64_t first)
     {
-        if (ahead_left_ > 0) {
-            std::memcpy(buf_, ahead_ + 64 * ahead_pos_, sizeof buf_);
-            ahead_pos_++;
-            ahead_left_--;
-        } else {
 #if defined(__x86_64__)
-            if (have_avx512()) { // sixteen blocks at once: four refills
-                uint32_t tmp[256];
-                blocks16(tmp);
-                std::memcpy(buf_, tmp, sizeof buf_);
-                std::memcpy(ahead_, tmp + 64, 3 * sizeof buf_);
-                ahead_pos_ = 0;
-                ahead_left_ = 3;
-            } else if (have_avx2()) {
-                uint32_t tmp[128];
-                blocks8(tmp);
-                std::memcpy(buf_, tmp, sizeof buf_);
-                std::memcpy(ahead_, tmp + 64, sizeof buf_);
-                ahead_pos_ = 0;
-                ahead_left_ = 1;
-            } else
+        if (have_avx512()) { blocks16(first); pool_blocks_ = 16; }
+        else if (have_avx2()) { blocks8(first); pool_blocks_ = 8; }
+        else
 #endif
-                blocks4(buf_);
-        }
-        counter_ += 4; // blocks handed to buf_ so far (ahead_ holds the blocks from counter_ on: 4 * ahead_left_ of them)
-        index_ = idx;
+        { blocks4(first); pool_blocks_ = 4; }
+        pool_first_ = first;
     }
     uint32_t key_[8];
-    uint64_t counter_ = 0;
-    uint32_t buf_[64];
-    uint32_t ahead_[192];
-    int ahead_pos_ = 0, ahead_left_ = 0; // refills (64 words each) waiting in ahead_
-
-    size_t index_ = 64;
+    uint64_t pos_ = 0;        // next word of the stream
+    uint64_t pool_first_ = 0; // first block in the pool
+    uint64_t pool_blocks_ = 0;
+    alignas(64) uint32_t pool_[16 * 16];
 };
 
 // ----------------------------------------------------------- rand 0.8.5 sampling
