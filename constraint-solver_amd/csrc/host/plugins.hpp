@@ -14,6 +14,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -202,6 +203,10 @@ struct NQueensProblem {
     mutable std::vector<double> weights_buf;
 
     NQueensProblem(ls_ctx *c, size_t n, NqBatcher *b = nullptr) : ctx(c), board_size(n), batcher(b) {}
+    // Optional, set by the solver entry (which knows the context's internals): registers work the library may do
+    // while it waits for a launch of this context (here: computing the generator's key stream ahead); fn returns false
+    // once there is nothing left to do.  nullptr arguments clear it.
+    void (*set_idle_work)(ls_ctx *, bool (*fn)(void *), void *arg) = nullptr;
 
     static const int64_t *rows_dummy() { static const int64_t z = 0; return &z; }
     std::vector<int32_t> pack(const Solution &s) const
@@ -352,6 +357,18 @@ struct NQueensProblem {
             batcher->submit(&rq);
         } else {
             const int32_t nc = (int32_t)cols.size();
+            // while the launch is in flight the waiting thread computes the next iteration's key stream (the weighted
+            // sample draws one f64 per conflicting column: about 1100 per iteration at n = 4096)
+            struct IdleWork {
+                NQueensProblem *p;
+                IdleWork(NQueensProblem *q, R &g) : p(q)
+                {
+                    if constexpr (std::is_same<R, ChaCha20Rng>::value) {
+                        if (p->set_idle_work) p->set_idle_work(p->ctx, [](void *x) { return static_cast<ChaCha20Rng *>(x)->prefetch(); }, &g);
+                    }
+                }
+                ~IdleWork() { if (p->set_idle_work) p->set_idle_work(p->ctx, nullptr, nullptr); }
+            } idle(this, rng);
             check_rc(ctx, ls_nqueens_eval_batch_next(ctx, 1, (int32_t)rows.size(), rows.data(), &current.score, cols.data(),
                                                      &nc, nc, (int64_t)window, &res, next_cs.data()),
                      "ls_nqueens_eval_batch_next");

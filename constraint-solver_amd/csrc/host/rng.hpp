@@ -138,16 +138,33 @@ public:
     // Standard f64: 53 random bits scaled into [0, 1)
     double gen_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
     uint64_t words_drawn() const { return pos_; }
+    // Compute one more group of the key stream ahead of the position (idle time of the caller, e.g. while a launch is in
+    // flight): the stream is a pure function of (key, block number), so this changes nothing but when the work is done.
+    // Returns false once GROUPS groups lie ahead.
+    bool prefetch()
+    {
+        const uint64_t cur = pos_ >> 8;
+        if (hi_group_ < cur) hi_group_ = cur; // nothing valid ahead
+        if (hi_group_ - cur >= (uint64_t)GROUPS) return false;
+        generate_group(hi_group_);
+        hi_group_++;
+        return true;
+    }
 
 private:
-    // word k of the stream = word k mod 16 of block k / 16.  The pool holds pool_blocks_ consecutive blocks from
-    // pool_first_ on, WORD-MAJOR (pool_[w * 16 + b] = word w of block pool_first_ + b): that is how the lanes of the
-    // vectorised block function lie, so a refill stores its sixteen vectors as they are -- no transposition.
+    // word k of the stream = word k mod 16 of block k / 16.  The pool is a ring of GROUPS groups of sixteen blocks
+    // (group g = blocks 16 g .. 16 g + 15, in slot g mod GROUPS; valid: the position's group up to hi_group_), each
+    // WORD-MAJOR (slot[w * 16 + b] = word w of block 16 g + b): that is how the lanes of the vectorised block function
+    // lie, so a group is stored as its sixteen vectors -- no transposition.  Access is sequential.
+    static constexpr int GROUPS = 16;
     uint32_t word(uint64_t k)
     {
-        const uint64_t blk = k >> 4;
-        if (blk - pool_first_ >= pool_blocks_) refill(blk);
-        return pool_[(size_t)(k & 15) * 16 + (size_t)(blk - pool_first_)];
+        const uint64_t g = k >> 8;
+        if (g >= hi_group_) {
+            generate_group(g);
+            hi_group_ = g + 1;
+        }
+        return pool_[(size_t)(g % GROUPS)][(size_t)(((k & 15) << 4) | ((k >> 4) & 15))];
     }
     // One 32-bit lane per block (compiler vector extension): four blocks at a time, eight with AVX2, sixteen with
     // AVX-512 (single-instruction rotates).  The word sequence is that of chacha20_block called block by block
@@ -171,17 +188,18 @@ private:
     }                                                                                                \
     for (int i = 0; i < 16; i++) {                                                                   \
         const vL o = x[i] + s[i];                                                                    \
-        std::memcpy(pool_ + 16 * i, &o, sizeof o);                                                   \
+        std::memcpy(dst + 16 * i, &o, sizeof o);                                                     \
     }
 #define LS_QR(a, b, c, d)                                                            \
     x[a] += x[b]; x[d] = ((x[d] ^ x[a]) << 16) | ((x[d] ^ x[a]) >> 16);              \
     x[c] += x[d]; x[b] = ((x[b] ^ x[c]) << 12) | ((x[b] ^ x[c]) >> 20);              \
     x[a] += x[b]; x[d] = ((x[d] ^ x[a]) << 8) | ((x[d] ^ x[a]) >> 24);               \
     x[c] += x[d]; x[b] = ((x[b] ^ x[c]) << 7) | ((x[b] ^ x[c]) >> 25);
-    void blocks4(uint64_t first) { LS_CHACHA_LANES(4) }
+    // blocks first .. first + L - 1 into columns of a word-major slot (dst = slot + first block's column)
+    void blocks4(uint64_t first, uint32_t *dst) { LS_CHACHA_LANES(4) }
 #if defined(__x86_64__)
-    __attribute__((target("avx2"))) void blocks8(uint64_t first) { LS_CHACHA_LANES(8) }
-    __attribute__((target("avx512f"))) void blocks16(uint64_t first) { LS_CHACHA_LANES(16) }
+    __attribute__((target("avx2"))) void blocks8(uint64_t first, uint32_t *dst) { LS_CHACHA_LANES(8) }
+    __attribute__((target("avx512f"))) void blocks16(uint64_t first, uint32_t *dst) { LS_CHACHA_LANES(16) }
     static bool have_avx2() // LS_HOST_NO_AVX2=1 forces the four-lane path (tests run all three)
     {
         static const bool v = __builtin_cpu_supports("avx2") && std::getenv("LS_HOST_NO_AVX2") == nullptr;
@@ -195,21 +213,20 @@ private:
 #endif
 #undef LS_QR
 #undef LS_CHACHA_LANES
-    void refill(uint64_t first)
+    void generate_group(uint64_t g)
     {
+        uint32_t *slot = pool_[(size_t)(g % GROUPS)];
+        const uint64_t first = g << 4;
 #if defined(__x86_64__)
-        if (have_avx512()) { blocks16(first); pool_blocks_ = 16; }
-        else if (have_avx2()) { blocks8(first); pool_blocks_ = 8; }
-        else
+        if (have_avx512()) { blocks16(first, slot); return; }
+        if (have_avx2()) { blocks8(first, slot); blocks8(first + 8, slot + 8); return; }
 #endif
-        { blocks4(first); pool_blocks_ = 4; }
-        pool_first_ = first;
+        for (int q = 0; q < 4; q++) blocks4(first + 4 * (uint64_t)q, slot + 4 * q);
     }
     uint32_t key_[8];
-    uint64_t pos_ = 0;        // next word of the stream
-    uint64_t pool_first_ = 0; // first block in the pool
-    uint64_t pool_blocks_ = 0;
-    alignas(64) uint32_t pool_[16 * 16];
+    uint64_t pos_ = 0;      // next word of the stream
+    uint64_t hi_group_ = 0; // groups below this one (and not behind the position by GROUPS or more) are in the pool
+    alignas(64) uint32_t pool_[GROUPS][256];
 };
 
 // ----------------------------------------------------------- rand 0.8.5 sampling

@@ -374,8 +374,10 @@ static void widen_i32(const int32_t *src, int64_t *dst, int n)
 static int wait_done_word(ls_ctx *ctx, const unsigned long long *flag, unsigned long long seq)
 {
     const auto t0 = std::chrono::steady_clock::now();
+    bool idle_work = ctx->idle_hook != nullptr;
     for (unsigned spins = 0;; spins++) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return LS_OK;
+        if (idle_work) { idle_work = ctx->idle_hook(ctx->idle_arg); continue; } // a bounded piece of the caller's own work, then poll again
         if (ctx->wait_hook) ctx->wait_hook(ctx->wait_hook_arg); // another restart of this thread gets the core meanwhile
 #if defined(__x86_64__)
         else __builtin_ia32_pause();

@@ -150,6 +150,8 @@ struct ls_ctx {
     // nq_keys_dirty is raised while a call is being queued and stays up if it failed half-way: the next call then
     // clears the keys in stream order first.
     bool nq_keys_dirty = false;
+    bool (*idle_hook)(void *) = nullptr; // completion-word poll: work to do while waiting (returns false when none is left); set per call by the solver
+    void *idle_arg = nullptr;
     void (*wait_hook)(void *) = nullptr; // completion-word poll: called between polls (ls_multi_solver: switch to another restart's fibre on this thread)
     void *wait_hook_arg = nullptr;
     bool yield_while_waiting = false; // completion-word poll: sched_yield() after a short spin (set by ls_multi_solver when slots > cores; LS_YIELD)

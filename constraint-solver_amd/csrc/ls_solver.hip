@@ -118,6 +118,12 @@ private:
     int cur_ = -1;
 };
 
+static void solver_set_idle_work(ls_ctx *c, bool (*fn)(void *), void *arg)
+{
+    c->idle_hook = fn;
+    c->idle_arg = arg;
+}
+
 unsigned usable_cores()
 {
     unsigned cores = std::thread::hardware_concurrency();
@@ -180,6 +186,7 @@ int ls_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, const char *seed,
         s->ctx = ctx;
         s->kind = 0;
         s->nq.reset(new NQueensProblem(ctx, (size_t)board_size));
+        s->nq->set_idle_work = &solver_set_idle_work;
         // examples/nqueens/src/main.rs:36-87: one seed, two identically seeded generators
         const ChaCha20Rng solver_rng = ChaCha20Rng::from_seed_string(seed);
         const ChaCha20Rng ils_rng = ChaCha20Rng::from_seed_string(seed);
@@ -388,6 +395,7 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
                     const int r = next_restart.fetch_add(1);
                     if (r >= R || stop.load()) break;
                     NQueensProblem problem(ctx, m->board_size, lockstep ? &batcher : nullptr);
+                    problem.set_idle_work = &solver_set_idle_work;
                     const ChaCha20Rng solver_rng = ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]);
                     const ChaCha20Rng ils_rng = ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]);
                     LocalSearch<NQueensProblem> ls(&problem, p.local_search_max_iterations, (size_t)p.window_size,
