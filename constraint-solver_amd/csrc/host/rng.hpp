@@ -21,6 +21,9 @@
 #include <string>
 #include <unordered_set>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace lshost {
 
@@ -406,18 +409,24 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted_reference(
     return out;
 }
 
-// The `amount` best of `keyed` by (key descending, index ascending), in that order: 256-bucket histogram over the keys.
-inline void weighted_top(std::vector<WeightedKey> &keyed, uint32_t amount, std::vector<uint32_t> &out)
+// The `amount` best of `keyed` by (key descending, index ascending), in that order: a bucket histogram over the keys.
+// `key_floor` is a hint -- the buckets divide [key_floor, 1], keys below it share bucket 0 -- so that a pre-filtered
+// input (all keys in a narrow band under 1) still spreads over the buckets; short inputs use 64 buckets, not 256.
+inline void weighted_top(std::vector<WeightedKey> &keyed, uint32_t amount, std::vector<uint32_t> &out, double key_floor = 0.0)
 {
     static thread_local std::vector<WeightedKey> taken;
     static thread_local std::vector<uint8_t> bucket;
     const uint32_t length = (uint32_t)keyed.size();
-    constexpr int B = 256;
-    uint32_t hist[B] = {0};
+    constexpr int BMAX = 256;
+    const int B = length <= 512 ? 64 : BMAX;
+    if (!(key_floor >= 0.0 && key_floor < 1.0)) key_floor = 0.0;
+    const double scale = (double)B / (1.0 - key_floor);
+    uint32_t hist[BMAX];
+    for (int b = 0; b < B; b++) hist[b] = 0;
     bucket.resize(length);
     for (uint32_t i = 0; i < length; i++) {
         const double k = keyed[i].key; // in [0, 1]; NaN cannot occur (w >= 0, 0 <= u < 1)
-        int b = (int)(k * B);
+        int b = k <= key_floor ? 0 : (int)((k - key_floor) * scale);
         b = b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
         bucket[i] = (uint8_t)b;
         hist[b]++;
@@ -425,7 +434,7 @@ inline void weighted_top(std::vector<WeightedKey> &keyed, uint32_t amount, std::
     int t = B - 1; // threshold bucket: the buckets above it hold fewer than `amount` keys, with it at least `amount`
     uint32_t above = 0;
     while (above + hist[t] < amount) { above += hist[t]; t--; }
-    uint32_t start[B]; // where every bucket's elements start in `taken` (descending buckets)
+    uint32_t start[BMAX]; // where every bucket's elements start in `taken` (descending buckets)
     {
         uint32_t off = 0;
         for (int b = B - 1; b > t; b--) { start[b] = off; off += hist[b]; }
@@ -433,7 +442,7 @@ inline void weighted_top(std::vector<WeightedKey> &keyed, uint32_t amount, std::
     }
     taken.resize((size_t)above + hist[t]);
     {
-        uint32_t fill[B];
+        uint32_t fill[BMAX];
         for (int b = t; b < B; b++) fill[b] = start[b];
         for (uint32_t i = 0; i < length; i++) {
             const int b = bucket[i];
@@ -472,13 +481,94 @@ inline double approx_log2_unit(double u)
     return (double)e + f + 0.345 * f * (1.0 - f);
 }
 
+// One key's bracket of t = y log2(u): the upper end, and the histogram bucket of the lower end (1/32 wide over [-8, 0),
+// everything below -8 in bucket 0).  u == 0: key 0, below everything.
+inline void weighted_bracket(double u, double y, double &h, int &b)
+{
+    double l = -1.0e300;
+    h = -1.0e300;
+    if (u > 0.0) {
+        const double a = y * approx_log2_unit(u);
+        const double half = y * LOG2_APPROX_ERR + 1e-12 * (1.0 - a); // bracket of t, rounding of a included
+        l = a - half;
+        h = a + half;
+    }
+    double t = (l + 8.0) * 32.0;
+    t = t > 0.0 ? t : 0.0;
+    t = t < 255.0 ? t : 255.0;
+    b = (int)t;
+}
+
+#if defined(__x86_64__)
+// the same for eight keys at a time (the same IEEE operations in the same order: identical values)
+__attribute__((target("avx512f,avx512dq,avx512vl"))) inline void weighted_brackets_avx512(const double *us, const double *ys, uint32_t length,
+                                                                                       double *hi, int32_t *bkt)
+{
+    const __m512d v1 = _mm512_set1_pd(1.0), vk = _mm512_set1_pd(0.345), verr = _mm512_set1_pd(LOG2_APPROX_ERR), veps = _mm512_set1_pd(1e-12),
+                  vneg = _mm512_set1_pd(-1.0e300), v8 = _mm512_set1_pd(8.0), v32 = _mm512_set1_pd(32.0), v0 = _mm512_setzero_pd(),
+                  v255 = _mm512_set1_pd(255.0);
+    const __m512i mant = _mm512_set1_epi64(0x000fffffffffffffll), onebits = _mm512_set1_epi64(0x3ff0000000000000ll), bias = _mm512_set1_epi64(1023);
+    uint32_t i = 0;
+    for (; i + 8 <= length; i += 8) {
+        const __m512d u = _mm512_loadu_pd(us + i), y = _mm512_loadu_pd(ys + i);
+        const __m512i bits = _mm512_castpd_si512(u);
+        const __m512d e = _mm512_cvtepi64_pd(_mm512_sub_epi64(_mm512_srli_epi64(bits, 52), bias));
+        const __m512d m = _mm512_castsi512_pd(_mm512_or_si512(_mm512_and_si512(bits, mant), onebits));
+        const __m512d f = _mm512_sub_pd(m, v1);
+        const __m512d lg = _mm512_add_pd(_mm512_add_pd(e, f), _mm512_mul_pd(_mm512_mul_pd(vk, f), _mm512_sub_pd(v1, f)));
+        const __m512d a = _mm512_mul_pd(y, lg);
+        const __m512d half = _mm512_add_pd(_mm512_mul_pd(y, verr), _mm512_mul_pd(veps, _mm512_sub_pd(v1, a)));
+        const __mmask8 pos = _mm512_cmp_pd_mask(u, v0, _CMP_GT_OQ);
+        const __m512d l = _mm512_mask_blend_pd(pos, vneg, _mm512_sub_pd(a, half));
+        const __m512d h = _mm512_mask_blend_pd(pos, vneg, _mm512_add_pd(a, half));
+        _mm512_storeu_pd(hi + i, h);
+        __m512d t = _mm512_mul_pd(_mm512_add_pd(l, v8), v32);
+        t = _mm512_mask_blend_pd(_mm512_cmp_pd_mask(t, v0, _CMP_GT_OQ), v0, t);
+        t = _mm512_mask_blend_pd(_mm512_cmp_pd_mask(t, v255, _CMP_LT_OQ), v255, t);
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(bkt + i), _mm512_cvttpd_epi32(t));
+    }
+    for (; i < length; i++) {
+        int b;
+        weighted_bracket(us[i], ys[i], hi[i], b);
+        bkt[i] = b;
+    }
+}
+
+// indices i with hi[i] >= cut, ascending
+__attribute__((target("avx512f,avx512dq,avx512vl"))) inline uint32_t weighted_filter_avx512(const double *hi, uint32_t length, double cut, uint32_t *idx)
+{
+    const __m512d vcut = _mm512_set1_pd(cut);
+    __m256i cur = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+    const __m256i eight = _mm256_set1_epi32(8);
+    uint32_t n = 0, i = 0;
+    for (; i + 8 <= length; i += 8) {
+        const __mmask8 keep = _mm512_cmp_pd_mask(_mm512_loadu_pd(hi + i), vcut, _CMP_GE_OQ);
+        _mm256_mask_compressstoreu_epi32(idx + n, keep, cur);
+        n += (uint32_t)__builtin_popcount((unsigned)keep);
+        cur = _mm256_add_epi32(cur, eight);
+    }
+    for (; i < length; i++)
+        if (hi[i] >= cut) idx[n++] = i;
+    return n;
+}
+
+inline bool weighted_have_avx512()
+{
+    static const bool v = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl") &&
+                          std::getenv("LS_HOST_NO_AVX512") == nullptr && std::getenv("LS_HOST_NO_AVX2") == nullptr;
+    return v;
+}
+#endif
+
 template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, const std::vector<double> &weights, uint32_t amount)
 {
     const uint32_t length = (uint32_t)weights.size();
     if (amount == 0) return {};
     if (amount > length) throw std::runtime_error("`amount` of samples must be less than or equal to `length`");
     static thread_local std::vector<WeightedKey> keyed;
-    static thread_local std::vector<double> us, ys, lo, hi;
+    static thread_local std::vector<double> us, ys, hi;
+    static thread_local std::vector<int32_t> bkt;
+    static thread_local std::vector<uint32_t> idx;
     // Pre-filter (pays when few of many are wanted): most keys cannot reach the top `amount`, and that can be PROVEN
     // from a cheap bracket of t_i = y_i log2(u_i) (key_i = 2^t_i up to pow's < 1 ulp error): if hi_i lies below the
     // amount-th largest lo_j by more than 1e-9, at least `amount` keys are strictly larger than key_i whatever the
@@ -501,39 +591,48 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, co
         ys[i] = (wi >= 0 && (double)wi == w) ? inv_small[(size_t)wi] : 1.0 / w;
         prefilter = prefilter && w >= 1.0;
     }
+    double key_floor = 0.0; // where the surviving keys start (a hint for the bucket mapping of weighted_top)
     if (!prefilter) {
         keyed.resize(length);
         for (uint32_t i = 0; i < length; i++) keyed[i] = WeightedKey{std::pow(us[i], ys[i]), i};
     } else {
-        lo.resize(length);
         hi.resize(length);
+        bkt.resize(length);
+        idx.resize(length);
         constexpr int B = 256; // histogram of the lower brackets over [-8, 0), 1/32 wide; everything below -8 in bucket 0
         uint32_t hist[B] = {0};
-        for (uint32_t i = 0; i < length; i++) {
-            double l = -1.0e300, h = -1.0e300; // u == 0: key 0, below everything
-            if (us[i] > 0.0) {
-                const double a = ys[i] * approx_log2_unit(us[i]);
-                const double half = ys[i] * LOG2_APPROX_ERR + 1e-12 * (1.0 - a); // bracket of t, rounding of a included
-                l = a - half;
-                h = a + half;
+#if defined(__x86_64__)
+        const bool wide = weighted_have_avx512();
+        if (wide) weighted_brackets_avx512(us.data(), ys.data(), length, hi.data(), bkt.data());
+        else
+#endif
+            for (uint32_t i = 0; i < length; i++) {
+                int b;
+                weighted_bracket(us[i], ys[i], hi[i], b);
+                bkt[i] = b;
             }
-            lo[i] = l;
-            hi[i] = h;
-            int b = l <= -8.0 ? 0 : (int)((l + 8.0) * 32.0);
-            b = b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
-            hist[b]++;
-        }
+        for (uint32_t i = 0; i < length; i++) hist[bkt[i]]++;
         int t = B - 1;
         uint32_t above = 0;
         while (t > 0 && above + hist[t] < amount) { above += hist[t]; t--; }
         // at least `amount` lower brackets are >= the lower edge of bucket t (bucket 0 has no lower edge: keep everything)
         const double cut = t == 0 ? -2.0e300 : (double)t / 32.0 - 8.0 - 1e-9;
-        keyed.clear();
-        for (uint32_t i = 0; i < length; i++)
-            if (hi[i] >= cut) keyed.push_back(WeightedKey{std::pow(us[i], ys[i]), i});
+        uint32_t n_keep = 0;
+#if defined(__x86_64__)
+        if (wide) n_keep = weighted_filter_avx512(hi.data(), length, cut, idx.data());
+        else
+#endif
+            for (uint32_t i = 0; i < length; i++)
+                if (hi[i] >= cut) idx[n_keep++] = i;
+        keyed.resize(n_keep);
+        for (uint32_t j = 0; j < n_keep; j++) {
+            const uint32_t i = idx[j];
+            keyed[j] = WeightedKey{std::pow(us[i], ys[i]), i};
+        }
+        if (t > 0) key_floor = std::exp2(cut);
     }
     std::vector<uint32_t> out;
-    weighted_top(keyed, amount, out);
+    weighted_top(keyed, amount, out, key_floor);
     return out;
 }
 

@@ -53,7 +53,7 @@ int main(){
                 if (hi[i] >= cut) keyed.push_back(WeightedKey{std::pow(us[i], ys[i]), i});
             auto a4 = now();
             std::vector<uint32_t> out;
-            weighted_top(keyed, amount, out);
+            weighted_top(keyed, amount, out, t > 0 ? std::exp2(cut) : 0.0);
             auto a5 = now();
             acc += out[0] + keyed.size();
             sec[0] += us_of(a0, a1); sec[1] += us_of(a1, a2); sec[2] += us_of(a2, a3); sec[3] += us_of(a3, a4); sec[4] += us_of(a4, a5);
