@@ -266,6 +266,39 @@ struct NQueensProblem {
         return tot;
     }
 
+    // the columns with a non-zero score and their sampling weights score + 1e-4 (lib.rs:184-190), in column order
+#if defined(__x86_64__)
+    __attribute__((target("avx512f,avx512dq,avx512vl"))) static size_t nonzero_columns_avx512(const int64_t *cs, size_t n, uint32_t *cols, double *weights)
+    {
+        const __m512d eps = _mm512_set1_pd(1e-4);
+        const __m512i zero = _mm512_setzero_si512();
+        __m256i cur = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+        const __m256i eight = _mm256_set1_epi32(8);
+        size_t k = 0, c = 0;
+        for (; c + 8 <= n; c += 8) {
+            const __m512i v = _mm512_loadu_si512(cs + c);
+            const __mmask8 m = _mm512_cmpneq_epi64_mask(v, zero);
+            _mm256_mask_compressstoreu_epi32(cols + k, m, cur);
+            _mm512_mask_compressstoreu_pd(weights + k, m, _mm512_add_pd(_mm512_cvtepi64_pd(v), eps));
+            k += (size_t)__builtin_popcount((unsigned)m);
+            cur = _mm256_add_epi32(cur, eight);
+        }
+        for (; c < n; c++)
+            if (cs[c] != 0) { cols[k] = (uint32_t)c; weights[k] = (double)cs[c] + 1e-4; k++; }
+        return k;
+    }
+#endif
+    static size_t nonzero_columns(const int64_t *cs, size_t n, uint32_t *cols, double *weights)
+    {
+#if defined(__x86_64__)
+        if (weighted_have_avx512()) return nonzero_columns_avx512(cs, n, cols, weights);
+#endif
+        size_t k = 0;
+        for (size_t c = 0; c < n; c++)
+            if (cs[c] != 0) { cols[k] = (uint32_t)c; weights[k] = (double)cs[c] + 1e-4; k++; }
+        return k;
+    }
+
     // NQueensMoveProposer::iter_local_moves, the part before the iterator (lib.rs:182-205):
     // columns with conflicts, Efraimidis-Spirakis weighted sample of `amount`, then a random
     // number of them in choose_multiple order.  Empty result <=> `random_cols == None`.
@@ -274,13 +307,11 @@ struct NQueensProblem {
         const std::vector<int64_t> &cs = col_scores(start, nullptr);
         std::vector<uint32_t> &conflict_cols = conflict_cols_buf;
         std::vector<double> &weights = weights_buf;
-        conflict_cols.clear();
-        weights.clear();
-        for (size_t c = 0; c < cs.size(); c++)
-            if (cs[c] != 0) {
-                conflict_cols.push_back((uint32_t)c);
-                weights.push_back((double)cs[c] + 1e-4);
-            }
+        conflict_cols.resize(cs.size());
+        weights.resize(cs.size());
+        const size_t n_conflict = nonzero_columns(cs.data(), cs.size(), conflict_cols.data(), weights.data());
+        conflict_cols.resize(n_conflict);
+        weights.resize(n_conflict);
         if (conflict_cols.empty()) return {};
         size_t amount = start.size() / 20;
         if (amount < 1) amount = 1;
