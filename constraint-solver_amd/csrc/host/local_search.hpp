@@ -147,7 +147,10 @@ public:
     SS execute(const typename P::Solution &start, uint64_t allow_no_improvement_for)
     {
         SS current{p_->score(start), start};
-        SS best = current;
+        // `best` of the reference (:303) is kept lazily: along a descent it IS the current solution, and copying a
+        // 32 KB board per improving iteration buys nothing -- it is copied out when the walk first moves off it.
+        SS best;
+        bool best_is_current = true;
         uint64_t no_improvement_for = 0;
         for (uint64_t it = 0; it < max_iterations_; it++) {
             history_.seen_solution(current);
@@ -159,9 +162,10 @@ public:
             ls_iterations++;
             if (p_->best_of_neighbourhood(current, rng_, window_size_, nb, history_)) {
                 if (nb.score < current.score) {
-                    best = nb;
+                    best_is_current = true; // best = nb, which becomes current below
                     no_improvement_for = 0;
                 } else {
+                    if (best_is_current) { best = current; best_is_current = false; }
                     no_improvement_for++;
                     if (no_improvement_for >= allow_no_improvement_for) break;
                 }
@@ -170,7 +174,7 @@ public:
                 break;
             }
         }
-        return best;
+        return best_is_current ? current : best;
     }
     uint64_t ls_iterations = 0;
 
