@@ -37,6 +37,7 @@ extern "C" {
     pub fn ls_ctx_synchronize(ctx: *mut ls_ctx) -> c_int;
     pub fn ls_ctx_set_nq_algo(ctx: *mut ls_ctx, algo: c_int) -> c_int;
     pub fn ls_ctx_get_nq_algo(ctx: *const ls_ctx, algo: *mut c_int) -> c_int;
+    pub fn ls_ctx_get_counters(ctx: *const ls_ctx, out: *mut u64) -> c_int;
     pub fn ls_ctx_device_info(ctx: *const ls_ctx, n_cus: *mut c_int, wave_size: *mut c_int, clock_khz: *mut c_int,
                               name: *mut c_char, name_cap: c_int) -> c_int;
     pub fn ls_nqueens_eval(ctx: *mut ls_ctx, n: i32, rows: *const i32, cur_score: i64, cols: *const i32, n_cols: i32,
@@ -107,6 +108,7 @@ extern "C" {
                                     cap: i32, len: *mut i32, have: *mut c_int) -> c_int;
     pub fn ls_multi_solver_get_stats(m: *const ls_multi_solver, ls_iterations: *mut u64, neighbours_scored: *mut u64,
                                      gpu_launches: *mut u64, rounds: *mut u64) -> c_int;
+    pub fn ls_multi_solver_get_counters(m: *const ls_multi_solver, out: *mut u64) -> c_int;
     pub fn ls_multi_solver_free(m: *mut ls_multi_solver) -> c_int;
     pub fn ls_host_hash_seed(seed: *const c_char, out32: *mut u8) -> c_int;
     pub fn ls_host_chacha20_block(key: *const u32, w12: u32, w13: u32, w14: u32, w15: u32, out16: *mut u32) -> c_int;

@@ -84,6 +84,33 @@ static int bind(ls_ctx *ctx)
     return LS_OK;
 }
 
+// The server a one-restart LS step of this context goes to: the attached slot of a shared server (ls_multi_solver), or the
+// context's own one-slot server, started on demand (and restarted when the board size changes).  *out stays null when the
+// step has to take the launch-per-call route (a shared server built for another board size).
+int nq_ctx_server(ls_ctx *ctx, int n, NqServer **out)
+{
+    *out = nullptr;
+    if (ctx->server && nq_server_n(ctx->server) == n) { *out = ctx->server; return LS_OK; }
+    if (ctx->server && !ctx->server_owned) return LS_OK;
+    if (ctx->server) { nq_server_destroy(ctx->server); ctx->server = nullptr; }
+    NqServer *s = nullptr;
+    const int rc = nq_server_create(ctx, n, 1, &s);
+    if (rc != LS_OK) return rc;
+    ctx->server = s; ctx->server_slot = 0; ctx->server_owned = true;
+    *out = s;
+    return LS_OK;
+}
+
+// ls_solver_create_nqueens: start the context's own server before the driver's first get_col_scores call, so that the
+// initial board is uploaded once and stays with the slot.
+int nq_ctx_prepare_server(ls_ctx *ctx, int n)
+{
+    if (ctx->nq_step_mode < 4 || !nq_server_supports(ctx, n)) return LS_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return LS_OK;
+    NqServer *s = nullptr;
+    return nq_ctx_server(ctx, n, &s);
+}
+
 } // namespace lsamd
 
 using namespace lsamd;
@@ -169,6 +196,8 @@ int ls_ctx_destroy(ls_ctx *ctx)
 {
     if (!ctx) return LS_OK;
     (void)hipSetDevice(ctx->device);
+    if (ctx->server && ctx->server_owned) nq_server_destroy(ctx->server); // the resident launch leaves before anything is freed
+    ctx->server = nullptr;
     (void)hipStreamSynchronize(ctx->stream);
     for_each_buf(ctx, [](DevBuf &b) { b.release(); });
     ctx->stage_in.release();
@@ -224,6 +253,20 @@ int ls_ctx_get_nq_algo(const ls_ctx *ctx, int *algo)
 {
     if (!ctx || !algo) return LS_ERR_INVALID;
     *algo = ctx->nq_algo;
+    return LS_OK;
+}
+
+int ls_ctx_get_counters(const ls_ctx *ctx, uint64_t out[LS_N_COUNTERS])
+{
+    if (!ctx || !out) return LS_ERR_INVALID;
+    for (int i = 0; i < LS_N_COUNTERS; i++) out[i] = 0;
+    if (ctx->server) {
+        unsigned long long c4[4];
+        nq_server_counters(ctx->server, c4);
+        for (int i = 0; i < 4; i++) out[i] = c4[i];
+    }
+    out[4] = ctx->n_done_fallbacks;
+    out[5] = ctx->n_resident_uploads;
     return LS_OK;
 }
 
@@ -338,7 +381,9 @@ __attribute__((target("avx2"))) static void nq_cs_after_move_avx2(const int32_t 
     cs[mc] = total;
 }
 
-static void nq_cs_after_move(const int32_t *rows, int32_t *cs, int n, int mc, int mv, int mq)
+} // extern "C"
+namespace lsamd {
+void nq_cs_after_move(const int32_t *rows, int32_t *cs, int n, int mc, int mv, int mq)
 {
     static const bool avx2 = __builtin_cpu_supports("avx2");
     if (avx2) { nq_cs_after_move_avx2(rows, cs, n, mc, mv, mq); return; }
@@ -353,6 +398,9 @@ static void nq_cs_after_move(const int32_t *rows, int32_t *cs, int n, int mc, in
     cs[mc] = total;
 }
 
+} // namespace lsamd
+extern "C" {
+
 __attribute__((target("avx2"))) static void widen_i32_avx2(const int32_t *src, int64_t *dst, int n)
 {
     int j = 0;
@@ -361,12 +409,17 @@ __attribute__((target("avx2"))) static void widen_i32_avx2(const int32_t *src, i
     for (; j < n; j++) dst[j] = src[j];
 }
 
-static void widen_i32(const int32_t *src, int64_t *dst, int n)
+} // extern "C"
+namespace lsamd {
+void widen_i32(const int32_t *src, int64_t *dst, int n)
 {
     static const bool avx2 = __builtin_cpu_supports("avx2");
     if (avx2) { widen_i32_avx2(src, dst, n); return; }
     for (int j = 0; j < n; j++) dst[j] = src[j];
 }
+
+} // namespace lsamd
+extern "C" {
 
 // Wait for a kernel's completion word (coherent host memory) instead of synchronising the stream: the poll sees the
 // word a PCIe write after the kernel's last store, a stream synchronisation costs a runtime round trip on top.
@@ -388,6 +441,7 @@ static int wait_done_word(ls_ctx *ctx, const unsigned long long *flag, unsigned 
         if ((spins & 0xfff) == 0xfff) {
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (dt > 0.002) { // far beyond any LS step: let the runtime tell whether the launch failed
+                ctx->n_done_fallbacks++;
                 LS_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return LS_OK;
                 return set_err(ctx, LS_ERR_HIP, "the LS-step kernel finished without publishing its completion word");
@@ -446,6 +500,7 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
             memcpy(sh, src, (size_t)n * 4);
             rs.valid[(size_t)r] = 1;
             rs.cs_valid[(size_t)r] = 0;
+            ctx->n_resident_uploads++;
             if (r < 64) fresh |= 1ull << r;
         }
         if (!cs_b) rs.cs_valid[(size_t)r] = 0; // nobody keeps the scores across this call
@@ -528,6 +583,15 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
             const int c = cols[(long long)r * max_cols + s];
             LS_REQUIRE(ctx, c >= 0 && c < n, "cols[%d][%d] = %d outside [0, %d)", r, s, c, n);
         }
+    }
+    if (!scores_out && n_restarts == 1 && ctx->nq_step_mode >= 4 && nq_step_eligible(ctx, n, max_cols, nq_clamp_window(window, max_cols, n))) {
+        // one restart, no score dump: the resident LS-step server (no launch, no copy; the board stays in the slot's LDS)
+        NqServer *srv = nullptr;
+        rc = nq_ctx_server(ctx, n, &srv);
+        if (rc != LS_OK) return rc;
+        if (srv)
+            return nq_server_step(ctx, srv, ctx->server_slot, rows, cur_scores[0], cols, n_cols[0], nq_clamp_window(window, max_cols, n), results,
+                                  next_col_scores);
     }
     const size_t rows_b = (size_t)n_restarts * n * 4, cur_b = (size_t)n_restarts * 8,
                  cols_b = (size_t)n_restarts * max_cols * 4, nc_b = (size_t)n_restarts * 4,
@@ -696,6 +760,8 @@ int ls_nqueens_col_scores(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int3
     if (!all_in_range(rows, (long long)n_restarts * n, n))
         for (long long i = 0; i < (long long)n_restarts * n; i++)
             LS_REQUIRE(ctx, rows[i] >= 0 && rows[i] < n, "rows[%lld] = %d outside [0, %d)", i, rows[i], n);
+    if (n_restarts == 1 && ctx->nq_step_mode >= 4 && ctx->server && nq_server_n(ctx->server) == n && nq_server_supports(ctx, n))
+        return nq_server_col_scores(ctx, ctx->server, ctx->server_slot, rows, col_scores, scores); // the board stays with the slot
     const size_t rows_b = (size_t)n_restarts * n * 4, cs_b = (size_t)n_restarts * n * 8, t_b = (size_t)n_restarts * 8;
     LS_RESERVE(ctx, ctx->nq_rows, rows_b);
     LS_RESERVE(ctx, ctx->nq_colscores, cs_b);

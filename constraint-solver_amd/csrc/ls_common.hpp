@@ -129,6 +129,9 @@ struct NqResident {
     unsigned long long seq = 0;
 };
 
+// The resident LS-step server (nq_server.hip): one never-ending launch per device whose workgroups are the slots.
+struct NqServer;
+
 struct SchedInstance {
     bool valid = false;
     int n_days_scored = 0, n_days_stored = 0, start_weekday = 0, n_employees = 0;
@@ -143,8 +146,14 @@ struct ls_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int nq_algo = LS_NQ_ALGO_AUTO;
-    int nq_step_mode = 3; // fused LS-step kernel (LS_NQ_STEP): 0 off, 1 through device staging copies, 2 zero-copy on pinned host memory +
-                          // stream sync, 3 = 2 + boards resident on the device, 16-bit column scores on the wire, polled completion word
+    int nq_step_mode = 4; // fused LS-step kernel (LS_NQ_STEP): 0 off, 1 through device staging copies, 2 zero-copy on pinned host memory +
+                          // stream sync, 3 = 2 + boards resident on the device, 16-bit column scores on the wire, polled completion word,
+                          // 4 (default) = one-restart host calls go to the resident LS-step server (nq_server.hip): no launch per call
+    lsamd::NqServer *server = nullptr; // the server this context's one-restart LS steps go to (own: started on demand; or a slot of a shared one)
+    int server_slot = 0;
+    bool server_owned = false;
+    unsigned long long n_done_fallbacks = 0;   // completion-word waits that fell back to hipStreamSynchronize (2 ms without the word)
+    unsigned long long n_resident_uploads = 0; // LS_NQ_STEP=3: boards uploaded because they were not the one resident on the device
     // Argmin keys: every entry of nq_keys holds NQ_KEY_EMPTY whenever no N-queens call is in flight (filled once, in
     // stream order, when the buffer is allocated; the finalize kernel puts back what the eval kernels touched).
     // nq_keys_dirty is raised while a call is being queued and stays up if it failed half-way: the next call then
@@ -187,6 +196,20 @@ struct ls_ctx {
 namespace lsamd {
 
 int set_err(const ls_ctx *ctx, int code, const char *fmt, ...);
+
+// nq_server.hip
+bool nq_server_supports(const ls_ctx *ctx, int n);
+int nq_server_create(ls_ctx *ctx, int n, int n_slots, NqServer **out);
+void nq_server_destroy(NqServer *s);
+int nq_server_n(const NqServer *s);
+int nq_server_slots(const NqServer *s);
+void nq_server_counters(const NqServer *s, unsigned long long out[4]); // requests, launches, waits that found the launch drained, boards uploaded
+int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int64_t cur_score, const int32_t *cols, int32_t n_cols,
+                   long long window, ls_nq_result *res, int64_t *next_col_scores);
+int nq_server_col_scores(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int64_t *col_scores, int64_t *total);
+// ls_api.hip
+int nq_ctx_server(ls_ctx *ctx, int n, NqServer **out);
+int nq_ctx_prepare_server(ls_ctx *ctx, int n);
 
 #define LS_HIP(ctx, call)                                                                   \
     do {                                                                                    \

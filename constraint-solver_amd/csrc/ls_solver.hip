@@ -37,6 +37,7 @@ struct ls_multi_solver {
     int n_slots = 16;                 // restarts in flight at once (create: 4 per usable core); further seeds queue behind them
     int mode = LS_MULTI_FREE_RUNNING; // LS_MULTI_FREE_RUNNING: a context per slot; LS_MULTI_LOCKSTEP: one batched launch per step
     uint64_t ls_iterations = 0, neighbours_scored = 0, gpu_launches = 0, rounds = 0;
+    uint64_t counters[LS_N_COUNTERS] = {0}; // ls_multi_solver_get_counters: the last run's
 };
 
 namespace {
@@ -185,6 +186,7 @@ int ls_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, const char *seed,
         std::unique_ptr<ls_solver> s(new ls_solver());
         s->ctx = ctx;
         s->kind = 0;
+        check_rc(ctx, lsamd::nq_ctx_prepare_server(ctx, (int)board_size), "LS-step server");
         s->nq.reset(new NQueensProblem(ctx, (size_t)board_size));
         s->nq->set_idle_work = &solver_set_idle_work;
         // examples/nqueens/src/main.rs:36-87: one seed, two identically seeded generators
@@ -368,6 +370,21 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
         if (lockstep && m->params.all_solution_iteration_expiry == 0)
             throw std::runtime_error("a History that keeps more than the current solution tabu (all_solution_iteration_expiry == 0) "
                                      "issues one-restart launches: use LS_MULTI_FREE_RUNNING");
+        // Free-running slots are the workgroups of ONE resident LS-step server launch (nq_server.hip): slot t's context sends its
+        // one-restart steps to workgroup t, no launch per LS iteration.  (LS_NQ_STEP <= 3, LS_NQ_ALGO_SCAN, n > 8192: a launch per call.)
+        struct SharedServer {
+            lsamd::NqServer *s = nullptr;
+            std::vector<ls_ctx *> owned; // per-slot contexts: destroyed after the server has left (hipHostFree waits for resident kernels)
+            ~SharedServer()
+            {
+                if (s) lsamd::nq_server_destroy(s);
+                for (ls_ctx *c : owned) if (c) (void)ls_ctx_destroy(c);
+            }
+        } shared;
+        shared.owned.assign((size_t)T, nullptr);
+        if (!lockstep && m->ctx->nq_step_mode >= 4 && lsamd::nq_server_supports(m->ctx, (int)m->board_size) && T <= 240)
+            check_rc(m->ctx, lsamd::nq_server_create(m->ctx, (int)m->board_size, T, &shared.s), "LS-step server");
+        std::vector<uint64_t> fallbacks((size_t)T, 0), reuploads((size_t)T, 0);
         NqBatcher batcher(m->ctx, (int32_t)m->board_size, T);
         std::vector<std::string> errors((size_t)T);
         std::vector<uint64_t> ls_it((size_t)R, 0), scored((size_t)R, 0), rounds((size_t)R, 0), launches((size_t)T, 0);
@@ -380,10 +397,19 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
                 ls_ctx *ctx = m->ctx;
                 if (!lockstep && t > 0) { // free-running: one context (stream, staging block) per slot; slot 0 uses the caller's
                     check_rc(nullptr, ls_ctx_create(m->ctx->device, &own), "ls_ctx_create");
+                    shared.owned[(size_t)t] = own;
                     own->nq_algo = m->ctx->nq_algo;
                     own->nq_step_mode = m->ctx->nq_step_mode;
                     ctx = own;
                 }
+                struct Attach { // this slot's workgroup of the shared server (slot 0: the caller's context lends itself for the run)
+                    ls_ctx *c; lsamd::NqServer *s0; int slot0; bool owned0; bool on;
+                    ~Attach() { if (on) { c->server = s0; c->server_slot = slot0; c->server_owned = owned0; } }
+                } attach{ctx, ctx->server, ctx->server_slot, ctx->server_owned, shared.s != nullptr};
+                if (shared.s) { ctx->server = shared.s; ctx->server_slot = t; ctx->server_owned = false; }
+                const uint64_t fb0 = ctx->n_done_fallbacks, ru0 = ctx->n_resident_uploads;
+                struct Count { ls_ctx *c; uint64_t *fb, *ru; uint64_t fb0, ru0; ~Count() { *fb = c->n_done_fallbacks - fb0; *ru = c->n_resident_uploads - ru0; } }
+                    count{ctx, &fallbacks[(size_t)t], &reuploads[(size_t)t], fb0, ru0};
                 // more slots than host threads: a waiting slot hands its thread to a slot that has host work to do
                 struct Restore {
                     ls_ctx *c; void (*h)(void *); void *a;
@@ -431,7 +457,6 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
                 batcher.fail(errors[(size_t)t]);
             }
             batcher.thread_done();
-            if (own) (void)ls_ctx_destroy(own);
         };
         // free-running slots beyond the host's cores share threads as cooperative fibres (slot t on thread t mod n_threads)
         const int hwc = (int)usable_cores();
@@ -455,6 +480,13 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
         }
         if (lockstep) m->gpu_launches = batcher.launches;
         else for (int t = 0; t < T; t++) m->gpu_launches += launches[(size_t)t];
+        for (uint64_t &c : m->counters) c = 0;
+        if (shared.s) {
+            unsigned long long c4[4];
+            lsamd::nq_server_counters(shared.s, c4);
+            for (int i = 0; i < 4; i++) m->counters[i] = c4[i];
+        }
+        for (int t = 0; t < T; t++) { m->counters[4] += fallbacks[(size_t)t]; m->counters[5] += reuploads[(size_t)t]; }
         return LS_OK;
     });
 }
@@ -477,6 +509,13 @@ int ls_multi_solver_get_stats(const ls_multi_solver *m, uint64_t *ls_iterations,
     if (neighbours_scored) *neighbours_scored = m->neighbours_scored;
     if (gpu_launches) *gpu_launches = m->gpu_launches;
     if (rounds) *rounds = m->rounds;
+    return LS_OK;
+}
+
+int ls_multi_solver_get_counters(const ls_multi_solver *m, uint64_t out[LS_N_COUNTERS])
+{
+    if (!m || !out) return LS_ERR_INVALID;
+    for (int i = 0; i < LS_N_COUNTERS; i++) out[i] = m->counters[i];
     return LS_OK;
 }
 

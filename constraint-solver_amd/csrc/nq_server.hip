@@ -1,0 +1,658 @@
+// nq_server.hip — the resident LS-step server: ONE launch per device whose workgroups are the slots.
+//
+// What it replaces: one kernel launch + dispatch + completion poll per LS iteration (local_search.rs:309-341 calls the
+// neighbourhood pipeline :315-325 once per iteration; at n = 4096 that was a 6 us kernel inside a 14.4 us round trip,
+// DESIGN 3.3b).  Here workgroup s of a never-relaunched kernel owns slot s: it keeps the slot's board and count tables in
+// ITS LDS between requests, polls a 64-byte mailbox line in coherent pinned host memory, runs nq_step_kernel's body on a
+// request (score the candidates take(window) can reach, (score, board) minimum, apply the move to the LDS board and
+// tables) and answers with one 32-byte line.  A steady-state LS iteration moves 64 bytes down and 32 bytes up and
+// nothing else; a board the slot does not hold (after a perturbation, iterated_local_search.rs:192-194, or after a
+// relaunch) is read once from the slot's pinned shadow copy.
+//
+// Mailbox protocol (no ordering assumption on the PCIe reads of one line, no atomics over PCIe): every dword of a line is
+// (tag16 << 16 | payload16); the writer gives all dwords of one message the same new tag, the reader takes a snapshot
+// with one dword per lane and accepts it only if all tags are equal (a torn snapshot mixes two tags and is simply polled
+// again).  Bulk data (a fresh board, more than 10 proposed columns, the column scores of a fresh board) lives in the
+// slot's pinned block and is written before the line that announces it.
+//
+// Leaving: the kernel must never outlive its use.  Every workgroup leaves (a) on a QUIT request, (b) when the launch's
+// quit word is raised, which any workgroup does once NO slot has been served for `idle_ticks` (default 2 ms) or the
+// launch is older than `limit_ticks` (2 s) -- so a dead or paused host cannot leave a kernel spinning -- and the last one
+// out publishes the launch generation to a host word.  The host relaunches on demand: a request posted while the
+// kernel drains is found by the next launch (the last SERVED tag is read back from the response line).
+//
+// The launch lives on its own hardware queue (a CU-masked stream; fallback: high priority): HIP multiplexes ordinary
+// streams onto a few queues and a queue runs its packets in order, so a resident kernel on an ordinary stream blocks
+// whatever stream shares its queue (tools/server_probe.hip: the 6th stream created afterwards waited 0.46 s).
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <sched.h>
+
+#include "nq_device.hpp"
+
+namespace lsamd {
+
+constexpr int SRV_INLINE_COLS = 10;
+constexpr unsigned SRV_F_STEP = 1u, SRV_F_WANT_CS = 2u, SRV_F_QUIT = 4u, SRV_F_EXT_COLS = 8u;
+
+struct NqSrvCtl {               // device memory, one per server
+    unsigned long long quit_gen;      // == the running launch's generation: everybody leaves
+    unsigned long long last_activity; // wall clock (100 MHz) of the last served request of any slot
+    unsigned exited;                  // workgroups of the running launch that have left
+    unsigned pad;
+};
+
+struct NqSrvArgs {
+    const unsigned *req;          // [slots][16]  pinned host: request lines
+    unsigned *resp;               // [slots][16]  pinned host: response lines
+    const int *cols_ext;          // [slots][NQ_STEP_MAX_SLOTS] pinned host
+    const int *shadow;            // [slots][n_pad] pinned host: the board of the slot's current request
+    unsigned *cs16;               // [slots][n_pad / 2] pinned host: column scores, two u16 per word
+    NqSrvCtl *ctl;
+    unsigned long long *exit_gen; // pinned host
+    unsigned long long gen, idle_ticks, limit_ticks;
+    int n, n_pad;
+};
+
+template <class T> __device__ __forceinline__ T sys_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// One workgroup = one slot.  Request line: d0 flags, d1 n_cols, d2-3 window, d4-5 board id, d6-15 the first ten columns.
+// Response line: d0 bit 0 "has a move", d1-2 n_scored, d3 winner slot, d4 winner value, d5-6 delta + bias (STEP) or the
+// board's score (no STEP), d7 zero.
+template <bool PAIRS>
+__global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[]; // tables | rows[n] | slot records[NQ_STEP_MAX_SLOTS]
+    __shared__ unsigned s_req[16];
+    __shared__ unsigned long long s_best[16];
+    __shared__ int s_sum[16], s_cnt[16];
+    __shared__ int s_leave;
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    const int n = a.n;
+    const int words = PAIRS ? (((6 * n + 4) >> 1) + 3) & ~3 : (((5 * n + 1) >> 1) + 3) & ~3;
+    unsigned *s_t16 = s_dyn;
+    int *s_rows = reinterpret_cast<int *>(s_dyn + words);
+    int4 *s_slot = reinterpret_cast<int4 *>(s_rows + ((n + 3) & ~3));
+    const int oR1 = n, oA = PAIRS ? 2 * n : n, oB = PAIRS ? 4 * n + 2 : 3 * n;
+    const unsigned *req = a.req + (size_t)blockIdx.x * 16;
+    unsigned *resp = a.resp + (size_t)blockIdx.x * 16;
+    const int *shadow = a.shadow + (size_t)blockIdx.x * a.n_pad;
+    const int *cols_ext = a.cols_ext + (size_t)blockIdx.x * NQ_STEP_MAX_SLOTS;
+    unsigned *cs16 = a.cs16 + (size_t)blockIdx.x * (a.n_pad >> 1);
+
+    unsigned lds_board = 0;      // id of the board this workgroup holds in LDS (0: none); block-uniform
+    // wave 0's poll state
+    unsigned last_tag = 0;
+    unsigned long long t_start = 0, t_served = 0;
+    if (wib == 0) {
+        t_start = t_served = wall_clock64();
+        last_tag = sys_load(resp) >> 16; // the last request an earlier launch answered
+        last_tag = __builtin_amdgcn_readfirstlane(last_tag);
+        if (lane == 0) atomicMax(&a.ctl->last_activity, t_start); // nobody reads a stale activity stamp of an earlier launch
+    }
+    for (;;) {
+        if (wib == 0) {
+            int leave = 0;
+            for (unsigned polls = 1;; polls++) {
+                unsigned v = 0;
+                unsigned long long q = 0;
+                if (lane < 16) v = sys_load(req + lane);
+                if (lane == 16) q = __hip_atomic_load(&a.ctl->quit_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned tag = v >> 16;
+                const unsigned t0 = __builtin_amdgcn_readfirstlane(tag);
+                const bool whole = __builtin_amdgcn_ballot_w64(lane < 16 && tag != t0) == 0;
+                if (whole && t0 != last_tag && t0 != 0) {
+                    if (lane < 16) s_req[lane] = v & 0xffffu;
+                    last_tag = t0;
+                    leave = (__builtin_amdgcn_readfirstlane(v) & SRV_F_QUIT) ? 1 : 0;
+                    break;
+                }
+                const unsigned qlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)q, 16);
+                const unsigned qhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(q >> 32), 16);
+                if ((((unsigned long long)qhi << 32) | qlo) == a.gen) { leave = 1; break; }
+                const unsigned long long now = wall_clock64();
+                if ((polls & 15u) == 0) { // nobody served for idle_ticks, or the launch has reached its age limit: everybody leaves
+                    unsigned long long la = 0;
+                    if (lane == 0) la = __hip_atomic_load(&a.ctl->last_activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned llo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)la);
+                    const unsigned lhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(la >> 32));
+                    la = ((unsigned long long)lhi << 32) | llo;
+                    if ((now > la && now - la > a.idle_ticks) || now - t_start > a.limit_ticks) {
+                        if (lane == 0) __hip_atomic_store(&a.ctl->quit_gen, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        leave = 1;
+                        break;
+                    }
+                }
+                // a slot in the middle of a walk is asked again within microseconds; one that has been quiet for longer polls less often
+                if (now - t_served > 20000) __builtin_amdgcn_s_sleep(64);      // > 200 us quiet: ~2 us between polls
+                else if (now - t_served > 2000) __builtin_amdgcn_s_sleep(8);   // > 20 us quiet
+                else __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) s_leave = leave;
+        }
+        __syncthreads(); // B1: the request is in s_req; wave 0's LDS patches of the previous step are visible
+        if (s_leave) break;
+        const unsigned flags = s_req[0];
+        int ncols = (int)s_req[1];
+        const long long window = (long long)(s_req[2] | (s_req[3] << 16));
+        const unsigned board = s_req[4] | (s_req[5] << 16);
+        ncols = ncols > NQ_STEP_MAX_SLOTS ? NQ_STEP_MAX_SLOTS : ncols;
+        const bool step = (flags & SRV_F_STEP) != 0, want_cs = (flags & SRV_F_WANT_CS) != 0;
+        const long long K = step ? nq_k_limit((long long)ncols * n, n, window) : 0;
+        const int n_slots = (int)((K + n - 1) / n);
+        int cv = -1;
+        if (tid < n_slots) {
+            if (flags & SRV_F_EXT_COLS) cv = sys_load(cols_ext + tid);
+            else if (tid < SRV_INLINE_COLS) cv = (int)s_req[6 + tid];
+        }
+        if (board != lds_board) { // block-uniform: the slot's board is not the one in LDS -- read it from the pinned shadow, rebuild the tables
+            int rv[NQ_STEP_MAX_N / 1024];
+#pragma unroll
+            for (int i = 0; i < NQ_STEP_MAX_N / 1024; i++) {
+                const int j = tid + 1024 * i;
+                rv[i] = j < n ? sys_load(shadow + j) : -1;
+            }
+            for (int i = tid; i < words; i += 1024) s_t16[i] = 0;
+#pragma unroll
+            for (int i = 0; i < NQ_STEP_MAX_N / 1024; i++) {
+                const int j = tid + 1024 * i;
+                if (j < n) s_rows[j] = rv[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NQ_STEP_MAX_N / 1024; i++) {
+                const int j = tid + 1024 * i, q = rv[i];
+                if (j < n && (unsigned)q < (unsigned)n) {
+                    tab16_inc(s_t16, q);
+                    if (PAIRS && q > 0) tab16_inc(s_t16, oR1 + q - 1);
+                    tab16_inc(s_t16, oA + (q - j + n));
+                    tab16_inc(s_t16, oB + (q + j));
+                }
+            }
+            if (PAIRS && tid == 0) atomicAdd(&s_t16[(oR1 + n - 1) >> 1], NQ_PAIR_SENTINEL << (16 * ((oR1 + n - 1) & 1)));
+            lds_board = board;
+            __syncthreads();
+        }
+        int my_scored = 0;
+        if (tid < n_slots) {
+            const int c = cv;
+            const int rc = (unsigned)c < (unsigned)n ? s_rows[c] : -1;
+            int conf_old = 0;
+            if ((unsigned)rc < (unsigned)n)
+                conf_old = tab16_get(s_t16, rc) + tab16_get(s_t16, oA + rc - c + n) + tab16_get(s_t16, oB + rc + c) - 3;
+            s_slot[tid] = make_int4(c, (unsigned)rc < (unsigned)n ? rc : -1, conf_old, 0);
+            my_scored = nq_slot_scored(tid, c, rc, n, window);
+        }
+        my_scored = wave_sum_i32(my_scored);
+        if (lane == 0) s_cnt[wib] = my_scored;
+        __syncthreads(); // B2
+        unsigned long long best = NQ_KEY_EMPTY;
+        if (step) { // block-uniform
+            if constexpr (PAIRS) {
+                long long n_whole = window / (n - 1);
+                if (n_whole > ncols) n_whole = ncols;
+                const long long rem = n_whole < ncols ? window - n_whole * (n - 1) : 0;
+                const int steps = (n + 127) >> 7;
+                int per_part = n_whole > 0 ? (int)((n_whole * steps + 15) / 16) : steps;
+                per_part = (per_part + 3) & ~3;
+                per_part = per_part > steps ? steps : (per_part < 4 ? 4 : per_part);
+                const int parts = (steps + per_part - 1) / per_part;
+                const int team = __builtin_amdgcn_readfirstlane(wib);
+                const int units = (int)n_whole * parts;
+                for (int u = team; u < units; u += 16) {
+                    const int slot = u / parts, part = u - slot * parts;
+                    const int4 si = s_slot[slot];
+                    const int c = __builtin_amdgcn_readfirstlane(si.x), rc = __builtin_amdgcn_readfirstlane(si.y),
+                              conf_old = __builtin_amdgcn_readfirstlane(si.z);
+                    if (rc < 0) continue;
+                    nq_pairs_unit<64, false>(s_t16, n, lane, c, rc, conf_old, slot, part * per_part, per_part, nullptr, 0, best);
+                }
+                if (rem > 0) { // the slot the window cuts: per-range loops, all lanes
+                    const int slot = (int)n_whole;
+                    const int4 si = s_slot[slot];
+                    const int c = si.x, rc = si.y, conf_old = si.z;
+                    if (rc >= 0) {
+                        const unsigned short *t16 = reinterpret_cast<const unsigned short *>(s_t16);
+                        const NqRanges rg = nq_ranges(0, n, rc, (long long)slot * (n - 1), window);
+                        unsigned m = NQ_KEY32_EMPTY;
+                        for (int v = rg.d0 + tid; v < rg.d1; v += 1024) {
+                            const unsigned kk = (((unsigned)t16[v] + (unsigned)t16[oA + v - c + n] + (unsigned)t16[oB + v + c]) << 15) | (unsigned)v;
+                            m = kk < m ? kk : m;
+                        }
+                        for (int v = rg.u0 + tid; v < rg.u1; v += 1024) {
+                            const unsigned kk = (((unsigned)t16[v] + (unsigned)t16[oA + v - c + n] + (unsigned)t16[oB + v + c]) << 15) | (unsigned)v;
+                            m = kk < m ? kk : m;
+                        }
+                        if (m != NQ_KEY32_EMPTY) {
+                            const int v = (int)(m & 0x7fffu);
+                            best = u64min(best, nq_key((int)(m >> 15) - conf_old, nq_key_hi(v > rc ? 1 : 0, c, n, slot), v));
+                        }
+                    }
+                }
+            } else {
+                const unsigned magic = (unsigned)(0x100000000ull / (unsigned)n) + 1u; // k / n for k < 2^17, n < 2^14
+                const int kmax = (int)K;
+#pragma unroll 4
+                for (int k = tid; k < kmax; k += 1024) {
+                    const int slot = (int)__umulhi((unsigned)k, magic);
+                    const int v = k - slot * n;
+                    const int4 si = s_slot[slot];
+                    const int c = si.x, rc = si.y;
+                    const bool up = v > rc;
+                    const long long rank = (long long)slot * (n - 1) + v - (up ? 1 : 0);
+                    if (rc >= 0 && v != rc && rank < window) {
+                        const int delta = tab16_get(s_t16, v) + tab16_get(s_t16, oA + v - c + n) + tab16_get(s_t16, oB + v + c) - si.z;
+                        best = u64min(best, nq_key(delta, nq_key_hi(up ? 1 : 0, c, n, slot), v));
+                    }
+                }
+            }
+        }
+        best = wave_min_u64(best);
+        if (lane == 0) s_best[wib] = best;
+        __syncthreads(); // B3
+        if (!want_cs && wib != 0) continue; // the other wavefronts are done: wave 0 answers, then patches the LDS state
+        unsigned long long key = s_best[0];
+#pragma unroll
+        for (int i = 1; i < 16; i++) key = u64min(key, s_best[i]);
+        int n_scored = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) n_scored += s_cnt[i];
+        const bool has_move = key != NQ_KEY_EMPTY && n_scored != 0;
+        int mc = -1, mv = -1, mq = -1;
+        if (has_move) {
+            mv = (int)((key >> 15) & 0x7fffu);
+            const int colkey = (int)((key >> 30) & 0x7fffu);
+            mc = ((key >> 45) & 1u) ? n - 1 - colkey : colkey;
+            mq = s_rows[mc];
+        }
+        long long total = 0;
+        if (want_cs) { // block-uniform: column scores of the board AFTER the move, from the old tables plus the move's two squares
+            int local = 0;
+            for (int p = tid; 2 * p < n; p += 1024) {
+                unsigned packed = 0;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int j = 2 * p + h;
+                    int sc = 0;
+                    if (j < n) {
+                        const int q = s_rows[j];
+                        if (j == mc) {
+                            sc = tab16_get(s_t16, mv) + tab16_get(s_t16, oA + mv - mc + n) + tab16_get(s_t16, oB + mv + mc);
+                        } else if ((unsigned)q < (unsigned)n) {
+                            sc = tab16_get(s_t16, q) + tab16_get(s_t16, oA + q - j + n) + tab16_get(s_t16, oB + q + j) - 3;
+                            if (has_move) {
+                                const int dc = j > mc ? j - mc : mc - j;
+                                const int dn = q > mv ? q - mv : mv - q, dq = q > mq ? q - mq : mq - q;
+                                sc += ((dn == 0) | (dn == dc)) - ((dq == 0) | (dq == dc));
+                            }
+                        }
+                    }
+                    packed |= (unsigned)(sc & 0xffff) << (16 * h);
+                    local += sc;
+                }
+                __hip_atomic_store(cs16 + p, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            const int ws = wave_sum_i32(local);
+            if (lane == 0) s_sum[wib] = ws;
+            __threadfence_system(); // the column scores are in host memory before the line that announces them
+            __syncthreads();
+            for (int i = 0; i < 16; i++) total += s_sum[i];
+            if (wib != 0) continue;
+        }
+        // wave 0: the response line, then the move goes into the LDS board and tables
+        {
+            const unsigned dl = step ? (unsigned)((int)(key >> 46)) : (unsigned)total; // delta + bias | the board's score
+            unsigned pay = 0;
+            if (lane == 0) pay = has_move ? 1u : 0u;
+            else if (lane == 1) pay = (unsigned)n_scored & 0xffffu;
+            else if (lane == 2) pay = (unsigned)n_scored >> 16;
+            else if (lane == 3) pay = has_move ? (unsigned)(key & 0x7fffu) : 0u;
+            else if (lane == 4) pay = has_move ? (unsigned)mv : 0u;
+            else if (lane == 5) pay = (has_move || !step) ? dl & 0xffffu : 0u;
+            else if (lane == 6) pay = (has_move || !step) ? dl >> 16 : 0u;
+            if (lane < 8) __hip_atomic_store(resp + lane, (last_tag << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            t_served = wall_clock64();
+            if (lane == 0) __hip_atomic_store(&a.ctl->last_activity, t_served, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (has_move && lane < 8) { // the old queen leaves (lanes 0..3), the new one arrives (4..7): row, shifted row copy, two diagonals
+                const int q = lane < 4 ? mq : mv, what = lane & 3;
+                int idx = -1;
+                if (what == 0) idx = q;
+                else if (what == 1) idx = (PAIRS && q > 0) ? oR1 + q - 1 : -1;
+                else if (what == 2) idx = oA + (q - mc + n);
+                else idx = oB + (q + mc);
+                if (idx >= 0) {
+                    if (lane < 4) tab16_dec(s_t16, idx); // the count includes the old queen: no borrow
+                    else tab16_inc(s_t16, idx);
+                }
+                if (lane == 0) s_rows[mc] = mv;
+            }
+        }
+    }
+    // leaving: the last workgroup out tells the host that this launch has drained
+    if (tid == 0) {
+        if (__hip_atomic_fetch_add(&a.ctl->exited, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            __hip_atomic_store(&a.ctl->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.exit_gen, a.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ host side
+struct NqServer {
+    int device = 0, n = 0, n_pad = 0, n_slots = 0;
+    bool pairs = false;
+    hipStream_t stream = nullptr;
+    char *pinned = nullptr;      // req lines | resp lines | exit word | cols_ext | shadow | cs16
+    size_t o_req = 0, o_resp = 0, o_exit = 0, o_cols = 0, o_shadow = 0, o_cs = 0;
+    NqSrvCtl *ctl = nullptr;
+    size_t lds = 0;
+    unsigned long long idle_ticks = 200000, limit_ticks = 200000000ull; // 2 ms, 2 s (100 MHz)
+    std::mutex launch_mu;
+    std::atomic<unsigned long long> launch_gen{0};
+    std::atomic<unsigned long long> relaunches{0}, slow_waits{0}, fresh_boards{0}, requests{0};
+    bool failed = false;
+    struct Slot {
+        unsigned tag = 0;
+        unsigned board_id = 0;
+        bool valid = false, cs_valid = false;
+        std::vector<int32_t> cs;
+    };
+    std::vector<Slot> slots;
+    unsigned *req(int s) const { return reinterpret_cast<unsigned *>(pinned + o_req) + (size_t)s * 16; }
+    unsigned *resp(int s) const { return reinterpret_cast<unsigned *>(pinned + o_resp) + (size_t)s * 16; }
+    unsigned long long *exit_gen() const { return reinterpret_cast<unsigned long long *>(pinned + o_exit); }
+    int *cols_ext(int s) const { return reinterpret_cast<int *>(pinned + o_cols) + (size_t)s * NQ_STEP_MAX_SLOTS; }
+    int *shadow(int s) const { return reinterpret_cast<int *>(pinned + o_shadow) + (size_t)s * n_pad; }
+    unsigned short *cs16(int s) const { return reinterpret_cast<unsigned short *>(pinned + o_cs) + (size_t)s * n_pad; }
+};
+
+bool nq_server_supports(const ls_ctx *ctx, int n)
+{
+    return ctx->nq_algo != LS_NQ_ALGO_SCAN && n >= 2 && n <= NQ_STEP_MAX_N;
+}
+
+int nq_server_n(const NqServer *s) { return s->n; }
+int nq_server_slots(const NqServer *s) { return s->n_slots; }
+
+void nq_server_counters(const NqServer *s, unsigned long long out[4])
+{
+    out[0] = s->requests.load(); out[1] = s->relaunches.load(); out[2] = s->slow_waits.load(); out[3] = s->fresh_boards.load();
+}
+
+static const void *server_fn(bool pairs)
+{
+    return pairs ? reinterpret_cast<const void *>(&nq_server_kernel<true>) : reinterpret_cast<const void *>(&nq_server_kernel<false>);
+}
+
+int nq_server_create(ls_ctx *ctx, int n, int n_slots, NqServer **out)
+{
+    *out = nullptr;
+    if (n < 2 || n > NQ_STEP_MAX_N || n_slots < 1 || n_slots > 240)
+        return set_err(ctx, LS_ERR_UNSUPPORTED, "LS-step server: n = %d, %d slots outside what one resident launch holds", n, n_slots);
+    NqServer *s = new (std::nothrow) NqServer();
+    if (!s) return set_err(ctx, LS_ERR_NOMEM, "out of host memory");
+    s->device = ctx->device;
+    s->n = n;
+    s->n_pad = (n + 63) & ~63;
+    s->n_slots = n_slots;
+    s->pairs = (n & 1) == 0 && n >= 128 && ctx->nq_table_variant >= 10;
+    if (const char *v = getenv("LS_NQ_SERVER_IDLE_US")) { const long long us = atoll(v); if (us >= 50) s->idle_ticks = (unsigned long long)us * 100; }
+    if (const char *v = getenv("LS_NQ_SERVER_LIMIT_MS")) { const long long ms = atoll(v); if (ms >= 1) s->limit_ticks = (unsigned long long)ms * 100000; }
+    const size_t tab_words = s->pairs ? ((((size_t)(6 * n + 4) >> 1) + 3) & ~(size_t)3) : ((((size_t)(5 * n + 1) / 2) + 3) & ~(size_t)3);
+    s->lds = (tab_words + (((size_t)n + 3) & ~(size_t)3) + 4 * (size_t)NQ_STEP_MAX_SLOTS) * 4;
+    auto fail = [&](int code, const char *what, hipError_t e) {
+        set_err(ctx, code, "LS-step server: %s failed: %s", what, hipGetErrorString(e));
+        if (s->stream) (void)hipStreamDestroy(s->stream);
+        if (s->pinned) (void)hipHostFree(s->pinned);
+        if (s->ctl) (void)hipFree(s->ctl);
+        delete s;
+        return code;
+    };
+    hipError_t e;
+    {   // a hardware queue of its own: CU-masked streams are never pooled; fallback: the high-priority pool
+        std::vector<uint32_t> mask(((size_t)ctx->n_cus + 31) / 32, 0xffffffffu);
+        if (ctx->n_cus % 32) mask.back() = (1u << (ctx->n_cus % 32)) - 1u;
+        e = getenv("LS_NQ_SERVER_PRIO_STREAM") ? hipErrorNotSupported : hipExtStreamCreateWithCUMask(&s->stream, (uint32_t)mask.size(), mask.data());
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            e = hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, hi);
+        }
+        if (e != hipSuccess) { s->stream = nullptr; return fail(LS_ERR_HIP, "stream creation", e); }
+    }
+    size_t off = 0;
+    s->o_req = off; off += (size_t)n_slots * 64;
+    s->o_resp = off; off += (size_t)n_slots * 64;
+    s->o_exit = off; off += 64;
+    s->o_cols = off; off += (size_t)n_slots * NQ_STEP_MAX_SLOTS * 4;
+    s->o_shadow = off; off += (size_t)n_slots * s->n_pad * 4;
+    s->o_cs = off; off += (size_t)n_slots * s->n_pad * 2;
+    e = hipHostMalloc(reinterpret_cast<void **>(&s->pinned), off, hipHostMallocCoherent);
+    if (e != hipSuccess) { s->pinned = nullptr; return fail(LS_ERR_NOMEM, "pinned allocation", e); }
+    memset(s->pinned, 0, off);
+    e = hipMalloc(reinterpret_cast<void **>(&s->ctl), 256);
+    if (e != hipSuccess) { s->ctl = nullptr; return fail(LS_ERR_NOMEM, "device allocation", e); }
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(64), 0, s->stream, reinterpret_cast<long long *>(s->ctl), 0ll, 32ll);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(s->stream)) != hipSuccess) return fail(LS_ERR_HIP, "control block set-up", e);
+    static std::atomic<bool> attr_done_dev[64];
+    if (!attr_done_dev[ctx->device & 63].load(std::memory_order_acquire)) {
+        const int max_lds = (((6 * NQ_STEP_MAX_N + 4) / 2 + 4) + NQ_STEP_MAX_N + 4 * NQ_STEP_MAX_SLOTS) * 4;
+        if ((e = hipFuncSetAttribute(server_fn(false), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess ||
+            (e = hipFuncSetAttribute(server_fn(true), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess)
+            return fail(LS_ERR_HIP, "hipFuncSetAttribute", e);
+        attr_done_dev[ctx->device & 63].store(true, std::memory_order_release);
+    }
+    s->slots.resize((size_t)n_slots);
+    for (auto &sl : s->slots) sl.cs.resize((size_t)n);
+    *out = s;
+    return LS_OK;
+}
+
+static bool server_drained(const NqServer *s)
+{
+    return __atomic_load_n(s->exit_gen(), __ATOMIC_ACQUIRE) == s->launch_gen.load(std::memory_order_acquire);
+}
+
+// (Re)launch when the previous launch has drained (or none has been made).  Cheap when the kernel is resident.
+static int server_ensure_running(ls_ctx *ctx, NqServer *s)
+{
+    if (!server_drained(s)) return LS_OK;
+    std::lock_guard<std::mutex> lk(s->launch_mu);
+    if (s->failed) return set_err(ctx, LS_ERR_HIP, "LS-step server: an earlier launch failed");
+    if (!server_drained(s)) return LS_OK;
+    NqSrvArgs a;
+    a.req = s->req(0); a.resp = s->resp(0); a.cols_ext = s->cols_ext(0); a.shadow = s->shadow(0);
+    a.cs16 = reinterpret_cast<unsigned *>(s->cs16(0)); a.ctl = s->ctl; a.exit_gen = s->exit_gen();
+    a.gen = s->launch_gen.load() + 1; a.idle_ticks = s->idle_ticks; a.limit_ticks = s->limit_ticks;
+    a.n = s->n; a.n_pad = s->n_pad;
+    void *args[] = {&a};
+    const hipError_t e = hipLaunchKernel(server_fn(s->pairs), dim3((unsigned)s->n_slots), dim3(1024), args, s->lds, s->stream);
+    if (e != hipSuccess) {
+        s->failed = true;
+        return set_err(ctx, LS_ERR_HIP, "LS-step server: launch failed: %s", hipGetErrorString(e));
+    }
+    s->launch_gen.store(a.gen, std::memory_order_release);
+    s->relaunches.fetch_add(1, std::memory_order_relaxed);
+    return LS_OK;
+}
+
+void nq_server_destroy(NqServer *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (!server_drained(s)) { // ask every workgroup to leave, then wait for the launch
+        for (int i = 0; i < s->n_slots; i++) {
+            NqServer::Slot &sl = s->slots[(size_t)i];
+            sl.tag = sl.tag >= 0xfffeu ? 1u : sl.tag + 1u;
+            alignas(64) unsigned line[16];
+            for (int d = 0; d < 16; d++) line[d] = sl.tag << 16;
+            line[0] |= SRV_F_QUIT;
+            memcpy(s->req(i), line, 64);
+        }
+    }
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipStreamDestroy(s->stream);
+    (void)hipHostFree(s->pinned);
+    (void)hipFree(s->ctl);
+    delete s;
+}
+
+static void post_line(NqServer *s, int slot, const unsigned pay[16])
+{
+    NqServer::Slot &sl = s->slots[(size_t)slot];
+    sl.tag = sl.tag >= 0xfffeu ? 1u : sl.tag + 1u;
+    alignas(64) unsigned line[16];
+    for (int d = 0; d < 16; d++) line[d] = (sl.tag << 16) | (pay[d] & 0xffffu);
+    __atomic_thread_fence(__ATOMIC_RELEASE); // the bulk data (board, columns) is written before the line that announces it
+    volatile unsigned *dst = s->req(slot);
+    for (int d = 0; d < 16; d++) dst[d] = line[d];
+    s->requests.fetch_add(1, std::memory_order_relaxed);
+}
+
+// Poll the slot's response line for the tag of the request just posted (the same hooks as the completion-word wait of the
+// launched LS step: the caller's idle work, another restart's fibre, sched_yield).
+static int wait_line(ls_ctx *ctx, NqServer *s, int slot, unsigned out[8])
+{
+    const unsigned tag = s->slots[(size_t)slot].tag;
+    const volatile unsigned *r = s->resp(slot);
+    bool idle_work = ctx->idle_hook != nullptr;
+    std::chrono::steady_clock::time_point t0;
+    bool timed = false;
+    for (unsigned spins = 0;; spins++) {
+        unsigned v[8];
+        bool ok = true;
+        for (int d = 0; d < 8; d++) { v[d] = r[d]; ok = ok && (v[d] >> 16) == tag; }
+        if (ok) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            for (int d = 0; d < 8; d++) out[d] = v[d] & 0xffffu;
+            return LS_OK;
+        }
+        if (idle_work) { idle_work = ctx->idle_hook(ctx->idle_arg); continue; }
+        if (ctx->wait_hook) ctx->wait_hook(ctx->wait_hook_arg);
+#if defined(__x86_64__)
+        else __builtin_ia32_pause();
+#endif
+        if (ctx->yield_while_waiting && spins >= 64) sched_yield();
+        if ((spins & 15u) == 15u) {
+            // has the launch drained under the request (idle time-out, age limit)?  Then it is launched again and finds the request.
+            if (server_drained(s)) {
+                s->slow_waits.fetch_add(1, std::memory_order_relaxed);
+                const int rc = server_ensure_running(ctx, s);
+                if (rc != LS_OK) return rc;
+            }
+            if ((spins & 0x3ffu) == 0x3ffu) {
+                if (!timed) { t0 = std::chrono::steady_clock::now(); timed = true; }
+                else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+                    const hipError_t e = hipStreamQuery(s->stream);
+                    return set_err(ctx, LS_ERR_HIP, "LS-step server: no answer from slot %d within 10 s (stream: %s)", slot, hipGetErrorString(e));
+                }
+            }
+        }
+    }
+}
+
+// The board of this request versus what the slot holds: an unchanged board costs a 4n-byte compare, a new one is copied
+// into the pinned shadow and gets a new id (the workgroup then reads it from there).
+static void sync_board(NqServer *s, int slot, const int32_t *rows)
+{
+    NqServer::Slot &sl = s->slots[(size_t)slot];
+    int *sh = s->shadow(slot);
+    if (!sl.valid || memcmp(rows, sh, (size_t)s->n * 4) != 0) {
+        memcpy(sh, rows, (size_t)s->n * 4);
+        sl.valid = true;
+        sl.cs_valid = false;
+        sl.board_id = sl.board_id == 0xffffffffu ? 1u : sl.board_id + 1u;
+        s->fresh_boards.fetch_add(1, std::memory_order_relaxed);
+    }
+}
+
+void nq_cs_after_move(const int32_t *rows, int32_t *cs, int n, int mc, int mv, int mq); // ls_api.hip
+void widen_i32(const int32_t *src, int64_t *dst, int n);                                // ls_api.hip
+
+// One LS iteration of one restart on slot `slot` (what ls_nqueens_eval_batch[_next] computes for n_restarts == 1).
+// rows / cols are validated by the caller; window is already clamped.
+int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int64_t cur_score, const int32_t *cols, int32_t n_cols,
+                   long long window, ls_nq_result *res, int64_t *next_col_scores)
+{
+    if (slot < 0 || slot >= s->n_slots) return set_err(ctx, LS_ERR_INVALID, "LS-step server: slot %d outside [0, %d)", slot, s->n_slots);
+    const int n = s->n;
+    NqServer::Slot &sl = s->slots[(size_t)slot];
+    sync_board(s, slot, rows);
+    if (!next_col_scores) sl.cs_valid = false; // nobody keeps the scores across this call
+    const bool want_cs = next_col_scores != nullptr && !(sl.cs_valid && ctx->nq_host_cs);
+    long long reach = n_cols;
+    if (window / (n - 1) < reach) reach = window / (n - 1) + 1; // slots take(window) can reach
+    unsigned pay[16] = {0};
+    pay[0] = SRV_F_STEP | (want_cs ? SRV_F_WANT_CS : 0u);
+    pay[1] = (unsigned)(n_cols > NQ_STEP_MAX_SLOTS ? NQ_STEP_MAX_SLOTS : n_cols);
+    pay[2] = (unsigned)window & 0xffffu; pay[3] = (unsigned)(window >> 16) & 0xffffu;
+    pay[4] = sl.board_id & 0xffffu; pay[5] = sl.board_id >> 16;
+    if (reach > SRV_INLINE_COLS) {
+        pay[0] |= SRV_F_EXT_COLS;
+        memcpy(s->cols_ext(slot), cols, (size_t)reach * 4);
+    } else {
+        for (int i = 0; i < (int)reach; i++) pay[6 + i] = (unsigned)cols[i];
+    }
+    int rc = server_ensure_running(ctx, s);
+    if (rc != LS_OK) return rc;
+    post_line(s, slot, pay);
+    unsigned r[8];
+    rc = wait_line(ctx, s, slot, r);
+    if (rc != LS_OK) { sl.valid = false; return rc; }
+    const bool moved = (r[0] & 1u) != 0;
+    if (!moved) {
+        res->n_scored = 0; res->best_index = -1; res->best_score = 0; res->best_col = -1; res->best_value = -1;
+    } else {
+        const int bslot = (int)r[3], v = (int)r[4];
+        res->n_scored = (long long)(r[1] | (r[2] << 16));
+        res->best_index = (long long)bslot * n + v;
+        res->best_score = cur_score + 2ll * ((int)(r[5] | (r[6] << 16)) - NQ_DELTA_BIAS);
+        res->best_col = cols[bslot];
+        res->best_value = v;
+    }
+    int *sh = s->shadow(slot);
+    if (next_col_scores) {
+        if (want_cs) { // from the kernel; remembered for the next call
+            const unsigned short *k16 = s->cs16(slot);
+            for (int j = 0; j < n; j++) { sl.cs[(size_t)j] = k16[j]; next_col_scores[j] = k16[j]; }
+            sl.cs_valid = true;
+        } else {
+            if (moved) nq_cs_after_move(sh, sl.cs.data(), n, res->best_col, res->best_value, sh[res->best_col]);
+            widen_i32(sl.cs.data(), next_col_scores, n);
+        }
+    }
+    if (moved) sh[res->best_col] = res->best_value; // the workgroup applied it to its LDS board
+    return LS_OK;
+}
+
+// get_col_scores + score of one board (examples/nqueens/src/lib.rs:74-87, 126-140) on the slot; the board stays with the
+// slot, so the LS walk that starts from it (local_search.rs:306-309) uploads nothing.
+int nq_server_col_scores(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int64_t *col_scores, int64_t *total)
+{
+    if (slot < 0 || slot >= s->n_slots) return set_err(ctx, LS_ERR_INVALID, "LS-step server: slot %d outside [0, %d)", slot, s->n_slots);
+    const int n = s->n;
+    NqServer::Slot &sl = s->slots[(size_t)slot];
+    sync_board(s, slot, rows);
+    unsigned pay[16] = {0};
+    pay[0] = SRV_F_WANT_CS;
+    pay[4] = sl.board_id & 0xffffu; pay[5] = sl.board_id >> 16;
+    int rc = server_ensure_running(ctx, s);
+    if (rc != LS_OK) return rc;
+    post_line(s, slot, pay);
+    unsigned r[8];
+    rc = wait_line(ctx, s, slot, r);
+    if (rc != LS_OK) { sl.valid = false; return rc; }
+    const unsigned short *k16 = s->cs16(slot);
+    for (int j = 0; j < n; j++) sl.cs[(size_t)j] = k16[j];
+    sl.cs_valid = true;
+    if (col_scores) for (int j = 0; j < n; j++) col_scores[j] = k16[j];
+    if (total) *total = (int64_t)(r[5] | (r[6] << 16));
+    return LS_OK;
+}
+
+} // namespace lsamd

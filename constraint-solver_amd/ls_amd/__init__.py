@@ -75,6 +75,12 @@ class Context:
         a = ALGOS[algo] if isinstance(algo, str) else int(algo)
         self._check(self._l.ls_ctx_set_nq_algo(self._h, a))
 
+    def counters(self) -> dict:
+        """ls_ctx_get_counters: the slow branches of the latency-critical path (see include/ls_amd.h)."""
+        out = np.zeros(_lib.LS_N_COUNTERS, dtype=np.uint64)
+        self._check(self._l.ls_ctx_get_counters(self._h, _vp(out)))
+        return {k: int(v) for k, v in zip(_lib.COUNTER_NAMES, out)}
+
     def device_info(self) -> dict:
         cus, ws, khz = C.c_int(), C.c_int(), C.c_int()
         name = C.create_string_buffer(256)
@@ -367,6 +373,11 @@ class MultiSolver:
         a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._ctx._check(self._l.ls_multi_solver_get_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return dict(ls_iterations=a.value, neighbours_scored=b.value, gpu_launches=c.value, rounds=d.value)
+
+    def counters(self) -> dict:
+        out = np.zeros(_lib.LS_N_COUNTERS, dtype=np.uint64)
+        self._ctx._check(self._l.ls_multi_solver_get_counters(self._h, _vp(out)))
+        return {k: int(v) for k, v in zip(_lib.COUNTER_NAMES, out)}
 
     def close(self):
         if getattr(self, "_h", None):

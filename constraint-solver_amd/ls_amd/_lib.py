@@ -19,6 +19,9 @@ LS_ERR_INVALID, LS_ERR_NO_DEVICE, LS_ERR_HIP, LS_ERR_UNSUPPORTED, LS_ERR_NOMEM, 
 LS_NQ_ALGO_SCAN, LS_NQ_ALGO_TABLE, LS_NQ_ALGO_AUTO = 0, 1, 2
 LS_NQ_MAX_N = 32768
 LS_SCHED_MAX_DAYS = 64
+LS_N_COUNTERS = 6
+COUNTER_NAMES = ("server_requests", "server_launches", "server_waits_on_drained_launch", "server_boards_uploaded",
+                 "completion_word_fallbacks", "resident_board_reuploads")
 INT64_MIN = -(2 ** 63)
 
 _ERR_NAMES = {1: "LS_ERR_INVALID", 2: "LS_ERR_NO_DEVICE", 3: "LS_ERR_HIP", 4: "LS_ERR_UNSUPPORTED",
@@ -66,6 +69,7 @@ SIGNATURES = {
     "ls_ctx_synchronize": (C.c_int, [_vp]),
     "ls_ctx_set_nq_algo": (C.c_int, [_vp, C.c_int]),
     "ls_ctx_get_nq_algo": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "ls_ctx_get_counters": (C.c_int, [_vp, _vp]),
     "ls_ctx_device_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                      C.c_char_p, C.c_int]),
     "ls_nqueens_eval": (C.c_int, [_vp, _i32, _vp, _i64, _vp, _i32, _i64, _vp, _vp]),
@@ -101,6 +105,7 @@ SIGNATURES = {
     "ls_multi_solver_get_best": (C.c_int, [_vp, _i32, _vp, _vp, _i32, C.POINTER(_i32), C.POINTER(C.c_int)]),
     "ls_multi_solver_get_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64)]),
+    "ls_multi_solver_get_counters": (C.c_int, [_vp, _vp]),
     "ls_multi_solver_free": (C.c_int, [_vp]),
     "ls_host_hash_seed": (C.c_int, [C.c_char_p, _vp]),
     "ls_host_chacha20_block": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),

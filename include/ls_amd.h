@@ -97,6 +97,19 @@ int ls_ctx_synchronize(ls_ctx *ctx);
 int ls_ctx_set_nq_algo(ls_ctx *ctx, int algo);
 int ls_ctx_get_nq_algo(const ls_ctx *ctx, int *algo);
 
+/* Counters of the latency-critical host-pointer path since the context was created (ls_multi_solver_get_counters: of
+ * the last run).  The reference has no counterpart (its loop, local_search.rs:301-342, never leaves the thread); they
+ * exist so that the slow branches of this boundary are visible instead of silent:
+ *   [0] requests served by the resident LS-step server (one launch whose workgroups are the slots: a one-restart
+ *       ls_nqueens_eval / ls_nqueens_eval_batch[_next] / ls_nqueens_col_scores call is a 64-byte mailbox write and a
+ *       32-byte answer, no kernel launch), [1] launches of that server (it leaves when no slot has been served for 2 ms
+ *       -- LS_NQ_SERVER_IDLE_US -- and is started again on demand), [2] waits that found the launch drained under their
+ *       request, [3] boards uploaded to server slots (a board that continues from the previous winner is not),
+ *   [4] completion-word waits of launched steps that fell back to hipStreamSynchronize after 2 ms,
+ *   [5] boards re-uploaded by the launch-per-call route (LS_NQ_STEP=3) because they were not the resident one. */
+#define LS_N_COUNTERS 6
+int ls_ctx_get_counters(const ls_ctx *ctx, uint64_t out[LS_N_COUNTERS]);
+
 /* Device properties the harness reports (CU count, wavefront size, clock kHz, name). */
 int ls_ctx_device_info(const ls_ctx *ctx, int *n_cus, int *wave_size, int *clock_khz,
                        char *name, int name_cap);
@@ -327,8 +340,10 @@ int ls_solver_free(ls_solver *s);
  * on a host thread (or fibre); n_slots of them are in flight at once and a finished restart's slot takes the next seed of
  * the list, so the GPU stays fed while restarts need very different numbers of iterations.  The result of
  * every restart is identical to running it alone with ls_solver_*.  Two ways to serve the slots' GPU requests:
- *   LS_MULTI_FREE_RUNNING  (default) every slot owns a context (stream + pinned staging block) on the same device
- *                          and issues its own one-restart launches; no slot ever waits for another;
+ *   LS_MULTI_FREE_RUNNING  (default) every slot is one workgroup of a single resident LS-step server launch on the
+ *                          device (board and count tables stay in that workgroup's LDS; an LS iteration is a 64-byte
+ *                          request and a 32-byte answer, no kernel launch); no slot ever waits for another.
+ *                          (LS_NQ_STEP=3, LS_NQ_ALGO_SCAN or n > 8192: a context per slot issuing one-restart launches);
  *   LS_MULTI_LOCKSTEP      the slots' requests of one step are merged into ONE batched launch on the caller's
  *                          context (ls_nqueens_eval_batch_next / ls_nqueens_col_scores).
  * ls_multi_solver_run drives all restarts until each is finished, has found a best-possible solution, or a
@@ -348,6 +363,7 @@ int ls_multi_solver_get_best(const ls_multi_solver *m, int32_t restart, int64_t 
 /* totals over all restarts: LS iterations, candidates scored, batched GPU launches, rounds executed */
 int ls_multi_solver_get_stats(const ls_multi_solver *m, uint64_t *ls_iterations, uint64_t *neighbours_scored,
                               uint64_t *gpu_launches, uint64_t *rounds);
+int ls_multi_solver_get_counters(const ls_multi_solver *m, uint64_t out[LS_N_COUNTERS]); /* see ls_ctx_get_counters */
 int ls_multi_solver_free(ls_multi_solver *m);
 
 /* Host RNG primitives, exported so the tests can pin them (RFC 7693 / RFC 7539 vectors, and

