@@ -458,6 +458,7 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
                                  ls_nq_result *results, int64_t *next_col_scores)
 {
     NqResident &rs = ctx->nq_res;
+    ctx->steps_done++;
     static const bool trace = getenv("LS_AMD_TRACE") != nullptr;
     const auto T0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     if (!rs.flag) {
@@ -569,13 +570,10 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
                         const int32_t *cols, const int32_t *n_cols, int32_t max_cols, int64_t window,
                         ls_nq_result *results, int64_t *scores_out, int64_t *next_col_scores)
 {
-    LS_BIND(ctx);
+    if (!ctx) return LS_ERR_INVALID;
     int rc = nq_check_dims(ctx, n_restarts, n, max_cols, window);
     if (rc != LS_OK) return rc;
     LS_REQUIRE(ctx, rows && cur_scores && n_cols && results && (cols || max_cols == 0), "null pointer");
-    if (!all_in_range(rows, (long long)n_restarts * n, n))
-        for (long long i = 0; i < (long long)n_restarts * n; i++)
-            LS_REQUIRE(ctx, rows[i] >= 0 && rows[i] < n, "rows[%lld] = %d outside [0, %d)", i, rows[i], n);
     for (int r = 0; r < n_restarts; r++) {
         LS_REQUIRE(ctx, n_cols[r] >= 0 && n_cols[r] <= max_cols, "n_cols[%d] = %d outside [0, max_cols = %d]", r,
                    n_cols[r], max_cols);
@@ -585,14 +583,22 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
         }
     }
     if (!scores_out && n_restarts == 1 && ctx->nq_step_mode >= 4 && nq_step_eligible(ctx, n, max_cols, nq_clamp_window(window, max_cols, n))) {
-        // one restart, no score dump: the resident LS-step server (no launch, no copy; the board stays in the slot's LDS)
-        NqServer *srv = nullptr;
-        rc = nq_ctx_server(ctx, n, &srv);
-        if (rc != LS_OK) return rc;
+        // One restart, no score dump: the resident LS-step server (no launch, no copy, no runtime call in the steady state; the
+        // board stays in the slot's LDS).  The board is range-checked there, and only when it is not the one the slot holds.
+        NqServer *srv = ctx->server && nq_server_n(ctx->server) == n ? ctx->server : nullptr;
+        if (!srv) {
+            LS_BIND(ctx);
+            rc = nq_ctx_server(ctx, n, &srv);
+            if (rc != LS_OK) return rc;
+        }
         if (srv)
             return nq_server_step(ctx, srv, ctx->server_slot, rows, cur_scores[0], cols, n_cols[0], nq_clamp_window(window, max_cols, n), results,
                                   next_col_scores);
     }
+    LS_BIND(ctx);
+    if (!all_in_range(rows, (long long)n_restarts * n, n))
+        for (long long i = 0; i < (long long)n_restarts * n; i++)
+            LS_REQUIRE(ctx, rows[i] >= 0 && rows[i] < n, "rows[%lld] = %d outside [0, %d)", i, rows[i], n);
     const size_t rows_b = (size_t)n_restarts * n * 4, cur_b = (size_t)n_restarts * 8,
                  cols_b = (size_t)n_restarts * max_cols * 4, nc_b = (size_t)n_restarts * 4,
                  res_b = (size_t)n_restarts * sizeof(ls_nq_result), cs_b = next_col_scores ? (size_t)n_restarts * n * 8 : 0,

@@ -163,6 +163,12 @@ struct ls_ctx {
     void *idle_arg = nullptr;
     void (*wait_hook)(void *) = nullptr; // completion-word poll: called between polls (ls_multi_solver: switch to another restart's fibre on this thread)
     void *wait_hook_arg = nullptr;
+    // What the wait in progress waits for, for a scheduler behind wait_hook (ls_multi_solver's fibre pool resumes a restart only
+    // once its answer is there): n_wait_words words whose upper 16 bits all become wait_tag; wait_words == nullptr: not known.
+    const volatile unsigned *wait_words = nullptr;
+    int n_wait_words = 0;
+    unsigned wait_tag = 0;
+    unsigned long long steps_done = 0; // one-restart LS steps of this context (ls_multi_solver: the running restart's scheduling priority)
     bool yield_while_waiting = false; // completion-word poll: sched_yield() after a short spin (set by ls_multi_solver when slots > cores; LS_YIELD)
     bool sched_zero_copy = true; // ls_sched_eval_resident: kernels work on the pinned staging blocks directly (LS_SCHED_ZEROCOPY)
     bool sched_fused = true;     // small scheduling launches: locate + eval + reduce in one kernel (LS_SCHED_FUSED)

@@ -2,7 +2,6 @@
 // the host driver of csrc/host/ wired to the GPU path of this library.  Plain host C++; it is a
 // .hip file only so that the one hipcc invocation style builds everything.
 #include <sched.h>
-#include <ucontext.h>
 
 #include <atomic>
 #include <functional>
@@ -13,10 +12,15 @@
 #include <new>
 #include <thread>
 
+#include "host/fibers.hpp"
 #include "host/plugins.hpp"
 #include "ls_common.hpp"
 
 using namespace lshost;
+
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+asm(LS_FIBER_SWITCH_ASM); // host/fibers.hpp: the fibre switch, emitted once (this file has a device pass too: not there)
+#endif
 
 struct ls_solver {
     ls_ctx *ctx = nullptr;
@@ -38,6 +42,7 @@ struct ls_multi_solver {
     int mode = LS_MULTI_FREE_RUNNING; // LS_MULTI_FREE_RUNNING: a context per slot; LS_MULTI_LOCKSTEP: one batched launch per step
     uint64_t ls_iterations = 0, neighbours_scored = 0, gpu_launches = 0, rounds = 0;
     uint64_t counters[LS_N_COUNTERS] = {0}; // ls_multi_solver_get_counters: the last run's
+    uint64_t fibre_steals = 0;
 };
 
 namespace {
@@ -50,74 +55,17 @@ int check_params(ls_ctx *ctx, const ls_solver_params *p)
     return LS_OK;
 }
 
-// Cores this process may really use: the affinity mask, further limited by the cgroup CPU quota when there is one
-// (hardware_concurrency() reports the whole machine inside a container).
-// Cooperative fibres: several restarts share one host thread.  A restart that waits for its launch (wait_done_word's
-// hook) hands the thread to the next restart, whose host work (proposer, History) then runs during the wait -- with one
-// restart per thread the core idles for half of every LS iteration.  Plain ucontext: a fibre only ever switches inside
-// that hook, never inside a runtime call.
-class FiberGroup {
-public:
-    explicit FiberGroup(size_t stack_bytes = 1 << 20) : stack_bytes_(stack_bytes) {}
-    void add(std::function<void()> fn) { fibers_.emplace_back(new Fiber{{}, std::unique_ptr<char[]>(new char[stack_bytes_]), false, std::move(fn)}); }
-    // runs every fibre to completion on the calling thread
-    void run()
-    {
-        if (fibers_.empty()) return;
-        for (auto &f : fibers_) {
-            getcontext(&f->uc);
-            f->uc.uc_stack.ss_sp = f->stack.get();
-            f->uc.uc_stack.ss_size = stack_bytes_;
-            f->uc.uc_link = nullptr;
-            makecontext(&f->uc, reinterpret_cast<void (*)()>(&FiberGroup::trampoline), 2, (unsigned)((uintptr_t)this >> 32),
-                        (unsigned)((uintptr_t)this & 0xffffffffu));
-        }
-        cur_ = 0;
-        swapcontext(&main_, &fibers_[0]->uc);
-    }
-    // called by the running fibre: give the thread to the next unfinished fibre, come back when the others yield
-    void yield()
-    {
-        const int nxt = next_alive(cur_);
-        if (nxt < 0 || nxt == cur_) return;
-        const int prev = cur_;
-        cur_ = nxt;
-        swapcontext(&fibers_[(size_t)prev]->uc, &fibers_[(size_t)nxt]->uc);
-    }
-    static void yield_hook(void *self) { static_cast<FiberGroup *>(self)->yield(); }
-
-private:
-    struct Fiber {
-        ucontext_t uc;
-        std::unique_ptr<char[]> stack;
-        bool done;
-        std::function<void()> fn;
-    };
-    int next_alive(int from) const
-    {
-        const int n = (int)fibers_.size();
-        for (int i = 1; i <= n; i++) {
-            const int j = (from + i) % n;
-            if (!fibers_[(size_t)j]->done) return j;
-        }
-        return -1;
-    }
-    static void trampoline(unsigned hi, unsigned lo)
-    {
-        FiberGroup *g = reinterpret_cast<FiberGroup *>(((uintptr_t)hi << 32) | lo);
-        Fiber &f = *g->fibers_[(size_t)g->cur_];
-        f.fn(); // catches everything itself
-        f.done = true;
-        const int nxt = g->next_alive(g->cur_);
-        if (nxt < 0) setcontext(&g->main_);
-        g->cur_ = nxt;
-        setcontext(&g->fibers_[(size_t)nxt]->uc);
-    }
-    size_t stack_bytes_;
-    std::vector<std::unique_ptr<Fiber>> fibers_;
-    ucontext_t main_;
-    int cur_ = -1;
-};
+// wait hook of a slot that is a fibre: say what the restart waits for and how far it has come (restart lengths are heavy-
+// tailed: the one that has run longest goes first), then give the thread up
+static void fibre_wait_hook(void *arg)
+{
+    const ls_ctx *c = static_cast<const ls_ctx *>(arg);
+    FiberPool::set_priority(c->steps_done);
+    if (!c->wait_words) { FiberPool::yield(); return; }
+    FiberWait w;
+    w.words = c->wait_words; w.n_words = c->n_wait_words; w.tag = c->wait_tag;
+    FiberPool::yield(&w);
+}
 
 static void solver_set_idle_work(ls_ctx *c, bool (*fn)(void *), void *arg)
 {
@@ -125,6 +73,8 @@ static void solver_set_idle_work(ls_ctx *c, bool (*fn)(void *), void *arg)
     c->idle_arg = arg;
 }
 
+// Cores this process may really use: the affinity mask, further limited by the cgroup CPU quota when there is one
+// (hardware_concurrency() reports the whole machine inside a container).
 unsigned usable_cores()
 {
     unsigned cores = std::thread::hardware_concurrency();
@@ -391,7 +341,7 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
         std::atomic<int> next_restart{0};
         std::atomic<bool> stop{false};
         const auto t0 = std::chrono::steady_clock::now();
-        auto worker = [&](int t, FiberGroup *group) {
+        auto worker = [&](int t, bool as_fibre) {
             ls_ctx *own = nullptr;
             try {
                 ls_ctx *ctx = m->ctx;
@@ -415,11 +365,12 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
                     ls_ctx *c; void (*h)(void *); void *a;
                     ~Restore() { c->wait_hook = h; c->wait_hook_arg = a; }
                 } restore{ctx, ctx->wait_hook, ctx->wait_hook_arg};
-                if (group) { ctx->wait_hook = &FiberGroup::yield_hook; ctx->wait_hook_arg = group; }
+                if (as_fibre) { ctx->wait_hook = &fibre_wait_hook; ctx->wait_hook_arg = ctx; }
                 const ls_solver_params &p = m->params;
                 for (;;) {
                     const int r = next_restart.fetch_add(1);
                     if (r >= R || stop.load()) break;
+                    ctx->steps_done = 0; // the new restart's scheduling priority starts over
                     NQueensProblem problem(ctx, m->board_size, lockstep ? &batcher : nullptr);
                     problem.set_idle_work = &solver_set_idle_work;
                     const ChaCha20Rng solver_rng = ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]);
@@ -458,18 +409,21 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
             }
             batcher.thread_done();
         };
-        // free-running slots beyond the host's cores share threads as cooperative fibres (slot t on thread t mod n_threads)
+        // Free-running slots beyond the host's cores are cooperative fibres of ONE pool over the cores (slot t starts on worker
+        // t mod n_threads; a worker that runs dry takes suspended fibres from a busy one, host/fibers.hpp).
         const int hwc = (int)usable_cores();
         const int n_threads = (!lockstep && hwc >= 1 && T > hwc) ? hwc : T;
-        std::vector<std::thread> threads;
-        for (int th = 0; th < n_threads; th++)
-            threads.emplace_back([&, th]() {
-                if (n_threads == T) { worker(th, nullptr); return; }
-                FiberGroup group;
-                for (int t = th; t < T; t += n_threads) group.add([&, t]() { worker(t, &group); });
-                group.run();
-            });
-        for (auto &t : threads) t.join();
+        m->fibre_steals = 0;
+        if (n_threads == T) {
+            std::vector<std::thread> threads;
+            for (int th = 0; th < n_threads; th++) threads.emplace_back([&, th]() { worker(th, false); });
+            for (auto &t : threads) t.join();
+        } else {
+            FiberPool pool(n_threads);
+            for (int t = 0; t < T; t++) pool.add([&, t]() { worker(t, true); }, t);
+            pool.run();
+            m->fibre_steals = pool.steals();
+        }
         for (const std::string &e : errors)
             if (!e.empty()) throw std::runtime_error(e);
         m->ls_iterations = m->neighbours_scored = m->rounds = m->gpu_launches = 0;
@@ -487,6 +441,7 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
             for (int i = 0; i < 4; i++) m->counters[i] = c4[i];
         }
         for (int t = 0; t < T; t++) { m->counters[4] += fallbacks[(size_t)t]; m->counters[5] += reuploads[(size_t)t]; }
+        m->counters[6] = m->fibre_steals;
         return LS_OK;
     });
 }

@@ -60,9 +60,11 @@ struct NqSrvArgs {
 
 template <class T> __device__ __forceinline__ T sys_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-// One workgroup = one slot.  Request line: d0 flags, d1 n_cols, d2-3 window, d4-5 board id, d6-15 the first ten columns.
+// One workgroup = one slot.  Request line: d0 flags, d1 whole columns take(window) reaches, d2 candidates taken from the next
+// column, d3 parts per column | steps per part << 8 (the split of the paired walk), d4-5 board id, d6-15 the first ten columns.
 // Response line: d0 bit 0 "has a move", d1-2 n_scored, d3 winner slot, d4 winner value, d5-6 delta + bias (STEP) or the
-// board's score (no STEP), d7 zero.
+// board's score (no STEP).  -DLS_NQ_STAMPS builds (tools/server_stamps.py) add d7-d11: when, in 10 ns ticks after the request
+// was seen, wave 0 passed B1, B2, finished scoring, passed B3 and had the answer ready.
 template <bool PAIRS>
 __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
 {
@@ -84,10 +86,18 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
     const int *cols_ext = a.cols_ext + (size_t)blockIdx.x * NQ_STEP_MAX_SLOTS;
     unsigned *cs16 = a.cs16 + (size_t)blockIdx.x * (a.n_pad >> 1);
 
+    const unsigned magic = 0xffffffffu / (unsigned)n + 1u; // ceil(2^32 / n): k / n == umulhi(k, magic) for k < 2^17, n < 2^14
     unsigned lds_board = 0;      // id of the board this workgroup holds in LDS (0: none); block-uniform
     // wave 0's poll state
     unsigned last_tag = 0;
     unsigned long long t_start = 0, t_served = 0;
+#ifdef LS_NQ_STAMPS
+    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0}; // wave 0: request seen, B1 passed, slot records done (B2), scored, B3 passed, answer ready
+    unsigned long long cyc0 = 0;                       // shader-clock counter when the request was seen
+#define SRV_STAMP(I) do { if (wib == 0) { stamp[I] = wall_clock64(); if ((I) == 0) cyc0 = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define SRV_STAMP(I) do { } while (0)
+#endif
     if (wib == 0) {
         t_start = t_served = wall_clock64();
         last_tag = sys_load(resp) >> 16; // the last request an earlier launch answered
@@ -108,6 +118,7 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
                 if (whole && t0 != last_tag && t0 != 0) {
                     if (lane < 16) s_req[lane] = v & 0xffffu;
                     last_tag = t0;
+                    SRV_STAMP(0);
                     leave = (__builtin_amdgcn_readfirstlane(v) & SRV_F_QUIT) ? 1 : 0;
                     break;
                 }
@@ -135,15 +146,17 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
             if (lane == 0) s_leave = leave;
         }
         __syncthreads(); // B1: the request is in s_req; wave 0's LDS patches of the previous step are visible
+        SRV_STAMP(1);
         if (s_leave) break;
+        // The host does the window arithmetic (64-bit divisions cost ~600 cycles each here): d1 = whole columns take(window)
+        // reaches, d2 = candidates it takes from the next column (0: none), d3 = parts a column is split into | steps per part << 8.
         const unsigned flags = s_req[0];
-        int ncols = (int)s_req[1];
-        const long long window = (long long)(s_req[2] | (s_req[3] << 16));
+        const int n_whole = (int)s_req[1], rem = (int)s_req[2];
+        const int parts = (int)(s_req[3] & 0xffu), per_part = (int)(s_req[3] >> 8);
         const unsigned board = s_req[4] | (s_req[5] << 16);
-        ncols = ncols > NQ_STEP_MAX_SLOTS ? NQ_STEP_MAX_SLOTS : ncols;
         const bool step = (flags & SRV_F_STEP) != 0, want_cs = (flags & SRV_F_WANT_CS) != 0;
-        const long long K = step ? nq_k_limit((long long)ncols * n, n, window) : 0;
-        const int n_slots = (int)((K + n - 1) / n);
+        const int n_slots = step ? n_whole + (rem > 0 ? 1 : 0) : 0; // <= NQ_STEP_MAX_SLOTS (the host checked)
+        const int window = n_whole * (n - 1) + rem;                  // < 2^24
         int cv = -1;
         if (tid < n_slots) {
             if (flags & SRV_F_EXT_COLS) cv = sys_load(cols_ext + tid);
@@ -185,24 +198,17 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
             if ((unsigned)rc < (unsigned)n)
                 conf_old = tab16_get(s_t16, rc) + tab16_get(s_t16, oA + rc - c + n) + tab16_get(s_t16, oB + rc + c) - 3;
             s_slot[tid] = make_int4(c, (unsigned)rc < (unsigned)n ? rc : -1, conf_old, 0);
-            my_scored = nq_slot_scored(tid, c, rc, n, window);
+            if ((unsigned)rc < (unsigned)n) my_scored = tid < n_whole ? n - 1 : rem; // a skipped slot keeps its window positions (nq_slot_scored)
         }
-        my_scored = wave_sum_i32(my_scored);
+        if (n_slots > 64 * wib) my_scored = wave_sum_i32(my_scored); // wave-uniform
         if (lane == 0) s_cnt[wib] = my_scored;
         __syncthreads(); // B2
+        SRV_STAMP(2);
         unsigned long long best = NQ_KEY_EMPTY;
         if (step) { // block-uniform
             if constexpr (PAIRS) {
-                long long n_whole = window / (n - 1);
-                if (n_whole > ncols) n_whole = ncols;
-                const long long rem = n_whole < ncols ? window - n_whole * (n - 1) : 0;
-                const int steps = (n + 127) >> 7;
-                int per_part = n_whole > 0 ? (int)((n_whole * steps + 15) / 16) : steps;
-                per_part = (per_part + 3) & ~3;
-                per_part = per_part > steps ? steps : (per_part < 4 ? 4 : per_part);
-                const int parts = (steps + per_part - 1) / per_part;
                 const int team = __builtin_amdgcn_readfirstlane(wib);
-                const int units = (int)n_whole * parts;
+                const int units = n_whole * parts;
                 for (int u = team; u < units; u += 16) {
                     const int slot = u / parts, part = u - slot * parts;
                     const int4 si = s_slot[slot];
@@ -212,12 +218,12 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
                     nq_pairs_unit<64, false>(s_t16, n, lane, c, rc, conf_old, slot, part * per_part, per_part, nullptr, 0, best);
                 }
                 if (rem > 0) { // the slot the window cuts: per-range loops, all lanes
-                    const int slot = (int)n_whole;
+                    const int slot = n_whole;
                     const int4 si = s_slot[slot];
                     const int c = si.x, rc = si.y, conf_old = si.z;
                     if (rc >= 0) {
                         const unsigned short *t16 = reinterpret_cast<const unsigned short *>(s_t16);
-                        const NqRanges rg = nq_ranges(0, n, rc, (long long)slot * (n - 1), window);
+                        const NqRanges rg = nq_ranges(0, n, rc, 0, rem); // `rem` candidates are left for this column
                         unsigned m = NQ_KEY32_EMPTY;
                         for (int v = rg.d0 + tid; v < rg.d1; v += 1024) {
                             const unsigned kk = (((unsigned)t16[v] + (unsigned)t16[oA + v - c + n] + (unsigned)t16[oB + v + c]) << 15) | (unsigned)v;
@@ -234,8 +240,7 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
                     }
                 }
             } else {
-                const unsigned magic = (unsigned)(0x100000000ull / (unsigned)n) + 1u; // k / n for k < 2^17, n < 2^14
-                const int kmax = (int)K;
+                const int kmax = n_whole * n + (rem > 0 ? rem + 1 : 0);   // unfiltered positions take(window) can reach (nq_k_limit)
 #pragma unroll 4
                 for (int k = tid; k < kmax; k += 1024) {
                     const int slot = (int)__umulhi((unsigned)k, magic);
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
                     const int4 si = s_slot[slot];
                     const int c = si.x, rc = si.y;
                     const bool up = v > rc;
-                    const long long rank = (long long)slot * (n - 1) + v - (up ? 1 : 0);
+                    const int rank = slot * (n - 1) + v - (up ? 1 : 0);
                     if (rc >= 0 && v != rc && rank < window) {
                         const int delta = tab16_get(s_t16, v) + tab16_get(s_t16, oA + v - c + n) + tab16_get(s_t16, oB + v + c) - si.z;
                         best = u64min(best, nq_key(delta, nq_key_hi(up ? 1 : 0, c, n, slot), v));
@@ -253,7 +258,9 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
         }
         best = wave_min_u64(best);
         if (lane == 0) s_best[wib] = best;
+        SRV_STAMP(3);
         __syncthreads(); // B3
+        SRV_STAMP(4);
         if (!want_cs && wib != 0) continue; // the other wavefronts are done: wave 0 answers, then patches the LDS state
         unsigned long long key = s_best[0];
 #pragma unroll
@@ -314,6 +321,12 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
             else if (lane == 4) pay = has_move ? (unsigned)mv : 0u;
             else if (lane == 5) pay = (has_move || !step) ? dl & 0xffffu : 0u;
             else if (lane == 6) pay = (has_move || !step) ? dl >> 16 : 0u;
+#ifdef LS_NQ_STAMPS
+            stamp[5] = wall_clock64();
+            if (lane >= 7 && lane < 12) { const unsigned long long dt = stamp[lane - 6] - stamp[0]; pay = dt > 0xffffu ? 0xffffu : (unsigned)dt; } // d7..d11: phase ends, 10 ns ticks
+            if (lane == 12) { const unsigned long long dc = (__builtin_amdgcn_s_memtime() - cyc0) >> 2; pay = dc > 0xffffu ? 0xffffu : (unsigned)dc; } // d12: shader cycles / 4 of the service
+            if (lane >= 8 && lane < 13) __hip_atomic_store(resp + lane, (last_tag << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
             if (lane < 8) __hip_atomic_store(resp + lane, (last_tag << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             t_served = wall_clock64();
             if (lane == 0) __hip_atomic_store(&a.ctl->last_activity, t_served, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -356,6 +369,8 @@ struct NqServer {
     std::atomic<unsigned long long> relaunches{0}, slow_waits{0}, fresh_boards{0}, requests{0};
     bool failed = false;
     struct Slot {
+        double t_pre = 0, t_wait = 0, t_post = 0; // LS_AMD_TRACE: where a call spends its time (host before / answer wait / host after)
+        unsigned long long calls = 0, dev_ticks[6] = {0, 0, 0, 0, 0, 0}; // stamps builds: phase ends of the workgroup's service, shader cycles / 4
         unsigned tag = 0;
         unsigned board_id = 0;
         bool valid = false, cs_valid = false;
@@ -465,6 +480,10 @@ static int server_ensure_running(ls_ctx *ctx, NqServer *s)
     std::lock_guard<std::mutex> lk(s->launch_mu);
     if (s->failed) return set_err(ctx, LS_ERR_HIP, "LS-step server: an earlier launch failed");
     if (!server_drained(s)) return LS_OK;
+    {
+        const hipError_t e = hipSetDevice(s->device); // the steady-state path makes no runtime call: this thread may never have bound the device
+        if (e != hipSuccess) return set_err(ctx, LS_ERR_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
+    }
     NqSrvArgs a;
     a.req = s->req(0); a.resp = s->resp(0); a.cols_ext = s->cols_ext(0); a.shadow = s->shadow(0);
     a.cs16 = reinterpret_cast<unsigned *>(s->cs16(0)); a.ctl = s->ctl; a.exit_gen = s->exit_gen();
@@ -484,6 +503,22 @@ static int server_ensure_running(ls_ctx *ctx, NqServer *s)
 void nq_server_destroy(NqServer *s)
 {
     if (!s) return;
+    if (getenv("LS_AMD_TRACE")) {
+        double pre = 0, wait = 0, post = 0;
+        unsigned long long calls = 0, ticks[6] = {0, 0, 0, 0, 0, 0};
+        for (const auto &sl : s->slots) {
+            pre += sl.t_pre; wait += sl.t_wait; post += sl.t_post; calls += sl.calls;
+            for (int d = 0; d < 6; d++) ticks[d] += sl.dev_ticks[d];
+        }
+        if (calls) {
+            fprintf(stderr, "ls step server (n = %d, %d slots): %llu steps, per step: host before %.2f us, answer wait %.2f us, host after %.2f us; %llu launches, "
+                            "%llu boards uploaded\n", s->n, s->n_slots, calls, pre / calls * 1e6, wait / calls * 1e6, post / calls * 1e6, s->relaunches.load(), s->fresh_boards.load());
+            if (ticks[4])
+                fprintf(stderr, "  workgroup, after the request was seen: request published to the block %.2f us, slot records %.2f, candidates scored %.2f, "
+                                "block minimum %.2f, answer written %.2f; %.0f shader cycles (%.2f GHz)\n", ticks[0] * 0.01 / calls, ticks[1] * 0.01 / calls, ticks[2] * 0.01 / calls,
+                        ticks[3] * 0.01 / calls, ticks[4] * 0.01 / calls, ticks[5] * 4.0 / calls, ticks[5] * 4.0 / (ticks[4] * 10.0));
+        }
+    }
     (void)hipSetDevice(s->device);
     if (!server_drained(s)) { // ask every workgroup to leave, then wait for the launch
         for (int i = 0; i < s->n_slots; i++) {
@@ -520,6 +555,11 @@ static int wait_line(ls_ctx *ctx, NqServer *s, int slot, unsigned out[8])
 {
     const unsigned tag = s->slots[(size_t)slot].tag;
     const volatile unsigned *r = s->resp(slot);
+    struct Announce { // what this wait waits for, for a scheduler behind wait_hook
+        ls_ctx *c;
+        Announce(ls_ctx *c_, const volatile unsigned *w, unsigned t) : c(c_) { c->wait_words = w; c->n_wait_words = 8; c->wait_tag = t; }
+        ~Announce() { c->wait_words = nullptr; c->n_wait_words = 0; }
+    } announce(ctx, r, tag);
     bool idle_work = ctx->idle_hook != nullptr;
     std::chrono::steady_clock::time_point t0;
     bool timed = false;
@@ -556,19 +596,27 @@ static int wait_line(ls_ctx *ctx, NqServer *s, int slot, unsigned out[8])
     }
 }
 
-// The board of this request versus what the slot holds: an unchanged board costs a 4n-byte compare, a new one is copied
-// into the pinned shadow and gets a new id (the workgroup then reads it from there).
-static void sync_board(NqServer *s, int slot, const int32_t *rows)
+// The board of this request versus what the slot holds: an unchanged board costs a 4n-byte compare; a new one is range-
+// checked, copied into the pinned shadow and gets a new id (the workgroup then reads it from there).  Returns the index of
+// an entry outside [0, n), or -1.
+static long long sync_board(NqServer *s, int slot, const int32_t *rows)
 {
     NqServer::Slot &sl = s->slots[(size_t)slot];
     int *sh = s->shadow(slot);
-    if (!sl.valid || memcmp(rows, sh, (size_t)s->n * 4) != 0) {
-        memcpy(sh, rows, (size_t)s->n * 4);
+    const int n = s->n;
+    if (!sl.valid || memcmp(rows, sh, (size_t)n * 4) != 0) {
+        uint32_t worst = 0; // (uint32_t)x < n  <=>  0 <= x < n
+        for (int i = 0; i < n; i++) worst = (uint32_t)rows[i] > worst ? (uint32_t)rows[i] : worst;
+        if (worst >= (uint32_t)n)
+            for (int i = 0; i < n; i++)
+                if ((uint32_t)rows[i] >= (uint32_t)n) return i;
+        memcpy(sh, rows, (size_t)n * 4);
         sl.valid = true;
         sl.cs_valid = false;
         sl.board_id = sl.board_id == 0xffffffffu ? 1u : sl.board_id + 1u;
         s->fresh_boards.fetch_add(1, std::memory_order_relaxed);
     }
+    return -1;
 }
 
 void nq_cs_after_move(const int32_t *rows, int32_t *cs, int n, int mc, int mv, int mq); // ls_api.hip
@@ -582,15 +630,30 @@ int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int6
     if (slot < 0 || slot >= s->n_slots) return set_err(ctx, LS_ERR_INVALID, "LS-step server: slot %d outside [0, %d)", slot, s->n_slots);
     const int n = s->n;
     NqServer::Slot &sl = s->slots[(size_t)slot];
-    sync_board(s, slot, rows);
+    static const bool trace = getenv("LS_AMD_TRACE") != nullptr;
+    const auto T0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    {
+        const long long bad = sync_board(s, slot, rows);
+        if (bad >= 0) return set_err(ctx, LS_ERR_INVALID, "rows[%lld] = %d outside [0, %d)", bad, rows[bad], n);
+    }
+    ctx->steps_done++;
     if (!next_col_scores) sl.cs_valid = false; // nobody keeps the scores across this call
     const bool want_cs = next_col_scores != nullptr && !(sl.cs_valid && ctx->nq_host_cs);
-    long long reach = n_cols;
-    if (window / (n - 1) < reach) reach = window / (n - 1) + 1; // slots take(window) can reach
+    // the window arithmetic of the step (nq_k_limit, nq_step_kernel) is done here: 64-bit divisions are slow on the device
+    const long long full = window / (n - 1);
+    const int n_whole = (int)(full < n_cols ? full : n_cols);
+    const int rem = n_whole < n_cols ? (int)(window - (long long)n_whole * (n - 1)) : 0;
+    const int reach = n_whole + (rem > 0 ? 1 : 0); // slots take(window) can reach (<= NQ_STEP_MAX_SLOTS: nq_step_eligible)
+    const int steps = (n + 127) >> 7;
+    int per_part = n_whole > 0 ? (int)(((long long)n_whole * steps + 15) / 16) : steps; // the sixteen wavefronts' fair share of the paired walk,
+    per_part = (per_part + 3) & ~3;                                                      // rounded up to its unroll factor of four
+    per_part = per_part > steps ? steps : (per_part < 4 ? 4 : per_part);
+    const int parts = (steps + per_part - 1) / per_part;
     unsigned pay[16] = {0};
     pay[0] = SRV_F_STEP | (want_cs ? SRV_F_WANT_CS : 0u);
-    pay[1] = (unsigned)(n_cols > NQ_STEP_MAX_SLOTS ? NQ_STEP_MAX_SLOTS : n_cols);
-    pay[2] = (unsigned)window & 0xffffu; pay[3] = (unsigned)(window >> 16) & 0xffffu;
+    pay[1] = (unsigned)n_whole;
+    pay[2] = (unsigned)rem;
+    pay[3] = (unsigned)parts | ((unsigned)per_part << 8);
     pay[4] = sl.board_id & 0xffffu; pay[5] = sl.board_id >> 16;
     if (reach > SRV_INLINE_COLS) {
         pay[0] |= SRV_F_EXT_COLS;
@@ -601,9 +664,11 @@ int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int6
     int rc = server_ensure_running(ctx, s);
     if (rc != LS_OK) return rc;
     post_line(s, slot, pay);
+    const auto T1 = trace ? std::chrono::steady_clock::now() : T0;
     unsigned r[8];
     rc = wait_line(ctx, s, slot, r);
     if (rc != LS_OK) { sl.valid = false; return rc; }
+    const auto T2 = trace ? std::chrono::steady_clock::now() : T0;
     const bool moved = (r[0] & 1u) != 0;
     if (!moved) {
         res->n_scored = 0; res->best_index = -1; res->best_score = 0; res->best_col = -1; res->best_value = -1;
@@ -627,6 +692,14 @@ int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int6
         }
     }
     if (moved) sh[res->best_col] = res->best_value; // the workgroup applied it to its LDS board
+    if (trace) {
+        const auto T3 = std::chrono::steady_clock::now();
+        auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        sl.t_pre += sec(T0, T1); sl.t_wait += sec(T1, T2); sl.t_post += sec(T2, T3);
+        sl.calls++;
+        const volatile unsigned *rl = s->resp(slot);
+        for (int d = 0; d < 6; d++) sl.dev_ticks[d] += (rl[7 + d] >> 16) == sl.tag ? rl[7 + d] & 0xffffu : 0u;
+    }
     return LS_OK;
 }
 
@@ -637,7 +710,10 @@ int nq_server_col_scores(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows
     if (slot < 0 || slot >= s->n_slots) return set_err(ctx, LS_ERR_INVALID, "LS-step server: slot %d outside [0, %d)", slot, s->n_slots);
     const int n = s->n;
     NqServer::Slot &sl = s->slots[(size_t)slot];
-    sync_board(s, slot, rows);
+    {
+        const long long bad = sync_board(s, slot, rows);
+        if (bad >= 0) return set_err(ctx, LS_ERR_INVALID, "rows[%lld] = %d outside [0, %d)", bad, rows[bad], n);
+    }
     unsigned pay[16] = {0};
     pay[0] = SRV_F_WANT_CS;
     pay[4] = sl.board_id & 0xffffu; pay[5] = sl.board_id >> 16;

@@ -19,9 +19,9 @@ LS_ERR_INVALID, LS_ERR_NO_DEVICE, LS_ERR_HIP, LS_ERR_UNSUPPORTED, LS_ERR_NOMEM, 
 LS_NQ_ALGO_SCAN, LS_NQ_ALGO_TABLE, LS_NQ_ALGO_AUTO = 0, 1, 2
 LS_NQ_MAX_N = 32768
 LS_SCHED_MAX_DAYS = 64
-LS_N_COUNTERS = 6
+LS_N_COUNTERS = 7
 COUNTER_NAMES = ("server_requests", "server_launches", "server_waits_on_drained_launch", "server_boards_uploaded",
-                 "completion_word_fallbacks", "resident_board_reuploads")
+                 "completion_word_fallbacks", "resident_board_reuploads", "fibres_taken_over")
 INT64_MIN = -(2 ** 63)
 
 _ERR_NAMES = {1: "LS_ERR_INVALID", 2: "LS_ERR_NO_DEVICE", 3: "LS_ERR_HIP", 4: "LS_ERR_UNSUPPORTED",

@@ -106,8 +106,10 @@ int ls_ctx_get_nq_algo(const ls_ctx *ctx, int *algo);
  *       -- LS_NQ_SERVER_IDLE_US -- and is started again on demand), [2] waits that found the launch drained under their
  *       request, [3] boards uploaded to server slots (a board that continues from the previous winner is not),
  *   [4] completion-word waits of launched steps that fell back to hipStreamSynchronize after 2 ms,
- *   [5] boards re-uploaded by the launch-per-call route (LS_NQ_STEP=3) because they were not the resident one. */
-#define LS_N_COUNTERS 6
+ *   [5] boards re-uploaded by the launch-per-call route (LS_NQ_STEP=3) because they were not the resident one,
+ *   [6] (ls_multi_solver only) restarts that an idle host thread took over from a busy one (slots beyond the cores are
+ *       cooperative fibres of one pool). */
+#define LS_N_COUNTERS 7
 int ls_ctx_get_counters(const ls_ctx *ctx, uint64_t out[LS_N_COUNTERS]);
 
 /* Device properties the harness reports (CU count, wavefront size, clock kHz, name). */

@@ -30,3 +30,15 @@ def test_weighted_sampler_histogram_selection_equals_selection_sort(tmp_path):
     for extra in ({}, {"LS_HOST_NO_AVX512": "1"}):
         r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
         assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (extra, r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_fibre_pool(tmp_path):
+    # csrc/host/fibers.hpp: ls_multi_solver's fibre pool (hand-written context switch, guard-paged stacks, idle workers take
+    # suspended fibres from busy ones) -- plain and under UBSan (ASan / TSan would need their fibre annotations)
+    src = os.path.join(ROOT, "tests", "cpp", "fiber_pool_test.cpp")
+    for flags in (["-O2"], ["-O1", "-fsanitize=undefined", "-fno-omit-frame-pointer"]):
+        exe = str(tmp_path / ("fiber_pool_test" + str(len(flags))))
+        subprocess.run(["g++", "-std=c++17", "-g", *flags, src, "-o", exe, "-lpthread"], check=True, capture_output=True, text=True, timeout=300)
+        for _ in range(3):
+            r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (flags, r.stdout[-2000:], r.stderr[-4000:])
