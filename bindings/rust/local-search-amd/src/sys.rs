@@ -108,6 +108,8 @@ extern "C" {
                                     cap: i32, len: *mut i32, have: *mut c_int) -> c_int;
     pub fn ls_multi_solver_get_stats(m: *const ls_multi_solver, ls_iterations: *mut u64, neighbours_scored: *mut u64,
                                      gpu_launches: *mut u64, rounds: *mut u64) -> c_int;
+    pub fn ls_multi_solver_get_restart_stats(m: *const ls_multi_solver, restart: i32, ls_iterations: *mut u64,
+                                             neighbours_scored: *mut u64, rounds: *mut u64) -> c_int;
     pub fn ls_multi_solver_get_counters(m: *const ls_multi_solver, out: *mut u64) -> c_int;
     pub fn ls_multi_solver_free(m: *mut ls_multi_solver) -> c_int;
     pub fn ls_host_hash_seed(seed: *const c_char, out32: *mut u8) -> c_int;

@@ -16,7 +16,11 @@
 // its only multi-run notion is the seed loop, examples/nqueens/src/main.rs:167).
 //
 // Switching is a dozen instructions (callee-saved registers + stack pointer; no signal-mask system call as in
-// swapcontext), stacks are mmap'ed with a guard page below them (an overflow faults instead of corrupting the heap).
+// swapcontext), stacks are mmap'ed with a guard page below them (an overflow faults instead of corrupting the heap) and as
+// large as a thread's (8 MB, committed lazily): a fibre calls into the HIP runtime, and with rocprofv3's tool library
+// interposed a kernel launch needs more than the 1 MB round 2 gave it -- that, not the profiler, was why the profiled
+// end-to-end run died (profiles/r03_rocprofv3_e2e_fibre_stack_overflow.stderr.txt: SIGSEGV at a page boundary under
+// hipLaunchKernel, called from a fibre).
 // A fibre only ever switches inside FiberPool::yield(), never inside a runtime call; after a switch it may be on another
 // thread, so nothing thread-local is cached across yield() (current_worker() is re-read, noinline).
 #pragma once
@@ -67,7 +71,7 @@ struct FiberWait {
 
 class FiberPool {
 public:
-    explicit FiberPool(int n_workers, size_t stack_bytes = 1 << 20) : stack_bytes_((stack_bytes + 4095) & ~(size_t)4095)
+    explicit FiberPool(int n_workers, size_t stack_bytes = (size_t)8 << 20) : stack_bytes_((stack_bytes + 4095) & ~(size_t)4095)
     {
         if (n_workers < 1) n_workers = 1;
         for (int i = 0; i < n_workers; i++) workers_.emplace_back(new Worker());

@@ -43,6 +43,7 @@ struct ls_multi_solver {
     uint64_t ls_iterations = 0, neighbours_scored = 0, gpu_launches = 0, rounds = 0;
     uint64_t counters[LS_N_COUNTERS] = {0}; // ls_multi_solver_get_counters: the last run's
     uint64_t fibre_steals = 0;
+    std::vector<uint64_t> restart_ls_iterations, restart_scored, restart_rounds; // per restart, of the last run
 };
 
 namespace {
@@ -426,6 +427,7 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
         }
         for (const std::string &e : errors)
             if (!e.empty()) throw std::runtime_error(e);
+        m->restart_ls_iterations = ls_it; m->restart_scored = scored; m->restart_rounds = rounds;
         m->ls_iterations = m->neighbours_scored = m->rounds = m->gpu_launches = 0;
         for (int r = 0; r < R; r++) {
             m->ls_iterations += ls_it[(size_t)r];
@@ -464,6 +466,17 @@ int ls_multi_solver_get_stats(const ls_multi_solver *m, uint64_t *ls_iterations,
     if (neighbours_scored) *neighbours_scored = m->neighbours_scored;
     if (gpu_launches) *gpu_launches = m->gpu_launches;
     if (rounds) *rounds = m->rounds;
+    return LS_OK;
+}
+
+int ls_multi_solver_get_restart_stats(const ls_multi_solver *m, int32_t restart, uint64_t *ls_iterations, uint64_t *neighbours_scored,
+                                      uint64_t *rounds)
+{
+    if (!m || restart < 0 || (size_t)restart >= m->seeds.size()) return LS_ERR_INVALID;
+    const size_t r = (size_t)restart;
+    if (ls_iterations) *ls_iterations = r < m->restart_ls_iterations.size() ? m->restart_ls_iterations[r] : 0;
+    if (neighbours_scored) *neighbours_scored = r < m->restart_scored.size() ? m->restart_scored[r] : 0;
+    if (rounds) *rounds = r < m->restart_rounds.size() ? m->restart_rounds[r] : 0;
     return LS_OK;
 }
 

@@ -374,6 +374,11 @@ class MultiSolver:
         self._ctx._check(self._l.ls_multi_solver_get_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return dict(ls_iterations=a.value, neighbours_scored=b.value, gpu_launches=c.value, rounds=d.value)
 
+    def restart_stats(self, restart: int) -> dict:
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._ctx._check(self._l.ls_multi_solver_get_restart_stats(self._h, int(restart), C.byref(a), C.byref(b), C.byref(c)))
+        return dict(ls_iterations=a.value, neighbours_scored=b.value, rounds=c.value)
+
     def counters(self) -> dict:
         out = np.zeros(_lib.LS_N_COUNTERS, dtype=np.uint64)
         self._ctx._check(self._l.ls_multi_solver_get_counters(self._h, _vp(out)))

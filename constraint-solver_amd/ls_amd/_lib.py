@@ -105,6 +105,7 @@ SIGNATURES = {
     "ls_multi_solver_get_best": (C.c_int, [_vp, _i32, _vp, _vp, _i32, C.POINTER(_i32), C.POINTER(C.c_int)]),
     "ls_multi_solver_get_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64)]),
+    "ls_multi_solver_get_restart_stats": (C.c_int, [_vp, _i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ls_multi_solver_get_counters": (C.c_int, [_vp, _vp]),
     "ls_multi_solver_free": (C.c_int, [_vp]),
     "ls_host_hash_seed": (C.c_int, [C.c_char_p, _vp]),

@@ -365,6 +365,10 @@ int ls_multi_solver_get_best(const ls_multi_solver *m, int32_t restart, int64_t 
 /* totals over all restarts: LS iterations, candidates scored, batched GPU launches, rounds executed */
 int ls_multi_solver_get_stats(const ls_multi_solver *m, uint64_t *ls_iterations, uint64_t *neighbours_scored,
                               uint64_t *gpu_launches, uint64_t *rounds);
+/* one restart of the last run (the same figures ls_solver_get_stats reports for a restart run alone: "same seed => same
+ * result", examples/nqueens/src/main.rs:156-200, extends to the iteration counts) */
+int ls_multi_solver_get_restart_stats(const ls_multi_solver *m, int32_t restart, uint64_t *ls_iterations,
+                                      uint64_t *neighbours_scored, uint64_t *rounds);
 int ls_multi_solver_get_counters(const ls_multi_solver *m, uint64_t out[LS_N_COUNTERS]); /* see ls_ctx_get_counters */
 int ls_multi_solver_free(ls_multi_solver *m);
 
