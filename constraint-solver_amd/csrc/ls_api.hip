@@ -177,6 +177,7 @@ int ls_ctx_create(int device_id, ls_ctx **out)
     if (const char *v = getenv("LS_NQ_HOST_CS")) ctx->nq_host_cs = atoi(v) != 0;
     if (const char *v = getenv("LS_NQ_RESIDENT_TABS")) ctx->nq_resident_tabs = atoi(v) != 0;
     if (const char *v = getenv("LS_SCHED_ONE_LAUNCH")) ctx->sched_one_launch = atoi(v) != 0;
+    if (const char *v = getenv("LS_SCHED_SERVER")) ctx->sched_server_on = atoi(v) != 0;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->wave_size = prop.warpSize;
     ctx->clock_khz = prop.clockRate;
@@ -196,8 +197,9 @@ int ls_ctx_destroy(ls_ctx *ctx)
 {
     if (!ctx) return LS_OK;
     (void)hipSetDevice(ctx->device);
-    if (ctx->server && ctx->server_owned) nq_server_destroy(ctx->server); // the resident launch leaves before anything is freed
+    if (ctx->server && ctx->server_owned) nq_server_destroy(ctx->server); // the resident launches leave before anything is freed
     ctx->server = nullptr;
+    sched_server_destroy(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     for_each_buf(ctx, [](DevBuf &b) { b.release(); });
     ctx->stage_in.release();
@@ -264,6 +266,11 @@ int ls_ctx_get_counters(const ls_ctx *ctx, uint64_t out[LS_N_COUNTERS])
         unsigned long long c4[4];
         nq_server_counters(ctx->server, c4);
         for (int i = 0; i < 4; i++) out[i] = c4[i];
+    }
+    {
+        unsigned long long c3[3];
+        sched_server_counters(ctx, c3); // the resident scheduling step counts into the same three
+        for (int i = 0; i < 3; i++) out[i] += c3[i];
     }
     out[4] = ctx->n_done_fallbacks;
     out[5] = ctx->n_resident_uploads;
@@ -816,7 +823,8 @@ int ls_sched_instance_upload(ls_ctx *ctx, int32_t n_days_scored, int32_t n_days_
         LS_REQUIRE(ctx, (holiday_bits[e] & ~scored_mask) == 0,
                    "employee %d has a holiday outside the scored range (the reference panics here: "
                    "examples/employee-scheduling/src/lib.rs:275)", e);
-    // the stream may still be reading the previous instance
+    // the stream (and the resident scheduling step, whose launch arguments are this instance) may still be reading the previous one
+    sched_server_pause(ctx);
     LS_SYNC(ctx);
     LS_RESERVE(ctx, ctx->sched.holiday_bits, (size_t)n_employees * 8);
     LS_HIP(ctx, hipMemcpyAsync(ctx->sched.holiday_bits.p, holiday_bits, (size_t)n_employees * 8,
@@ -849,6 +857,7 @@ int ls_sched_score(ls_ctx *ctx, int32_t n_states, const int32_t *states, int64_t
     LS_BIND(ctx);
     if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
     LS_REQUIRE(ctx, n_states >= 1 && states && hard && soft, "bad arguments");
+    if (n_states == 1 && !terms && sched_server_can_score(ctx)) return sched_server_score(ctx, states, hard, soft); // no launch
     const int S = ctx->sched.n_days_stored;
     int rc = sched_check_state(ctx, states, (long long)n_states * S);
     if (rc != LS_OK) return rc;
@@ -988,6 +997,7 @@ int ls_sched_moves_upload(ls_ctx *ctx, const ls_sched_move *moves, int64_t n_mov
     LS_REQUIRE(ctx, n_moves >= 0 && (moves || n_moves == 0), "bad arguments");
     int rc = sched_check_moves(ctx, moves, n_moves, 0);
     if (rc != LS_OK) return rc;
+    sched_server_pause(ctx); // the resident scheduling step holds the previous list: it leaves and is started again with the new one
     LS_SYNC(ctx); // the stream may still read the previous list
     LS_RESERVE(ctx, ctx->sc_resident_moves, (size_t)n_moves * sizeof(ls_sched_move));
     if (n_moves)
@@ -995,6 +1005,7 @@ int ls_sched_moves_upload(ls_ctx *ctx, const ls_sched_move *moves, int64_t n_mov
                                    hipMemcpyHostToDevice, ctx->stream));
     LS_SYNC(ctx);
     ctx->sc_resident_n = n_moves;
+    ctx->sc_resident_host.assign(moves, moves + n_moves);
     return LS_OK;
 }
 
@@ -1006,6 +1017,7 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
     LS_REQUIRE(ctx, n_moves >= 0 && n_moves <= ctx->sc_resident_n, "n_moves = %lld exceeds the resident list (%lld)",
                (long long)n_moves, ctx->sc_resident_n);
     const int S = ctx->sched.n_days_stored;
+    if (sched_server_eligible(ctx, n_moves)) return sched_server_eval(ctx, state, n_moves, window, out); // no launch: the resident workgroup
     int rc = sched_check_state(ctx, state, S);
     if (rc != LS_OK) return rc;
     const size_t o_nm = 0, o_st = 256, in_b = align256(o_st + (size_t)S * 4), out_b = 256;

@@ -131,6 +131,7 @@ struct NqResident {
 
 // The resident LS-step server (nq_server.hip): one never-ending launch per device whose workgroups are the slots.
 struct NqServer;
+struct SchedServer; // sched_kernels.hip: the resident scheduling LS step (one workgroup per context)
 
 struct SchedInstance {
     bool valid = false;
@@ -194,6 +195,9 @@ struct ls_ctx {
     lsamd::DevBuf sc_states, sc_moves, sc_nmoves, sc_results, sc_hard, sc_soft, sc_keys, sc_terms, sc_cand_keys, sc_ticket;
     lsamd::SchedInstance sched;
     lsamd::DevBuf sc_resident_moves; // ls_sched_moves_upload
+    std::vector<ls_sched_move> sc_resident_host; // host copy of the resident list (the server route applies winners to its shadow state)
+    lsamd::SchedServer *sched_server = nullptr;  // resident scheduling LS step (started on demand by ls_sched_eval_resident)
+    bool sched_server_on = true;                 // LS_SCHED_SERVER=0: one launch per call
     lsamd::Staging stage_in, stage_out;
     lsamd::NqResident nq_res;
     long long sc_resident_n = 0;
@@ -213,6 +217,14 @@ void nq_server_counters(const NqServer *s, unsigned long long out[4]); // reques
 int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int64_t cur_score, const int32_t *cols, int32_t n_cols,
                    long long window, ls_nq_result *res, int64_t *next_col_scores);
 int nq_server_col_scores(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int64_t *col_scores, int64_t *total);
+// sched_kernels.hip
+bool sched_server_eligible(const ls_ctx *ctx, long long n_moves);
+void sched_server_pause(ls_ctx *ctx);
+void sched_server_destroy(ls_ctx *ctx);
+void sched_server_counters(const ls_ctx *ctx, unsigned long long out[3]); // requests, launches, waits that found the launch drained
+bool sched_server_can_score(const ls_ctx *ctx);
+int sched_server_score(ls_ctx *ctx, const int32_t *state, int64_t *hard, int64_t *soft);
+int sched_server_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out);
 // ls_api.hip
 int nq_ctx_server(ls_ctx *ctx, int n, NqServer **out);
 int nq_ctx_prepare_server(ls_ctx *ctx, int n);

@@ -9,21 +9,8 @@
 // nothing else; a board the slot does not hold (after a perturbation, iterated_local_search.rs:192-194, or after a
 // relaunch) is read once from the slot's pinned shadow copy.
 //
-// Mailbox protocol (no ordering assumption on the PCIe reads of one line, no atomics over PCIe): every dword of a line is
-// (tag16 << 16 | payload16); the writer gives all dwords of one message the same new tag, the reader takes a snapshot
-// with one dword per lane and accepts it only if all tags are equal (a torn snapshot mixes two tags and is simply polled
-// again).  Bulk data (a fresh board, more than 10 proposed columns, the column scores of a fresh board) lives in the
-// slot's pinned block and is written before the line that announces it.
-//
-// Leaving: the kernel must never outlive its use.  Every workgroup leaves (a) on a QUIT request, (b) when the launch's
-// quit word is raised, which any workgroup does once NO slot has been served for `idle_ticks` (default 2 ms) or the
-// launch is older than `limit_ticks` (2 s) -- so a dead or paused host cannot leave a kernel spinning -- and the last one
-// out publishes the launch generation to a host word.  The host relaunches on demand: a request posted while the
-// kernel drains is found by the next launch (the last SERVED tag is read back from the response line).
-//
-// The launch lives on its own hardware queue (a CU-masked stream; fallback: high priority): HIP multiplexes ordinary
-// streams onto a few queues and a queue runs its packets in order, so a resident kernel on an ordinary stream blocks
-// whatever stream shares its queue (tools/server_probe.hip: the 6th stream created afterwards waited 0.46 s).
+// The mailbox protocol, the rules by which the launch leaves (QUIT, 2 ms without any request, 2 s age limit) and comes back
+// on demand, and its private hardware queue are shared with the scheduling server: srv_common.hpp.
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -33,32 +20,22 @@
 #include <sched.h>
 
 #include "nq_device.hpp"
+#include "srv_common.hpp"
 
 namespace lsamd {
 
 constexpr int SRV_INLINE_COLS = 10;
-constexpr unsigned SRV_F_STEP = 1u, SRV_F_WANT_CS = 2u, SRV_F_QUIT = 4u, SRV_F_EXT_COLS = 8u;
-
-struct NqSrvCtl {               // device memory, one per server
-    unsigned long long quit_gen;      // == the running launch's generation: everybody leaves
-    unsigned long long last_activity; // wall clock (100 MHz) of the last served request of any slot
-    unsigned exited;                  // workgroups of the running launch that have left
-    unsigned pad;
-};
+constexpr unsigned SRV_F_STEP = 1u, SRV_F_WANT_CS = 2u, SRV_F_EXT_COLS = 8u; // + SRV_F_QUIT = 4 (srv_common.hpp)
 
 struct NqSrvArgs {
-    const unsigned *req;          // [slots][16]  pinned host: request lines
-    unsigned *resp;               // [slots][16]  pinned host: response lines
+    SrvLink link;                 // request / answer lines, control block, launch generation and leaving rules
     const int *cols_ext;          // [slots][NQ_STEP_MAX_SLOTS] pinned host
     const int *shadow;            // [slots][n_pad] pinned host: the board of the slot's current request
     unsigned *cs16;               // [slots][n_pad / 2] pinned host: column scores, two u16 per word
-    NqSrvCtl *ctl;
-    unsigned long long *exit_gen; // pinned host
-    unsigned long long gen, idle_ticks, limit_ticks;
     int n, n_pad;
 };
 
-template <class T> __device__ __forceinline__ T sys_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+template <class T> __device__ __forceinline__ T sys_load(const T *p) { return srv_sys_load(p); }
 
 // One workgroup = one slot.  Request line: d0 flags, d1 whole columns take(window) reaches, d2 candidates taken from the next
 // column, d3 parts per column | steps per part << 8 (the split of the paired walk), d4-5 board id, d6-15 the first ten columns.
@@ -80,17 +57,15 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
     int *s_rows = reinterpret_cast<int *>(s_dyn + words);
     int4 *s_slot = reinterpret_cast<int4 *>(s_rows + ((n + 3) & ~3));
     const int oR1 = n, oA = PAIRS ? 2 * n : n, oB = PAIRS ? 4 * n + 2 : 3 * n;
-    const unsigned *req = a.req + (size_t)blockIdx.x * 16;
-    unsigned *resp = a.resp + (size_t)blockIdx.x * 16;
+    const unsigned *req = a.link.req + (size_t)blockIdx.x * 16;
+    unsigned *resp = a.link.resp + (size_t)blockIdx.x * 16;
     const int *shadow = a.shadow + (size_t)blockIdx.x * a.n_pad;
     const int *cols_ext = a.cols_ext + (size_t)blockIdx.x * NQ_STEP_MAX_SLOTS;
     unsigned *cs16 = a.cs16 + (size_t)blockIdx.x * (a.n_pad >> 1);
 
     const unsigned magic = 0xffffffffu / (unsigned)n + 1u; // ceil(2^32 / n): k / n == umulhi(k, magic) for k < 2^17, n < 2^14
     unsigned lds_board = 0;      // id of the board this workgroup holds in LDS (0: none); block-uniform
-    // wave 0's poll state
-    unsigned last_tag = 0;
-    unsigned long long t_start = 0, t_served = 0;
+    SrvPoll poll{0, 0, 0}; // wave 0's
 #ifdef LS_NQ_STAMPS
     unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0}; // wave 0: request seen, B1 passed, slot records done (B2), scored, B3 passed, answer ready
     unsigned long long cyc0 = 0;                       // shader-clock counter when the request was seen
@@ -98,51 +73,11 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
 #else
 #define SRV_STAMP(I) do { } while (0)
 #endif
-    if (wib == 0) {
-        t_start = t_served = wall_clock64();
-        last_tag = sys_load(resp) >> 16; // the last request an earlier launch answered
-        last_tag = __builtin_amdgcn_readfirstlane(last_tag);
-        if (lane == 0) atomicMax(&a.ctl->last_activity, t_start); // nobody reads a stale activity stamp of an earlier launch
-    }
+    if (wib == 0) srv_poll_begin(poll, a.link, resp, lane);
     for (;;) {
         if (wib == 0) {
-            int leave = 0;
-            for (unsigned polls = 1;; polls++) {
-                unsigned v = 0;
-                unsigned long long q = 0;
-                if (lane < 16) v = sys_load(req + lane);
-                if (lane == 16) q = __hip_atomic_load(&a.ctl->quit_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned tag = v >> 16;
-                const unsigned t0 = __builtin_amdgcn_readfirstlane(tag);
-                const bool whole = __builtin_amdgcn_ballot_w64(lane < 16 && tag != t0) == 0;
-                if (whole && t0 != last_tag && t0 != 0) {
-                    if (lane < 16) s_req[lane] = v & 0xffffu;
-                    last_tag = t0;
-                    SRV_STAMP(0);
-                    leave = (__builtin_amdgcn_readfirstlane(v) & SRV_F_QUIT) ? 1 : 0;
-                    break;
-                }
-                const unsigned qlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)q, 16);
-                const unsigned qhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(q >> 32), 16);
-                if ((((unsigned long long)qhi << 32) | qlo) == a.gen) { leave = 1; break; }
-                const unsigned long long now = wall_clock64();
-                if ((polls & 15u) == 0) { // nobody served for idle_ticks, or the launch has reached its age limit: everybody leaves
-                    unsigned long long la = 0;
-                    if (lane == 0) la = __hip_atomic_load(&a.ctl->last_activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned llo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)la);
-                    const unsigned lhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(la >> 32));
-                    la = ((unsigned long long)lhi << 32) | llo;
-                    if ((now > la && now - la > a.idle_ticks) || now - t_start > a.limit_ticks) {
-                        if (lane == 0) __hip_atomic_store(&a.ctl->quit_gen, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        leave = 1;
-                        break;
-                    }
-                }
-                // a slot in the middle of a walk is asked again within microseconds; one that has been quiet for longer polls less often
-                if (now - t_served > 20000) __builtin_amdgcn_s_sleep(64);      // > 200 us quiet: ~2 us between polls
-                else if (now - t_served > 2000) __builtin_amdgcn_s_sleep(8);   // > 20 us quiet
-                else __builtin_amdgcn_s_sleep(1);
-            }
+            const int leave = srv_poll_wait(poll, a.link, req, s_req, lane);
+            SRV_STAMP(0);
             if (lane == 0) s_leave = leave;
         }
         __syncthreads(); // B1: the request is in s_req; wave 0's LDS patches of the previous step are visible
@@ -325,11 +260,10 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
             stamp[5] = wall_clock64();
             if (lane >= 7 && lane < 12) { const unsigned long long dt = stamp[lane - 6] - stamp[0]; pay = dt > 0xffffu ? 0xffffu : (unsigned)dt; } // d7..d11: phase ends, 10 ns ticks
             if (lane == 12) { const unsigned long long dc = (__builtin_amdgcn_s_memtime() - cyc0) >> 2; pay = dc > 0xffffu ? 0xffffu : (unsigned)dc; } // d12: shader cycles / 4 of the service
-            if (lane >= 8 && lane < 13) __hip_atomic_store(resp + lane, (last_tag << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane >= 8 && lane < 13) __hip_atomic_store(resp + lane, (poll.last_tag << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
-            if (lane < 8) __hip_atomic_store(resp + lane, (last_tag << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            t_served = wall_clock64();
-            if (lane == 0) __hip_atomic_store(&a.ctl->last_activity, t_served, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < 8) __hip_atomic_store(resp + lane, (poll.last_tag << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            srv_served(poll, a.link, lane);
             if (has_move && lane < 8) { // the old queen leaves (lanes 0..3), the new one arrives (4..7): row, shifted row copy, two diagonals
                 const int q = lane < 4 ? mq : mv, what = lane & 3;
                 int idx = -1;
@@ -345,44 +279,28 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
             }
         }
     }
-    // leaving: the last workgroup out tells the host that this launch has drained
-    if (tid == 0) {
-        if (__hip_atomic_fetch_add(&a.ctl->exited, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-            __hip_atomic_store(&a.ctl->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.exit_gen, a.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    if (tid == 0) srv_block_leaves(a.link);
 }
 
 // ------------------------------------------------------------------------------------------------------------ host side
 struct NqServer {
-    int device = 0, n = 0, n_pad = 0, n_slots = 0;
+    SrvHost h;                   // stream, lines, control block, (re)launch, post / wait
+    int n = 0, n_pad = 0, n_slots = 0;
     bool pairs = false;
-    hipStream_t stream = nullptr;
-    char *pinned = nullptr;      // req lines | resp lines | exit word | cols_ext | shadow | cs16
-    size_t o_req = 0, o_resp = 0, o_exit = 0, o_cols = 0, o_shadow = 0, o_cs = 0;
-    NqSrvCtl *ctl = nullptr;
+    size_t o_cols = 0, o_shadow = 0, o_cs = 0; // in h.extra(): cols_ext | shadow | cs16
     size_t lds = 0;
-    unsigned long long idle_ticks = 200000, limit_ticks = 200000000ull; // 2 ms, 2 s (100 MHz)
-    std::mutex launch_mu;
-    std::atomic<unsigned long long> launch_gen{0};
-    std::atomic<unsigned long long> relaunches{0}, slow_waits{0}, fresh_boards{0}, requests{0};
-    bool failed = false;
+    std::atomic<unsigned long long> fresh_boards{0};
     struct Slot {
         double t_pre = 0, t_wait = 0, t_post = 0; // LS_AMD_TRACE: where a call spends its time (host before / answer wait / host after)
         unsigned long long calls = 0, dev_ticks[6] = {0, 0, 0, 0, 0, 0}; // stamps builds: phase ends of the workgroup's service, shader cycles / 4
-        unsigned tag = 0;
         unsigned board_id = 0;
         bool valid = false, cs_valid = false;
         std::vector<int32_t> cs;
     };
     std::vector<Slot> slots;
-    unsigned *req(int s) const { return reinterpret_cast<unsigned *>(pinned + o_req) + (size_t)s * 16; }
-    unsigned *resp(int s) const { return reinterpret_cast<unsigned *>(pinned + o_resp) + (size_t)s * 16; }
-    unsigned long long *exit_gen() const { return reinterpret_cast<unsigned long long *>(pinned + o_exit); }
-    int *cols_ext(int s) const { return reinterpret_cast<int *>(pinned + o_cols) + (size_t)s * NQ_STEP_MAX_SLOTS; }
-    int *shadow(int s) const { return reinterpret_cast<int *>(pinned + o_shadow) + (size_t)s * n_pad; }
-    unsigned short *cs16(int s) const { return reinterpret_cast<unsigned short *>(pinned + o_cs) + (size_t)s * n_pad; }
+    int *cols_ext(int s) const { return reinterpret_cast<int *>(h.extra() + o_cols) + (size_t)s * NQ_STEP_MAX_SLOTS; }
+    int *shadow(int s) const { return reinterpret_cast<int *>(h.extra() + o_shadow) + (size_t)s * n_pad; }
+    unsigned short *cs16(int s) const { return reinterpret_cast<unsigned short *>(h.extra() + o_cs) + (size_t)s * n_pad; }
 };
 
 bool nq_server_supports(const ls_ctx *ctx, int n)
@@ -395,7 +313,7 @@ int nq_server_slots(const NqServer *s) { return s->n_slots; }
 
 void nq_server_counters(const NqServer *s, unsigned long long out[4])
 {
-    out[0] = s->requests.load(); out[1] = s->relaunches.load(); out[2] = s->slow_waits.load(); out[3] = s->fresh_boards.load();
+    out[0] = s->h.requests.load(); out[1] = s->h.relaunches.load(); out[2] = s->h.slow_waits.load(); out[3] = s->fresh_boards.load();
 }
 
 static const void *server_fn(bool pairs)
@@ -410,93 +328,42 @@ int nq_server_create(ls_ctx *ctx, int n, int n_slots, NqServer **out)
         return set_err(ctx, LS_ERR_UNSUPPORTED, "LS-step server: n = %d, %d slots outside what one resident launch holds", n, n_slots);
     NqServer *s = new (std::nothrow) NqServer();
     if (!s) return set_err(ctx, LS_ERR_NOMEM, "out of host memory");
-    s->device = ctx->device;
     s->n = n;
     s->n_pad = (n + 63) & ~63;
     s->n_slots = n_slots;
     s->pairs = (n & 1) == 0 && n >= 128 && ctx->nq_table_variant >= 10;
-    if (const char *v = getenv("LS_NQ_SERVER_IDLE_US")) { const long long us = atoll(v); if (us >= 50) s->idle_ticks = (unsigned long long)us * 100; }
-    if (const char *v = getenv("LS_NQ_SERVER_LIMIT_MS")) { const long long ms = atoll(v); if (ms >= 1) s->limit_ticks = (unsigned long long)ms * 100000; }
     const size_t tab_words = s->pairs ? ((((size_t)(6 * n + 4) >> 1) + 3) & ~(size_t)3) : ((((size_t)(5 * n + 1) / 2) + 3) & ~(size_t)3);
     s->lds = (tab_words + (((size_t)n + 3) & ~(size_t)3) + 4 * (size_t)NQ_STEP_MAX_SLOTS) * 4;
-    auto fail = [&](int code, const char *what, hipError_t e) {
-        set_err(ctx, code, "LS-step server: %s failed: %s", what, hipGetErrorString(e));
-        if (s->stream) (void)hipStreamDestroy(s->stream);
-        if (s->pinned) (void)hipHostFree(s->pinned);
-        if (s->ctl) (void)hipFree(s->ctl);
-        delete s;
-        return code;
-    };
-    hipError_t e;
-    {   // a hardware queue of its own: CU-masked streams are never pooled; fallback: the high-priority pool
-        std::vector<uint32_t> mask(((size_t)ctx->n_cus + 31) / 32, 0xffffffffu);
-        if (ctx->n_cus % 32) mask.back() = (1u << (ctx->n_cus % 32)) - 1u;
-        e = getenv("LS_NQ_SERVER_PRIO_STREAM") ? hipErrorNotSupported : hipExtStreamCreateWithCUMask(&s->stream, (uint32_t)mask.size(), mask.data());
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            e = hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, hi);
-        }
-        if (e != hipSuccess) { s->stream = nullptr; return fail(LS_ERR_HIP, "stream creation", e); }
-    }
     size_t off = 0;
-    s->o_req = off; off += (size_t)n_slots * 64;
-    s->o_resp = off; off += (size_t)n_slots * 64;
-    s->o_exit = off; off += 64;
     s->o_cols = off; off += (size_t)n_slots * NQ_STEP_MAX_SLOTS * 4;
     s->o_shadow = off; off += (size_t)n_slots * s->n_pad * 4;
     s->o_cs = off; off += (size_t)n_slots * s->n_pad * 2;
-    e = hipHostMalloc(reinterpret_cast<void **>(&s->pinned), off, hipHostMallocCoherent);
-    if (e != hipSuccess) { s->pinned = nullptr; return fail(LS_ERR_NOMEM, "pinned allocation", e); }
-    memset(s->pinned, 0, off);
-    e = hipMalloc(reinterpret_cast<void **>(&s->ctl), 256);
-    if (e != hipSuccess) { s->ctl = nullptr; return fail(LS_ERR_NOMEM, "device allocation", e); }
-    hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(64), 0, s->stream, reinterpret_cast<long long *>(s->ctl), 0ll, 32ll);
-    if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(s->stream)) != hipSuccess) return fail(LS_ERR_HIP, "control block set-up", e);
+    int rc = s->h.init(ctx, "LS-step server", n_slots, off);
+    if (rc != LS_OK) { delete s; return rc; }
     static std::atomic<bool> attr_done_dev[64];
     if (!attr_done_dev[ctx->device & 63].load(std::memory_order_acquire)) {
         const int max_lds = (((6 * NQ_STEP_MAX_N + 4) / 2 + 4) + NQ_STEP_MAX_N + 4 * NQ_STEP_MAX_SLOTS) * 4;
+        hipError_t e;
         if ((e = hipFuncSetAttribute(server_fn(false), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess ||
-            (e = hipFuncSetAttribute(server_fn(true), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess)
-            return fail(LS_ERR_HIP, "hipFuncSetAttribute", e);
+            (e = hipFuncSetAttribute(server_fn(true), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) {
+            rc = set_err(ctx, LS_ERR_HIP, "LS-step server: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            s->h.release();
+            delete s;
+            return rc;
+        }
         attr_done_dev[ctx->device & 63].store(true, std::memory_order_release);
     }
     s->slots.resize((size_t)n_slots);
     for (auto &sl : s->slots) sl.cs.resize((size_t)n);
+    s->h.launch = [s](const SrvLink &L) {
+        NqSrvArgs a;
+        a.link = L;
+        a.cols_ext = s->cols_ext(0); a.shadow = s->shadow(0); a.cs16 = reinterpret_cast<unsigned *>(s->cs16(0));
+        a.n = s->n; a.n_pad = s->n_pad;
+        void *args[] = {&a};
+        return hipLaunchKernel(server_fn(s->pairs), dim3((unsigned)s->n_slots), dim3(1024), args, s->lds, s->h.stream);
+    };
     *out = s;
-    return LS_OK;
-}
-
-static bool server_drained(const NqServer *s)
-{
-    return __atomic_load_n(s->exit_gen(), __ATOMIC_ACQUIRE) == s->launch_gen.load(std::memory_order_acquire);
-}
-
-// (Re)launch when the previous launch has drained (or none has been made).  Cheap when the kernel is resident.
-static int server_ensure_running(ls_ctx *ctx, NqServer *s)
-{
-    if (!server_drained(s)) return LS_OK;
-    std::lock_guard<std::mutex> lk(s->launch_mu);
-    if (s->failed) return set_err(ctx, LS_ERR_HIP, "LS-step server: an earlier launch failed");
-    if (!server_drained(s)) return LS_OK;
-    {
-        const hipError_t e = hipSetDevice(s->device); // the steady-state path makes no runtime call: this thread may never have bound the device
-        if (e != hipSuccess) return set_err(ctx, LS_ERR_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
-    }
-    NqSrvArgs a;
-    a.req = s->req(0); a.resp = s->resp(0); a.cols_ext = s->cols_ext(0); a.shadow = s->shadow(0);
-    a.cs16 = reinterpret_cast<unsigned *>(s->cs16(0)); a.ctl = s->ctl; a.exit_gen = s->exit_gen();
-    a.gen = s->launch_gen.load() + 1; a.idle_ticks = s->idle_ticks; a.limit_ticks = s->limit_ticks;
-    a.n = s->n; a.n_pad = s->n_pad;
-    void *args[] = {&a};
-    const hipError_t e = hipLaunchKernel(server_fn(s->pairs), dim3((unsigned)s->n_slots), dim3(1024), args, s->lds, s->stream);
-    if (e != hipSuccess) {
-        s->failed = true;
-        return set_err(ctx, LS_ERR_HIP, "LS-step server: launch failed: %s", hipGetErrorString(e));
-    }
-    s->launch_gen.store(a.gen, std::memory_order_release);
-    s->relaunches.fetch_add(1, std::memory_order_relaxed);
     return LS_OK;
 }
 
@@ -512,88 +379,15 @@ void nq_server_destroy(NqServer *s)
         }
         if (calls) {
             fprintf(stderr, "ls step server (n = %d, %d slots): %llu steps, per step: host before %.2f us, answer wait %.2f us, host after %.2f us; %llu launches, "
-                            "%llu boards uploaded\n", s->n, s->n_slots, calls, pre / calls * 1e6, wait / calls * 1e6, post / calls * 1e6, s->relaunches.load(), s->fresh_boards.load());
+                            "%llu boards uploaded\n", s->n, s->n_slots, calls, pre / calls * 1e6, wait / calls * 1e6, post / calls * 1e6, s->h.relaunches.load(), s->fresh_boards.load());
             if (ticks[4])
                 fprintf(stderr, "  workgroup, after the request was seen: request published to the block %.2f us, slot records %.2f, candidates scored %.2f, "
                                 "block minimum %.2f, answer written %.2f; %.0f shader cycles (%.2f GHz)\n", ticks[0] * 0.01 / calls, ticks[1] * 0.01 / calls, ticks[2] * 0.01 / calls,
                         ticks[3] * 0.01 / calls, ticks[4] * 0.01 / calls, ticks[5] * 4.0 / calls, ticks[5] * 4.0 / (ticks[4] * 10.0));
         }
     }
-    (void)hipSetDevice(s->device);
-    if (!server_drained(s)) { // ask every workgroup to leave, then wait for the launch
-        for (int i = 0; i < s->n_slots; i++) {
-            NqServer::Slot &sl = s->slots[(size_t)i];
-            sl.tag = sl.tag >= 0xfffeu ? 1u : sl.tag + 1u;
-            alignas(64) unsigned line[16];
-            for (int d = 0; d < 16; d++) line[d] = sl.tag << 16;
-            line[0] |= SRV_F_QUIT;
-            memcpy(s->req(i), line, 64);
-        }
-    }
-    (void)hipStreamSynchronize(s->stream);
-    (void)hipStreamDestroy(s->stream);
-    (void)hipHostFree(s->pinned);
-    (void)hipFree(s->ctl);
+    s->h.shutdown();
     delete s;
-}
-
-static void post_line(NqServer *s, int slot, const unsigned pay[16])
-{
-    NqServer::Slot &sl = s->slots[(size_t)slot];
-    sl.tag = sl.tag >= 0xfffeu ? 1u : sl.tag + 1u;
-    alignas(64) unsigned line[16];
-    for (int d = 0; d < 16; d++) line[d] = (sl.tag << 16) | (pay[d] & 0xffffu);
-    __atomic_thread_fence(__ATOMIC_RELEASE); // the bulk data (board, columns) is written before the line that announces it
-    volatile unsigned *dst = s->req(slot);
-    for (int d = 0; d < 16; d++) dst[d] = line[d];
-    s->requests.fetch_add(1, std::memory_order_relaxed);
-}
-
-// Poll the slot's response line for the tag of the request just posted (the same hooks as the completion-word wait of the
-// launched LS step: the caller's idle work, another restart's fibre, sched_yield).
-static int wait_line(ls_ctx *ctx, NqServer *s, int slot, unsigned out[8])
-{
-    const unsigned tag = s->slots[(size_t)slot].tag;
-    const volatile unsigned *r = s->resp(slot);
-    struct Announce { // what this wait waits for, for a scheduler behind wait_hook
-        ls_ctx *c;
-        Announce(ls_ctx *c_, const volatile unsigned *w, unsigned t) : c(c_) { c->wait_words = w; c->n_wait_words = 8; c->wait_tag = t; }
-        ~Announce() { c->wait_words = nullptr; c->n_wait_words = 0; }
-    } announce(ctx, r, tag);
-    bool idle_work = ctx->idle_hook != nullptr;
-    std::chrono::steady_clock::time_point t0;
-    bool timed = false;
-    for (unsigned spins = 0;; spins++) {
-        unsigned v[8];
-        bool ok = true;
-        for (int d = 0; d < 8; d++) { v[d] = r[d]; ok = ok && (v[d] >> 16) == tag; }
-        if (ok) {
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            for (int d = 0; d < 8; d++) out[d] = v[d] & 0xffffu;
-            return LS_OK;
-        }
-        if (idle_work) { idle_work = ctx->idle_hook(ctx->idle_arg); continue; }
-        if (ctx->wait_hook) ctx->wait_hook(ctx->wait_hook_arg);
-#if defined(__x86_64__)
-        else __builtin_ia32_pause();
-#endif
-        if (ctx->yield_while_waiting && spins >= 64) sched_yield();
-        if ((spins & 15u) == 15u) {
-            // has the launch drained under the request (idle time-out, age limit)?  Then it is launched again and finds the request.
-            if (server_drained(s)) {
-                s->slow_waits.fetch_add(1, std::memory_order_relaxed);
-                const int rc = server_ensure_running(ctx, s);
-                if (rc != LS_OK) return rc;
-            }
-            if ((spins & 0x3ffu) == 0x3ffu) {
-                if (!timed) { t0 = std::chrono::steady_clock::now(); timed = true; }
-                else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
-                    const hipError_t e = hipStreamQuery(s->stream);
-                    return set_err(ctx, LS_ERR_HIP, "LS-step server: no answer from slot %d within 10 s (stream: %s)", slot, hipGetErrorString(e));
-                }
-            }
-        }
-    }
 }
 
 // The board of this request versus what the slot holds: an unchanged board costs a 4n-byte compare; a new one is range-
@@ -661,12 +455,12 @@ int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int6
     } else {
         for (int i = 0; i < (int)reach; i++) pay[6 + i] = (unsigned)cols[i];
     }
-    int rc = server_ensure_running(ctx, s);
+    int rc = s->h.ensure_running(ctx);
     if (rc != LS_OK) return rc;
-    post_line(s, slot, pay);
+    s->h.post(slot, pay);
     const auto T1 = trace ? std::chrono::steady_clock::now() : T0;
     unsigned r[8];
-    rc = wait_line(ctx, s, slot, r);
+    rc = s->h.wait(ctx, slot, r);
     if (rc != LS_OK) { sl.valid = false; return rc; }
     const auto T2 = trace ? std::chrono::steady_clock::now() : T0;
     const bool moved = (r[0] & 1u) != 0;
@@ -697,8 +491,8 @@ int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int6
         auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
         sl.t_pre += sec(T0, T1); sl.t_wait += sec(T1, T2); sl.t_post += sec(T2, T3);
         sl.calls++;
-        const volatile unsigned *rl = s->resp(slot);
-        for (int d = 0; d < 6; d++) sl.dev_ticks[d] += (rl[7 + d] >> 16) == sl.tag ? rl[7 + d] & 0xffffu : 0u;
+        const volatile unsigned *rl = s->h.resp(slot);
+        for (int d = 0; d < 6; d++) sl.dev_ticks[d] += (rl[7 + d] >> 16) == s->h.tags[(size_t)slot] ? rl[7 + d] & 0xffffu : 0u;
     }
     return LS_OK;
 }
@@ -717,11 +511,11 @@ int nq_server_col_scores(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows
     unsigned pay[16] = {0};
     pay[0] = SRV_F_WANT_CS;
     pay[4] = sl.board_id & 0xffffu; pay[5] = sl.board_id >> 16;
-    int rc = server_ensure_running(ctx, s);
+    int rc = s->h.ensure_running(ctx);
     if (rc != LS_OK) return rc;
-    post_line(s, slot, pay);
+    s->h.post(slot, pay);
     unsigned r[8];
-    rc = wait_line(ctx, s, slot, r);
+    rc = s->h.wait(ctx, slot, r);
     if (rc != LS_OK) { sl.valid = false; return rc; }
     const unsigned short *k16 = s->cs16(slot);
     for (int j = 0; j < n; j++) sl.cs[(size_t)j] = k16[j];

@@ -40,9 +40,12 @@
 // per edit (class: lowers < none < raises, position key, new value).  Packed with the scores
 // into one 64-bit key per candidate; the last kernel takes the minimum (key, index).
 #include <cstdlib>
+#include <cstring>
+#include <new>
 
 #include "ls_common.hpp"
 #include "sched_common.hpp"
+#include "srv_common.hpp"
 
 namespace lsamd {
 
@@ -1274,6 +1277,119 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_small_kernel(SchedEvalArgs
 }
 
 // ---------------------------------------------------------------------------------------------
+// The resident scheduling LS step (srv_common.hpp: mailbox protocol, leaving rules).  One workgroup that is never
+// relaunched serves ls_sched_eval_resident for move lists of at most 64 * NW entries -- the reference example's window-100
+// iteration (employee-scheduling/src/main.rs:26): the launch + dispatch + completion poll around a 7 us kernel were more
+// than half of the 17.8 us LS iteration.  The workgroup keeps the slot's state vector in LDS and each lane its move of the
+// resident stream (the stream never changes during a run: the reference's iterator clones the generator, lib.rs:488); a
+// request names how many moves of the stream are candidates, the window and the state's id, the answer is one line.  The
+// winner is applied to the LDS state (the host applies it to its copy: local_search.rs:335 always moves to the winner), so
+// a steady-state LS iteration moves 64 bytes down and 32 bytes up; a state the workgroup does not hold (perturbation,
+// relaunch) is read from the pinned shadow copy.  Body = sched_eval_small_kernel.
+constexpr unsigned SCS_F_EVAL = 1u, SCS_F_SCORE = 2u; // neighbourhood of the state | score of the state (get_scored_solution, lib.rs:261-375)
+
+struct SchedSrvArgs {
+    SrvLink link;
+    SchedInst in;
+    const ls_sched_move *moves; // the resident stream (device memory), fixed while the launch lives
+    long long n_resident;
+    const int *shadow;          // pinned host: the state of the current request [64]
+};
+
+template <typename M, int NW>
+__global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int S = a.in.S, D = a.in.D, E = a.in.n_employees;
+    __shared__ SchedBaseTab<M> T;
+    __shared__ u64 s_key[NW];
+    __shared__ long long s_idx[NW];
+    __shared__ int s_wcnt[NW];
+    __shared__ unsigned s_req[16];
+    __shared__ int s_state[64];
+    __shared__ int s_leave;
+    SchedLaneConst L{};
+    if (wib < 3) L = a.in.lane_tab[lane];
+    // this lane's move of the resident stream: loaded once, the stream is fixed while the launch lives
+    int mtype = -1, mma = 0, mmb = 0;
+    if (tid < a.n_resident) { const ls_sched_move m = a.moves[tid]; mtype = m.type; mma = m.a; mmb = m.b; }
+    unsigned lds_state = 0; // id of the state in s_state (0: none); block-uniform
+    SrvPoll poll{0, 0, 0};
+    if (wib == 0) srv_poll_begin(poll, a.link, a.link.resp, lane);
+    for (;;) {
+        if (wib == 0) {
+            const int leave = srv_poll_wait(poll, a.link, a.link.req, s_req, lane);
+            if (lane == 0) s_leave = leave;
+        }
+        __syncthreads(); // B1: the request is in s_req, the previous winner is in s_state
+        if (s_leave) break;
+        const long long nm = (long long)s_req[1] < a.n_resident ? (long long)s_req[1] : a.n_resident;
+        const long long window = (long long)s_req[2];
+        const unsigned state_id = s_req[3] | (s_req[4] << 16);
+        if (state_id != lds_state) { // block-uniform: not the state this workgroup holds
+            if (tid < 64) s_state[tid] = tid < S ? srv_sys_load(a.shadow + tid) : 0;
+            lds_state = state_id;
+            __syncthreads();
+        }
+        const int e_lane = lane < S ? s_state[lane] : -1 - lane;
+        const int hol_base = wib == 0 ? sched_holiday_bit(a.in, e_lane, lane) : 0;
+        if (s_req[0] & SCS_F_SCORE) { // block-uniform: the state's own score, by the wavefront-per-state scorer (sched_score_kernel)
+            if (wib == 0) {
+                const u64 eq = sched_build_eq(D, e_lane) & L.scored_mask;
+                const SchedScore r = sched_terms<false>(D, L, lane, eq, hol_base);
+                unsigned pay = 0;
+                if (lane == 3) pay = (unsigned)r.hard;
+                else if (lane == 4) pay = (unsigned)r.soft;
+                if (lane < 8) __hip_atomic_store(a.link.resp + lane, (poll.last_tag << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                srv_served(poll, a.link, lane);
+            }
+            continue;
+        }
+        const long long k = tid;
+        const SchedEdit ed = sched_edit_of(e_lane, S, E, k < nm ? mtype : -1, mma, mmb);
+        const u64 bal = __ballot(ed.active);
+        if (lane == 0) s_wcnt[wib] = __popcll(bal);
+        const int hbits = sched_edit_hbits(a.in, ed);
+        if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            if (i < wib) before += s_wcnt[i];
+            total += s_wcnt[i];
+        }
+        const long long rank = before + __popcll(bal & ((2ull << lane) - 1)); // 1-based among the real candidates
+        u64 best_key = SC_KEY_EMPTY;
+        long long best_idx = -1;
+        if (ed.active && rank <= window) {
+            int hard, soft;
+            best_key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft);
+            best_idx = k;
+        }
+        sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib); // valid in wavefront 0 afterwards
+        if (wib == 0) {
+            const bool has = best_key != SC_KEY_EMPTY;
+            const long long n_scored = window <= 0 || !has ? 0 : (total < window ? total : window);
+            unsigned pay = 0;
+            if (lane == 0) pay = has ? 1u : 0u;
+            else if (lane == 1) pay = (unsigned)n_scored;
+            else if (lane == 2) pay = has ? (unsigned)best_idx : 0u;
+            else if (lane == 3) pay = has ? (unsigned)(best_key >> 54) : 0u;          // hard
+            else if (lane == 4) pay = has ? (unsigned)((best_key >> 46) & 0xffu) : 0u; // soft
+            if (lane < 8) __hip_atomic_store(a.link.resp + lane, (poll.last_tag << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            srv_served(poll, a.link, lane);
+            if (has && lane == 0) { // the loop continues from the winner (local_search.rs:335)
+                const ls_sched_move m = a.moves[best_idx];
+                if (m.type == 0) s_state[m.a] = m.b;
+                else { const int ea = s_state[m.a], eb = s_state[m.b]; s_state[m.a] = eb; s_state[m.b] = ea; }
+            }
+        }
+    }
+    if (tid == 0) srv_block_leaves(a.link);
+}
+
+// ---------------------------------------------------------------------------------------------
 // The production pipeline for move lists beyond one block (no per-candidate score dump): TWO launches.
 //   sched_eval_all_kernel   every chunk of a.chunk_moves moves is scored by one block, which records each
 //                           candidate's key, the chunk's number of real (non-tabu) candidates and its minimum
@@ -1753,6 +1869,142 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
     if (bpr > 1) { // with one block per restart pass 2 has already written the result
         hipLaunchKernelGGL(sched_reduce_kernel, dim3(n_restarts), dim3(256), 0, ctx->stream, a);
         LS_HIP(ctx, hipGetLastError());
+    }
+    return LS_OK;
+}
+
+// ------------------------------------------------------------------------------------------ resident scheduling LS step
+constexpr int SCS_NW = 8; // wavefronts of the server workgroup: move lists of at most 512 entries
+
+struct SchedServer {
+    SrvHost h;
+    unsigned state_id = 0;
+    bool valid = false;
+    int *shadow() const { return reinterpret_cast<int *>(h.extra()); }
+};
+
+bool sched_server_eligible(const ls_ctx *ctx, long long n_moves)
+{
+    return ctx->sched_server_on && ctx->sched_delta && ctx->sched.valid && n_moves <= 64 * SCS_NW && ctx->sched.n_employees <= 32768 &&
+           ctx->sc_resident_n > 0 && (long long)ctx->sc_resident_host.size() == ctx->sc_resident_n;
+}
+
+void sched_server_counters(const ls_ctx *ctx, unsigned long long out[3])
+{
+    out[0] = out[1] = out[2] = 0;
+    if (const SchedServer *s = ctx->sched_server) { out[0] = s->h.requests.load(); out[1] = s->h.relaunches.load(); out[2] = s->h.slow_waits.load(); }
+}
+
+// the launch leaves (its arguments -- instance, resident stream -- are about to change, or memory is about to be released)
+void sched_server_pause(ls_ctx *ctx)
+{
+    SchedServer *s = ctx->sched_server;
+    if (!s || !s->h.stream) return;
+    s->valid = false; // whatever changes next (instance, stream) may change what the state means
+    (void)hipSetDevice(s->h.device);
+    if (!s->h.drained()) {
+        const unsigned tag = s->h.next_tag(0);
+        volatile unsigned *dst = s->h.req(0);
+        for (int d = 0; d < 16; d++) dst[d] = (tag << 16) | (d == 0 ? SRV_F_QUIT : 0u);
+    }
+    (void)hipStreamSynchronize(s->h.stream);
+}
+
+void sched_server_destroy(ls_ctx *ctx)
+{
+    SchedServer *s = ctx->sched_server;
+    if (!s) return;
+    s->h.shutdown();
+    delete s;
+    ctx->sched_server = nullptr;
+}
+
+// the state of this request versus what the workgroup holds: a new one is range-checked, copied to the pinned shadow, gets a new id
+static int sched_server_sync_state(ls_ctx *ctx, SchedServer *s, const int32_t *state)
+{
+    const int S = ctx->sched.n_days_stored, E = ctx->sched.n_employees;
+    int *sh = s->shadow();
+    if (!s->valid || memcmp(sh, state, (size_t)S * 4) != 0) {
+        for (int d = 0; d < S; d++)
+            if (state[d] < 0 || state[d] >= E)
+                return set_err(ctx, LS_ERR_INVALID, "state entry %d = %d is not an employee index in [0, %d)", d, state[d], E);
+        memcpy(sh, state, (size_t)S * 4);
+        s->valid = true;
+        s->state_id = s->state_id == 0xffffffffu ? 1u : s->state_id + 1u;
+    }
+    return LS_OK;
+}
+
+// ls_sched_score for one state through the resident workgroup (only once it exists: the LS walk that follows then starts
+// from a state the workgroup already holds)
+bool sched_server_can_score(const ls_ctx *ctx) { return ctx->sched_server != nullptr && sched_server_eligible(ctx, 0); }
+
+int sched_server_score(ls_ctx *ctx, const int32_t *state, int64_t *hard, int64_t *soft)
+{
+    SchedServer *s = ctx->sched_server;
+    int rc = sched_server_sync_state(ctx, s, state);
+    if (rc != LS_OK) return rc;
+    unsigned pay[16] = {0};
+    pay[0] = SCS_F_SCORE;
+    pay[3] = s->state_id & 0xffffu; pay[4] = s->state_id >> 16;
+    rc = s->h.ensure_running(ctx);
+    if (rc != LS_OK) return rc;
+    s->h.post(0, pay);
+    unsigned r[8];
+    rc = s->h.wait(ctx, 0, r);
+    if (rc != LS_OK) { s->valid = false; return rc; }
+    *hard = r[3];
+    *soft = r[4];
+    return LS_OK;
+}
+
+// ls_sched_eval_resident through the resident workgroup; `state` is range-checked here when it is not the one the
+// workgroup holds.  n_moves <= 512 (sched_server_eligible).
+int sched_server_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out)
+{
+    SchedServer *s = ctx->sched_server;
+    if (!s) {
+        LS_HIP(ctx, hipSetDevice(ctx->device));
+        s = new (std::nothrow) SchedServer();
+        if (!s) return set_err(ctx, LS_ERR_NOMEM, "out of host memory");
+        const int rc = s->h.init(ctx, "scheduling LS-step server", 1, 256);
+        if (rc != LS_OK) { delete s; return rc; }
+        s->h.launch = [s, ctx](const SrvLink &L) {
+            SchedSrvArgs a;
+            a.link = L;
+            a.in = make_inst(ctx);
+            a.moves = ctx->sc_resident_moves.as<ls_sched_move>();
+            a.n_resident = ctx->sc_resident_n;
+            a.shadow = s->shadow();
+            void *args[] = {&a};
+            const bool m32 = ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64;
+            const void *fn = m32 ? reinterpret_cast<const void *>(&sched_server_kernel<unsigned, SCS_NW>)
+                                 : reinterpret_cast<const void *>(&sched_server_kernel<u64, SCS_NW>);
+            return hipLaunchKernel(fn, dim3(1), dim3(64 * SCS_NW), args, 0, s->h.stream);
+        };
+        ctx->sched_server = s;
+    }
+    int rc = sched_server_sync_state(ctx, s, state);
+    if (rc != LS_OK) return rc;
+    int *sh = s->shadow();
+    unsigned pay[16] = {0};
+    pay[0] = SCS_F_EVAL;
+    pay[1] = (unsigned)n_moves;
+    pay[2] = (unsigned)(window > 0xffff ? 0xffff : window); // n_moves <= 512: a larger window changes nothing
+    pay[3] = s->state_id & 0xffffu; pay[4] = s->state_id >> 16;
+    rc = s->h.ensure_running(ctx);
+    if (rc != LS_OK) return rc;
+    s->h.post(0, pay);
+    unsigned r[8];
+    rc = s->h.wait(ctx, 0, r);
+    if (rc != LS_OK) { s->valid = false; return rc; }
+    if (!(r[0] & 1u)) {
+        out->n_scored = 0; out->best_index = -1; out->best_hard = 0; out->best_soft = 0;
+    } else {
+        out->n_scored = r[1]; out->best_index = r[2]; out->best_hard = r[3]; out->best_soft = r[4];
+        const ls_sched_move &m = ctx->sc_resident_host[(size_t)r[2]]; // the workgroup applied it to its state
+        if (m.type == 0) sh[m.a] = m.b;
+        else { const int ea = sh[m.a], eb = sh[m.b]; sh[m.a] = eb; sh[m.b] = ea; }
     }
     return LS_OK;
 }

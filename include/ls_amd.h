@@ -100,7 +100,8 @@ int ls_ctx_get_nq_algo(const ls_ctx *ctx, int *algo);
 /* Counters of the latency-critical host-pointer path since the context was created (ls_multi_solver_get_counters: of
  * the last run).  The reference has no counterpart (its loop, local_search.rs:301-342, never leaves the thread); they
  * exist so that the slow branches of this boundary are visible instead of silent:
- *   [0] requests served by the resident LS-step server (one launch whose workgroups are the slots: a one-restart
+ *   [0] requests served by the resident LS-step servers (N-queens: one launch whose workgroups are the slots; scheduling:
+ *       one workgroup behind ls_sched_eval_resident / ls_sched_score for lists of <= 512 moves; a one-restart
  *       ls_nqueens_eval / ls_nqueens_eval_batch[_next] / ls_nqueens_col_scores call is a 64-byte mailbox write and a
  *       32-byte answer, no kernel launch), [1] launches of that server (it leaves when no slot has been served for 2 ms
  *       -- LS_NQ_SERVER_IDLE_US -- and is started again on demand), [2] waits that found the launch drained under their

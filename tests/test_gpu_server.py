@@ -240,3 +240,79 @@ def test_multi_solver_lockstep_large_n_equals_single_runs():
         assert [m.best(r) for r in range(len(seeds))] == singles
         assert m.stats()["ls_iterations"] == sum(iters)
         m.close()
+
+
+# ------------------------------------------------------------------------------------------------- scheduling
+def _random_moves(rng, n, D, E):
+    mv = np.zeros((n, 3), dtype=np.int64)
+    for i in range(n):
+        if rng.integers(0, 5) == 0:
+            mv[i] = (0, rng.integers(0, D), rng.integers(0, E))       # ChangeDay (lib.rs:466-470)
+        else:
+            a, b = rng.choice(D, size=2, replace=False)
+            mv[i] = (1, a, b)                                          # SwapDays (:471-478)
+    return mv
+
+
+@pytest.mark.parametrize("dates,E", [(((2022, 5, 9), (2022, 6, 8)), 7),        # the example instance: 31 scored / 32 stored days
+                                     (((2022, 5, 9), (2022, 7, 10)), 40),       # 63 / 64 days: the 64-bit day sets
+                                     (((2022, 5, 11), (2022, 5, 24)), 3)])      # 14 / 15 days, starts on a Wednesday
+def test_sched_server_follows_any_call_sequence(monkeypatch, dates, E):
+    # ls_sched_eval_resident / ls_sched_score through the resident scheduling workgroup (no launch per call): continue from
+    # the winner (the workgroup applies it to its LDS state), perturb, repeat, windows that cut / exceed the list, a new
+    # resident list and a new instance under a live server, idle time-out; every call against the oracle and, for the same
+    # sequence, against the launch-per-call route.
+    import ls_amd
+    monkeypatch.setenv("LS_NQ_SERVER_IDLE_US", "500")
+    rng = np.random.default_rng(77)
+    hol = {e: list(rng.choice(10, size=int(rng.integers(0, 3)), replace=False)) for e in range(E)}
+    inst = orc.Sched(dates[0], dates[1], hol)
+    D, S = inst.n_scored_days, inst.n_scored_days + 1
+    bits = np.zeros(E, dtype=np.uint64)
+    for e, ds in hol.items():
+        for d in ds:
+            bits[e] |= np.uint64(1) << np.uint64(int(d))
+    results = {}
+    for server in ("1", "0"):
+        monkeypatch.setenv("LS_SCHED_SERVER", server)
+        prng = np.random.default_rng(5)
+        got = []
+        with ls_amd.Context(0) as c:
+            c.sched_instance_upload(D, S, inst.start_weekday, E, bits)
+            moves = _random_moves(prng, 400, D, E)
+            c.sched_moves_upload(moves)
+            state = prng.integers(0, E, size=S)
+            for it in range(60):
+                k = int(prng.integers(1, len(moves) + 1))
+                w = int(prng.choice([1, 7, 100, 299, 399, 400, 10 ** 6]))
+                r = c.sched_eval_resident(state, k, w)
+                exp = inst.neighbourhood(state, moves[:k], w)
+                assert (r["n_scored"], r["best_index"]) == (exp["n_scored"], exp["best_index"]), (it, k, w)
+                if exp["best_index"] >= 0:
+                    assert (r["best_hard"], r["best_soft"]) == (exp["best_hard"], exp["best_soft"])
+                got.append(r)
+                what = it % 5
+                if what in (0, 1, 2) and r["best_index"] >= 0:           # continue from the winner (local_search.rs:335)
+                    t, a, b = moves[r["best_index"]]
+                    state = state.copy()
+                    if t == 0:
+                        state[a] = b
+                    else:
+                        state[a], state[b] = state[b], state[a]
+                elif what == 3:
+                    state = prng.integers(0, E, size=S)                  # perturbed
+                    h, s_ = c.sched_score(state)                         # score of a fresh state: the same workgroup
+                    assert (int(h[0]), int(s_[0])) == inst.score(state)
+                if it == 20:
+                    moves = _random_moves(prng, 300, D, E)               # a new resident list under a live server
+                    c.sched_moves_upload(moves)
+                if it == 35:
+                    time.sleep(0.01)                                     # the launch leaves (idle) and comes back
+                if it == 45:
+                    c.sched_instance_upload(D, S, inst.start_weekday, E, bits)   # the instance again: the launch is restarted
+            cnt = c.counters()
+            assert (cnt["server_requests"] > 60) == (server == "1")
+            if server == "1":
+                assert cnt["server_launches"] >= 3
+        results[server] = got
+    assert results["1"] == results["0"]
