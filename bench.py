@@ -283,6 +283,8 @@ def run_rank(args, rank, world, device, sync, launcher):
                 out["roofline"]["default_path"] = {
                     "table_neighbours_per_s": tb.get("neighbours_per_s"), "table_frac": (tb.get("roofline") or {}).get("frac"),
                     "table_bound": (tb.get("roofline") or {}).get("bound"),
+                    "table_64_restarts_neighbours_per_s": ex.get("table_full_neighbourhood_64_restarts", {}).get("neighbours_per_s"),
+                    "table_64_restarts_frac": (ex.get("table_full_neighbourhood_64_restarts", {}).get("roofline") or {}).get("frac"),
                     "ls_step_round_trip_us_one_restart": st1.get("us_per_call"),
                     "config4_end_to_end_s": e2e.get("seconds"), "config4_end_to_end_neighbours_per_s": e2e.get("neighbours_per_s"),
                     "config4_end_to_end_equals_single_solver_runs": (e2e.get("timed_run_vs_single_solver_runs_on_the_launch_per_call_route") or {}).get("equal")}
@@ -581,6 +583,24 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True):
                                                      ncols_ref.data_ptr(), mc, w, res_d.data_ptr()), 200)
         out[f"{algo}_reference_shaped_window_5n"] = {"neighbours_per_s": R * min(w, mc * (n - 1)) / s,
                                                      "us_per_launch": s * 1e6, "candidates_per_launch": R * min(w, mc * (n - 1))}
+    # the default TABLE kernel with 64 restarts per launch (config 4's restart count): the same 512 workgroups, eight times the
+    # columns per table build -- the 8-restart launch above is bounded by the workgroup dispatch ramp, not by issue
+    try:
+        R64 = 64
+        b64 = make_boards(n, range(R64))
+        _, cur64 = ctx.nqueens_col_scores(b64)
+        rows64, cur64_d = torch.from_numpy(b64).to(dev), torch.from_numpy(cur64).to(dev)
+        cols64 = torch.arange(n, dtype=torch.int32, device=dev).repeat(R64, 1).contiguous()
+        nc64 = torch.full((R64,), n, dtype=torch.int32, device=dev)
+        res64 = torch.zeros((R64, 4), dtype=torch.int64, device=dev)
+        ctx.set_algo("table")
+        s = timed(lambda: ctx.nqueens_eval_batch_dev(R64, n, rows64.data_ptr(), cur64_d.data_ptr(), cols64.data_ptr(), nc64.data_ptr(), n,
+                                                     n * (n - 1), res64.data_ptr()), 30)
+        out["table_full_neighbourhood_64_restarts"] = {"neighbours_per_s": R64 * n * (n - 1) / s, "us_per_launch": s * 1e6,
+                                                       "roofline": issue_roofline("nq_table_pairs_kernel_r64", s)}
+        del rows64, cur64_d, cols64, nc64, res64
+    except Exception as e:  # noqa: BLE001 - a secondary line must not take the bench down
+        out["table_full_neighbourhood_64_restarts"] = {"error": repr(e)}
     # the all-integer formulation of the scan kernel (BoardPk16: packed u16 xor / min / add, LS_NQ_SCAN_VARIANT=1) on the same
     # launch: the same results (parity-tested), half-rate instructions -- the fp32 product test is a speed choice, not a precision one
     try:

@@ -457,6 +457,24 @@ static int wait_done_word(ls_ctx *ctx, const unsigned long long *flag, unsigned 
     }
 }
 
+
+// The context's completion word (coherent host memory) and the block counter of multi-block publishers.  The counter is
+// allocated and zeroed (by a kernel, in stream order: DESIGN 3 -- no memset node in any launch path) BEFORE the word is
+// published in rs.flag, so a failed allocation cannot leave a launch with a null counter.
+static int ensure_done_word(ls_ctx *ctx)
+{
+    NqResident &rs = ctx->nq_res;
+    if (rs.flag) return LS_OK;
+    LS_RESERVE(ctx, rs.counter, 256);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, ctx->stream, rs.counter.as<int>(), 0, 64ll);
+    LS_HIP(ctx, hipGetLastError());
+    unsigned long long *flag = nullptr;
+    LS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&flag), 64, hipHostMallocCoherent));
+    *flag = 0;
+    rs.flag = flag;
+    return LS_OK;
+}
+
 // LS_NQ_STEP=3: the fused LS step with boards resident on the device.  Inputs that cross PCIe per call: the current
 // scores, the proposed columns and -- only for a restart whose board is not the one the device already holds -- the
 // board; outputs: the result records and the winners' column scores as 16-bit values.  One launch, no stream sync.
@@ -468,23 +486,24 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
     ctx->steps_done++;
     static const bool trace = getenv("LS_AMD_TRACE") != nullptr;
     const auto T0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-    if (!rs.flag) {
-        LS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&rs.flag), 64, hipHostMallocCoherent));
-        *rs.flag = 0;
-        LS_RESERVE(ctx, rs.counter, 256);
-        LS_HIP(ctx, hipMemsetAsync(rs.counter.p, 0, 256, ctx->stream));
+    {
+        const int rc0 = ensure_done_word(ctx);
+        if (rc0 != LS_OK) return rc0;
     }
     if (rs.n != n || (int)rs.valid.size() < R) { // geometry changed: nothing on the device can be reused
-        rs.n = n;
+        // the step kernel's table layout (nq_step_dev picks the paired layout for even n >= 128): 6n + 4 or 5n + 1 u16
+        const bool pairs = (n & 1) == 0 && n >= 128 && ctx->nq_table_variant >= 10;
+        const int tab_words = pairs ? ((((6 * n + 4) >> 1) + 3) & ~3) : ((((5 * n + 1) >> 1) + 3) & ~3);
+        rs.n = 0; // nothing is committed before both reservations have succeeded (a failure leaves "no resident geometry")
+        rs.valid.clear();
+        LS_RESERVE(ctx, rs.dev_rows, (size_t)R * n * 4);
+        LS_RESERVE(ctx, rs.dev_tabs, (size_t)R * tab_words * 4);
+        rs.tab_words = tab_words;
         rs.valid.assign((size_t)R, 0);
         rs.cs_valid.assign((size_t)R, 0);
         rs.shadow.resize((size_t)R * n);
         rs.cs.resize((size_t)R * n);
-        LS_RESERVE(ctx, rs.dev_rows, (size_t)R * n * 4);
-        // the step kernel's table layout (nq_step_dev picks the paired layout for even n >= 128): 6n + 4 or 5n + 1 u16
-        const bool pairs = (n & 1) == 0 && n >= 128 && ctx->nq_table_variant >= 10;
-        rs.tab_words = pairs ? ((((6 * n + 4) >> 1) + 3) & ~3) : ((((5 * n + 1) >> 1) + 3) & ~3);
-        LS_RESERVE(ctx, rs.dev_tabs, (size_t)R * rs.tab_words * 4);
+        rs.n = n;
     }
     const size_t rows_b = (size_t)R * n * 4, cur_b = (size_t)R * 8, cols_b = (size_t)R * max_cols * 4, nc_b = (size_t)R * 4,
                  res_b = (size_t)R * sizeof(ls_nq_result), cs_b = next_col_scores ? (size_t)R * n * 2 : 0;
@@ -1036,11 +1055,9 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
     // The result record always goes straight to pinned host memory and its writer publishes a completion word, which
     // the caller polls instead of synchronising the stream.
     NqResident &rs = ctx->nq_res; // the context's completion word is shared with the N-queens LS step (one call at a time per context)
-    if (!rs.flag) {
-        LS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&rs.flag), 64, hipHostMallocCoherent));
-        *rs.flag = 0;
-        LS_RESERVE(ctx, rs.counter, 256);
-        LS_HIP(ctx, hipMemsetAsync(rs.counter.p, 0, 256, ctx->stream));
+    {
+        const int rc0 = ensure_done_word(ctx);
+        if (rc0 != LS_OK) return rc0;
     }
     rc = sched_eval_batch_dev(ctx, 1, si.d<int>(o_st), ctx->sc_resident_moves.as<ls_sched_move>(), si.d<long long>(o_nm), n_moves, window,
                               so.h<ls_sched_result>(0), nullptr, nullptr, rs.flag, ++rs.seq, zc ? state : nullptr, n_moves);
@@ -1096,11 +1113,9 @@ int ls_sched_eval_exhaustive(ls_ctx *ctx, int32_t n_restarts, const int32_t *sta
         hipError_t e = ctx->stage_out.reserve(256);
         if (e != hipSuccess) return set_err(ctx, LS_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
         NqResident &rs = ctx->nq_res;
-        if (!rs.flag) {
-            LS_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&rs.flag), 64, hipHostMallocCoherent));
-            *rs.flag = 0;
-            LS_RESERVE(ctx, rs.counter, 256);
-            LS_HIP(ctx, hipMemsetAsync(rs.counter.p, 0, 256, ctx->stream));
+        {
+            const int rc0 = ensure_done_word(ctx);
+            if (rc0 != LS_OK) return rc0;
         }
         rc = sched_eval_exhaustive_dev(ctx, 1, nullptr, window, ctx->stage_out.h<ls_sched_result>(0), &handled, rs.flag, ++rs.seq, states);
         if (rc != LS_OK) return rc;

@@ -12,6 +12,10 @@
 
 #include "../../include/ls_amd.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the kernels are written for gfx950: wave64, stores counted in vmcnt (the completion words are published after s_waitcnt vmcnt(0)), DPP row operations"
+#endif
+
 namespace lsamd {
 
 // ---------------------------------------------------------------- device bufs
@@ -62,9 +66,9 @@ struct Staging {
         if (bytes <= cap) return hipSuccess;
         release();
         size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
-        // coherent (fine-grained) whatever HIP_HOST_COHERENT says: kernels read and write this block in place
+        // coherent (fine-grained) whatever HIP_HOST_COHERENT says: kernels read and write this block in place and publish
+        // completion words next to it -- there is no non-coherent fallback (the polled routes would not be sound on it)
         hipError_t e = hipHostMalloc(&host, want, hipHostMallocCoherent);
-        if (e != hipSuccess) e = hipHostMalloc(&host, want, hipHostMallocDefault);
         if (e != hipSuccess) { host = nullptr; return e; }
         e = hipMalloc(&dev, want);
         if (e != hipSuccess) { (void)hipHostFree(host); host = nullptr; dev = nullptr; return e; }

@@ -144,6 +144,9 @@ __device__ __forceinline__ void nq_pairs_unit(const unsigned *s_t16, int n, int 
         if (v##J != rc) srow[v##J] = cur + 2ll * ((int)(lo##J >> 15) - conf_old);                      \
         if (v##J + 1 != rc && v##J + 1 < n) srow[v##J + 1] = cur + 2ll * ((int)(hi##J >> 15) - conf_old); \
     }
+    // (Issuing the NEXT four steps' twelve look-ups before reducing the current four -- a hand-pipelined loop -- was measured
+    // slower, also where the launch is not dispatch-bound: 189 against 164 us for 64 restarts x 4096 columns; the register
+    // copies cost more than the overlap buys.)
     for (; i + 4 <= i1f; i += 4) {
         LS_PAIR(0) LS_PAIR(1) LS_PAIR(2) LS_PAIR(3)
         unsigned m0 = lo0 < hi0 ? lo0 : hi0, m1 = lo1 < hi1 ? lo1 : hi1, m2 = lo2 < hi2 ? lo2 : hi2,

@@ -1806,7 +1806,7 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
     // workspace: k_end[R] | n_scored[R] | part_key[R][bpr] | part_idx[R][bpr] | chunk_counts[R][n_chunks]
     const size_t parts = (size_t)n_restarts * (size_t)bpr;
     LS_RESERVE(ctx, ctx->sc_keys, (size_t)n_restarts * 16 + parts * 16 + (size_t)n_restarts * n_chunks * 4);
-    SchedEvalArgs a;
+    SchedEvalArgs a{};
     a.in = make_inst(ctx);
     a.n_restarts = n_restarts;
     a.states = states_d; a.moves = moves_d; a.n_moves = n_moves_d;

@@ -52,7 +52,7 @@ def nq_case(ctx):
                 (exp["best_index"] >= 0 and got["best_score"] != exp["best_score"]) or not np.array_equal(scores, exp["scores"]):
             fail(f"nqueens {algo}", n=n, rows=rows, cols=cols, window=window, got=got,
                  exp={k: exp[k] for k in ("n_scored", "best_index", "best_score")})
-        got2, _ = ctx.nqueens_eval(rows, cur, cols, window)          # production path (no score output)
+        got2, _ = ctx.nqueens_eval(rows, cur, cols, window)          # production path (no score output; "table": the resident LS-step server)
         if got2 != got:
             fail(f"nqueens {algo}: debug and production paths differ", n=n, rows=rows, cols=cols, window=window)
     stats["nq"] += 1
@@ -149,12 +149,38 @@ def sched_case(ctx):
     stats["sched_candidates"] += exp["n_scored"]
 
 
+def server_walk(ctx):
+    """A short LS walk through the resident LS-step server (one-restart calls continuing from the winner, a perturbation in
+    between): the slot's LDS board / tables and the host-kept column scores against the oracle at every step."""
+    n = int(rng.choice([rng.integers(2, 200), rng.integers(128, 1100) & ~1, 4096]))
+    rows = rng.integers(0, n, size=n)
+    ctx.set_algo("auto")
+    for it in range(12):
+        mc = int(rng.integers(1, min(n, 16) + 1))
+        cols = rng.permutation(n)[:mc]
+        window = int(rng.choice([1, 5 * n, rng.integers(1, mc * (n - 1) + 2)]))
+        exp = orc.nq_neighbourhood(rows, cols, window, "table", want_scores=False)
+        out, nxt = ctx.nqueens_eval_batch_next(rows.reshape(1, -1), [orc.nq_score(rows)], cols.reshape(1, -1), [mc], window)
+        b = rows.copy()
+        if exp["best_index"] >= 0:
+            b[cols[exp["best_index"] // n]] = exp["best_index"] % n
+        if (out[0]["n_scored"], out[0]["best_index"]) != (exp["n_scored"], exp["best_index"]) or \
+                (exp["best_index"] >= 0 and out[0]["best_score"] != exp["best_score"]) or not np.array_equal(nxt[0], orc.nq_col_scores(b)):
+            fail("nqueens server walk", n=n, rows=rows, cols=cols, window=window, got=out[0])
+        rows = rng.integers(0, n, size=n) if it == 6 else b
+    stats["server_steps"] = stats.get("server_steps", 0) + 12
+
+
 with ls_amd.Context(0) as ctx:
     last = time.time()
     while time.time() < t_end:
         nq_case(ctx)
         sched_case(ctx)
+        server_walk(ctx)
         if time.time() - last > 30:
             print("progress", stats, flush=True)
             last = time.time()
-print("SOAK OK", stats, "seed", seed)
+    cnt = ctx.counters()
+# the slow branches of the latency-critical path must not have been taken silently (VERDICT r2, weak 6)
+assert cnt["completion_word_fallbacks"] == 0, cnt
+print("SOAK OK", stats, "seed", seed, "counters", cnt)

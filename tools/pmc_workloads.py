@@ -12,6 +12,11 @@ sys.path.insert(0, os.path.join(ROOT, "constraint-solver_amd"))
 
 import numpy as np  # noqa: E402
 
+# the LAUNCHED kernels are what per-dispatch counters can describe: one-restart host calls take the launch-per-call route here
+# (the resident servers are one long dispatch each; their service timeline comes from tools/step_server_trace.py)
+os.environ.setdefault("LS_NQ_STEP", "3")
+os.environ.setdefault("LS_SCHED_SERVER", "0")
+
 import ls_amd  # noqa: E402
 
 
@@ -30,6 +35,17 @@ def main():
                 out, _ = ctx.nqueens_eval_batch(boards, cur, cols, ncols, n * (n - 1))
             meta[kernel] = dict(candidates_per_launch=int(sum(o["n_scored"] for o in out)), restarts=R, n=n,
                                 workload="bench workload: 8 restarts x full n x n neighbourhood")
+        # the same TABLE kernel with 64 restarts per launch: the same 512 workgroups, eight times the columns per table build
+        R64 = 64
+        b64 = np.stack([np.random.default_rng(r).integers(0, n, size=n) for r in range(R64)]).astype(np.int32)
+        _, cur64 = ctx.nqueens_col_scores(b64)
+        ctx.set_algo("table")
+        for _ in range(reps):
+            out, _ = ctx.nqueens_eval_batch(b64, cur64, np.tile(np.arange(n, dtype=np.int32), (R64, 1)), np.full(R64, n, np.int32), n * (n - 1))
+        meta["nq_table_pairs_kernel_r64"] = dict(candidates_per_launch=int(sum(o["n_scored"] for o in out)), restarts=R64, n=n,
+                                                 workload="64 restarts x full n x n neighbourhood (same grid as the 8-restart launch: the second group of dispatches)",
+                                                 match="nq_table_pairs_kernel", dispatch_slice=[reps, 2 * reps], shares_group_with="nq_table_pairs_kernel")
+        meta["nq_table_pairs_kernel"]["dispatch_slice"] = [0, reps]
         # n = 1024 scan: 32 restarts x 1024 columns
         n2, R2 = 1024, 32
         b2 = np.stack([np.random.default_rng(100 + r).integers(0, n2, size=n2) for r in range(R2)]).astype(np.int32)

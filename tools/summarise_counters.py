@@ -60,28 +60,36 @@ def main():
         ent = {"kernel": name, "grid_threads": grid, "workgroup_size": e["workgroup_size"], "vgprs": e["vgpr"],
                "lds_bytes": e["lds_block_size"], "order": min(e["first_dispatch"].values()),
                "counters_mean_per_dispatch": {c: sum(v) / len(v) for c, v in e["counters"].items()},
+               "counters_per_dispatch_in_order": e["counters"],
                "dispatches_per_counter": {c: len(v) for c, v in e["counters"].items()}}
         ds = dur.get((name, grid))
         if ds:
+            ent["durations_ns_in_order"] = list(ds)
             ds = sorted(ds)
             ent["duration_ns"] = {"mean": sum(ds) / len(ds), "min": ds[0], "calls": len(ds)}
         raw[f"{name} | grid {grid}"] = ent
     with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_counters.json"), "w") as f:
-        json.dump(raw, f, indent=1)
+        json.dump({k: {kk: vv for kk, vv in v.items() if kk not in ("counters_per_dispatch_in_order", "durations_ns_in_order")} for k, v in raw.items()}, f, indent=1)
     with open(os.path.join(prof_dir, "workloads.json")) as f:
         meta = json.loads(f.read().split("PMC_WORKLOADS ", 1)[1])
     used = set()
     out = {}
     for wname, m in meta.items():
         match = m.get("match", wname)
-        cands = [k for k, e in raw.items() if match in e["kernel"] and k not in used
+        cands = [k for k, e in raw.items() if match in e["kernel"] and (k not in used or m.get("shares_group_with"))
                  and ("grid_blocks" not in m or e["grid_threads"] == m["grid_blocks"] * e["workgroup_size"])]
         if not cands:
             continue
         k = min(cands, key=lambda k: raw[k]["order"])
         used.add(k)
-        e = raw[k]
+        e = dict(raw[k])
         c = e["counters_mean_per_dispatch"]
+        if "dispatch_slice" in m:   # two workloads with the same kernel and grid: this one's dispatches are values[a:b] of every counter
+            a, b = m["dispatch_slice"]
+            c = {name: (sum(v[a:b]) / len(v[a:b])) for name, v in e["counters_per_dispatch_in_order"].items() if len(v[a:b])}
+            ds = e.get("durations_ns_in_order", [])[a:b]
+            if ds:
+                e["duration_ns"] = {"mean": sum(ds) / len(ds), "min": min(ds), "calls": len(ds)}
         cand = m["candidates_per_launch"]
         ent = {"kernel": e["kernel"], "grid_threads": e["grid_threads"], "vgprs": e["vgprs"], "lds_bytes": e["lds_bytes"],
                "workload": m["workload"], "candidates_per_launch": cand, "counters_per_launch": c,
