@@ -1037,6 +1037,7 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
                (long long)n_moves, ctx->sc_resident_n);
     const int S = ctx->sched.n_days_stored;
     if (sched_server_eligible(ctx, n_moves)) return sched_server_eval(ctx, state, n_moves, window, out); // no launch: the resident workgroup
+    if (sched_grid_eligible(ctx, n_moves)) return sched_grid_eval(ctx, state, n_moves, window, out);       // no launch: the resident grid
     int rc = sched_check_state(ctx, state, S);
     if (rc != LS_OK) return rc;
     const size_t o_nm = 0, o_st = 256, in_b = align256(o_st + (size_t)S * 4), out_b = 256;

@@ -223,6 +223,8 @@ struct SchedEvalArgs {
     unsigned long long done_seq;
     unsigned *ticket;               // delta pipeline, one launch: [n_restarts] blocks done so far (zero between launches)
     u64 *cand_keys;                 // delta pipeline: [n_restarts][max_moves] argmin key per candidate (SC_KEY_EMPTY: not a candidate)
+    unsigned *resp_line;            // nullable; resident grid: the result goes out as a tagged answer line (srv_common.hpp) instead
+    unsigned resp_tag;
     // one-restart launches may carry their per-call inputs in the kernel arguments (no copy, no PCIe read):
     int inline_valid;
     long long inline_n_moves;
@@ -376,7 +378,14 @@ __device__ __forceinline__ void sched_write_result_n(const SchedEvalArgs &a, int
         out.best_hard = (long long)(bk >> 54);
         out.best_soft = (long long)((bk >> 46) & 0xffu);
     }
-    if (a.done_flag) {
+    if (a.resp_line) {
+        // resident grid: d0 has-move, d1-2 n_scored, d3-4 best_index, d5 hard, d6 soft -- every dword tagged, one store each
+        const unsigned has = bk != SC_KEY_EMPTY ? 1u : 0u;
+        const unsigned pay[8] = {has, (unsigned)out.n_scored & 0xffffu, (unsigned)(out.n_scored >> 16) & 0xffffu,
+                                 has ? (unsigned)out.best_index & 0xffffu : 0u, has ? (unsigned)(out.best_index >> 16) & 0xffffu : 0u,
+                                 (unsigned)out.best_hard, (unsigned)out.best_soft, 0u};
+        for (int d = 0; d < 8; d++) __hip_atomic_store(a.resp_line + d, (a.resp_tag << 16) | (pay[d] & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (a.done_flag) {
         // one-restart launch from a resident entry: the record is the kernel's only output and lives in pinned host
         // memory; the caller polls the completion word instead of synchronising the stream.  Write-through
         // (system-scope) stores, their acknowledgement, then the word: no system-scope release (an L2 write-back).
@@ -1400,7 +1409,7 @@ __global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
 //                           the cut chunk its recorded keys up to the window, and the block writes the result.
 // GEN: the candidates are those of the exhaustive proposer, generated in place (no move list in memory).
 template <int NW> struct SchedFinishShared;
-template <int NW>
+template <int NW, bool COHERENT = false>
 __device__ __forceinline__ void sched_finish_block(const SchedEvalArgs &a, bool gen, int r, SchedFinishShared<NW> &sh);
 
 template <typename M, int NW, bool GEN>
@@ -1510,10 +1519,15 @@ template <int NW> struct SchedFinishShared {
     long long before;
 };
 
-// the finish step of restart r by one block of NW wavefronts (see above)
-template <int NW>
+// the finish step of restart r by one block of NW wavefronts (see above).  COHERENT: the records were written by other
+// workgroups of the SAME launch with agent-scope (write-through) stores and are read with agent-scope loads -- no cache
+// write-back / invalidate between the XCDs' L2s is needed (the resident grid).
+template <int NW, bool COHERENT>
 __device__ __forceinline__ void sched_finish_block(const SchedEvalArgs &a, bool gen, int r, SchedFinishShared<NW> &sh)
 {
+    auto ld_i = [](const int *p) { return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
+    auto ld_k = [](const u64 *p) { return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
+    auto ld_l = [](const long long *p) { return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     u64 *s_key = sh.key;
@@ -1533,7 +1547,7 @@ __device__ __forceinline__ void sched_finish_block(const SchedEvalArgs &a, bool 
     if (a.window > 0) {
         for (int t0 = 0; t0 < nch; t0 += 64 * NW) {
             const int b = t0 + (int)threadIdx.x;
-            const int cb = b < nch ? counts[b] : 0;
+            const int cb = b < nch ? ld_i(counts + b) : 0;
             int incl = cb;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -1549,7 +1563,7 @@ __device__ __forceinline__ void sched_finish_block(const SchedEvalArgs &a, bool 
             }
             const long long through = run + before + incl; // real candidates up to and including chunk b
             if (b < nch) {
-                if (through <= a.window) sched_min_key(best_key, best_idx, pk[b], pi[b]); // the whole chunk is inside the window
+                if (through <= a.window) sched_min_key(best_key, best_idx, ld_k(pk + b), ld_l(pi + b)); // the whole chunk is inside the window
                 else if (through - cb < a.window) { s_cut = b; s_before = through - cb; }  // the window ends inside this chunk
             }
             __syncthreads();
@@ -1568,7 +1582,7 @@ __device__ __forceinline__ void sched_finish_block(const SchedEvalArgs &a, bool 
         long long taken = 0;
         for (long long base = c0; base < c1 && taken < need; base += 64 * NW) {
             const long long k = base + threadIdx.x;
-            const u64 key = k < c1 ? keys[k] : SC_KEY_EMPTY;
+            const u64 key = k < c1 ? ld_k(keys + k) : SC_KEY_EMPTY;
             const u64 bal = __ballot(key != SC_KEY_EMPTY);
             __syncthreads(); // s_wcnt is reused
             if (lane == 0) s_wcnt[wib] = __popcll(bal);
@@ -1644,6 +1658,214 @@ __global__ __launch_bounds__(256) void sched_exhaustive_moves_kernel(const int *
         moves[t] = m;
         if (k == 0 && n_moves) n_moves[r] = per;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The resident scheduling GRID: ls_sched_eval_resident for lists beyond one workgroup (config 5: window 65 536 over a stream
+// of ~82 000 moves) without the two launches per LS iteration of the pipeline above.  One never-relaunched kernel, one
+// workgroup per 512-move chunk of the resident stream (each lane keeps its move in registers).  A request is ONE message of
+// four tagged lines (srv_common.hpp): header (flags, n_moves, window) + the state, one entry per dword -- the workgroups keep
+// no state, so there is nothing to apply or re-upload.  Workgroup 0 owns the host mailbox: it copies the four lines, tags and
+// all, to a device-side "go" record, which every workgroup polls in ONE 64-lane load and accepts when all tags agree (the same
+// torn-snapshot rule as over PCIe: no fence, no cache write-back between the XCDs' L2s -- the first version released and
+// acquired at agent scope and an LS iteration took 60 us).  Every workgroup scores its chunk (sched_eval_all_kernel's body),
+// records count and minimum with write-through stores and takes a ticket; the last one finishes: prefix over the counts,
+// minima of the chunks inside the window, and the chunk the window cuts is scored AGAIN by the finisher up to the window
+// (cheaper than 512 write-through key stores in every workgroup plus their acknowledgement on the critical path).
+// All workgroups must be resident at once: the launcher asks for at most two per CU.
+constexpr int SCG_STATE_AT = 16; // dword of the message that holds state[0]: the state fits lines 1..3 (S <= 48)
+
+struct SchedGridCtl {        // device memory
+    unsigned go[64];         // the current request, as the host wrote it (tagged dwords)
+    unsigned ticket;         // workgroups that have recorded their chunk of the current request
+    unsigned pad;
+    unsigned long long ready; // workgroups that have started, over all launches of this server
+};
+
+struct SchedGridArgs {
+    SrvLink link;            // lines 0..3 of the mailbox = one message
+    SchedInst in;
+    const ls_sched_move *moves;
+    long long n_resident;
+    SchedGridCtl *g;
+    unsigned long long ready_target; // g->ready once every workgroup of THIS launch has started (the host adds the grid size per launch)
+    u64 *part_key; long long *part_idx; int *chunk_counts; // [n_chunks] each
+};
+
+template <typename M, int NW>
+__global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArgs a)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c = (int)blockIdx.x, nch = (int)gridDim.x;
+    const int S = a.in.S, D = a.in.D, E = a.in.n_employees;
+    __shared__ SchedBaseTab<M> T;
+    __shared__ u64 s_key[NW];
+    __shared__ long long s_idx[NW];
+    __shared__ int s_cnt[NW];
+    __shared__ unsigned s_req[64];
+    __shared__ int s_ctl[2]; // [0] leave, [1] last (this workgroup runs the finish step)
+    __shared__ int s_cut;
+    __shared__ long long s_before;
+    SchedLaneConst L{};
+    if (wib < 3) L = a.in.lane_tab[lane];
+    const long long k = (long long)c * (64 * NW) + tid; // this lane's move of the resident stream: loaded once
+    int mtype = -1, mma = 0, mmb = 0;
+    if (k < a.n_resident) { const ls_sched_move m = a.moves[k]; mtype = m.type; mma = m.a; mmb = m.b; }
+    unsigned last_seq = 0;
+    SrvPoll poll{0, 0, 0};
+    if (wib == 0) {
+        last_seq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.g->go[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16);
+        if (c == 0) srv_poll_begin(poll, a.link, a.link.resp, lane);
+        if (lane == 0) __hip_atomic_fetch_add(&a.g->ready, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c == 0) { // the master serves only once every workgroup of THIS launch polls the go record
+            const unsigned long long t0 = wall_clock64();
+            bool all = false;
+            for (;;) {
+                all = __hip_atomic_load(&a.g->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.ready_target;
+                if (all || wall_clock64() - t0 > a.link.idle_ticks) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!all && lane == 0) // they cannot all be resident: everybody leaves (the polls below see the quit word)
+                __hip_atomic_store(&a.link.ctl->quit_gen, a.link.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    for (;;) {
+        if (wib == 0) {
+            int leave = 0;
+            if (c == 0) { // the master: host mailbox -> go record, verbatim
+                unsigned raw = 0;
+                leave = srv_poll_wait<64>(poll, a.link, a.link.req, s_req, lane, &raw);
+                if (!leave) __hip_atomic_store(&a.g->go[lane], raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (lane == 0) __hip_atomic_store(&a.link.ctl->quit_gen, a.link.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // tell the others
+                last_seq = poll.last_tag;
+            } else {
+                for (;;) { // one 64-lane snapshot of the go record per poll; valid when all tags agree and the tag is new
+                    const unsigned v = __hip_atomic_load(&a.g->go[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned t0 = __builtin_amdgcn_readfirstlane(v >> 16);
+                    if (t0 != last_seq && t0 != 0 && __builtin_amdgcn_ballot_w64((v >> 16) != t0) == 0) {
+                        s_req[lane] = v & 0xffffu;
+                        last_seq = t0;
+                        break;
+                    }
+                    unsigned long long q = 0;
+                    if (lane == 0) q = __hip_atomic_load(&a.link.ctl->quit_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__builtin_amdgcn_readfirstlane((int)(q == a.link.gen))) { leave = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (lane == 0) s_ctl[0] = leave;
+        }
+        __syncthreads();
+        if (s_ctl[0]) break;
+        long long nm = (long long)(s_req[1] | (s_req[2] << 16));
+        nm = nm < a.n_resident ? nm : a.n_resident;
+        const long long window = (long long)(s_req[3] | (s_req[4] << 16));
+        const int e_lane = lane < S ? (int)s_req[SCG_STATE_AT + lane] : -1 - lane;
+        const int hol_base = wib == 0 ? sched_holiday_bit(a.in, e_lane, lane) : 0;
+        // ---- this workgroup's chunk (sched_eval_all_kernel with one batch per wavefront, keys not recorded)
+        const SchedEdit ed = sched_edit_of(e_lane, S, E, k < nm ? mtype : -1, mma, mmb);
+        const int hbits = sched_edit_hbits(a.in, ed);
+        if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T);
+        __syncthreads();
+        u64 best_key = SC_KEY_EMPTY;
+        long long best_idx = -1;
+        int cnt = 0;
+        if (ed.active) {
+            int hard, soft;
+            best_key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft);
+            best_idx = k; cnt = 1;
+        }
+        cnt = wave_sum_i32(cnt);
+        if (lane == 0) s_cnt[wib] = cnt;
+        sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib); // synchronises the block
+        if (tid == 0) {
+            int total = 0;
+            for (int i = 0; i < NW; i++) total += s_cnt[i];
+            __hip_atomic_store(a.part_key + c, best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.part_idx + c, best_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.chunk_counts + c, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the record's write-through stores are acknowledged before the ticket
+            const unsigned t = __hip_atomic_fetch_add(&a.g->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ctl[1] = t == (unsigned)nch - 1;
+            if (s_ctl[1]) __hip_atomic_store(&a.g->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_cut = -1; s_before = 0;
+        }
+        __syncthreads();
+        if (s_ctl[1]) { // ---- the finish step (sched_finish_block on agent-scope loads; the cut chunk is scored again)
+            u64 fkey = SC_KEY_EMPTY;
+            long long fidx = -1, run = 0;
+            if (window > 0) {
+                for (int t0 = 0; t0 < nch; t0 += 64 * NW) {
+                    const int b = t0 + tid;
+                    // the chunk's count, minimum and index are fetched together (three independent agent-scope loads in flight)
+                    const int cb = b < nch ? __hip_atomic_load(a.chunk_counts + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    const u64 pkb = b < nch ? __hip_atomic_load(a.part_key + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SC_KEY_EMPTY;
+                    const long long pib = b < nch ? __hip_atomic_load(a.part_idx + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+                    int incl = cb;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int o = __shfl_up(incl, off, 64);
+                        if (lane >= off) incl += o;
+                    }
+                    if (lane == 63) s_cnt[wib] = incl;
+                    __syncthreads();
+                    int before = 0, total = 0;
+                    for (int i = 0; i < NW; i++) {
+                        if (i < wib) before += s_cnt[i];
+                        total += s_cnt[i];
+                    }
+                    const long long through = run + before + incl; // real candidates up to and including chunk b
+                    if (b < nch) {
+                        if (through <= window) sched_min_key(fkey, fidx, pkb, pib);
+                        else if (through - cb < window) { s_cut = b; s_before = through - cb; }
+                    }
+                    __syncthreads();
+                    run += total;
+                    if (run >= window) break;
+                }
+            }
+            const long long n_scored = window <= 0 ? 0 : (run < window ? run : window);
+            const int cut = s_cut;
+            if (cut >= 0) { // the chunk the window cuts: scored again here (same state, same table), up to the window
+                const long long need = window - s_before;
+                const long long kk = (long long)cut * (64 * NW) + tid;
+                int ty = -1, xa = 0, xb = 0;
+                if (kk < nm) { const ls_sched_move m = a.moves[kk]; ty = m.type; xa = m.a; xb = m.b; }
+                const SchedEdit e2 = sched_edit_of(e_lane, S, E, ty, xa, xb);
+                const int hb2 = sched_edit_hbits(a.in, e2);
+                const u64 bal = __ballot(e2.active);
+                __syncthreads(); // s_cnt is reused
+                if (lane == 0) s_cnt[wib] = __popcll(bal);
+                __syncthreads();
+                int before = 0;
+                for (int i = 0; i < NW; i++)
+                    if (i < wib) before += s_cnt[i];
+                const long long rank = before + __popcll(bal & ((2ull << lane) - 1)); // 1-based among the chunk's real candidates
+                if (e2.active && rank <= need) {
+                    int hard, soft;
+                    const u64 key2 = sched_delta_key<M>(T, D, e_lane, e2, hb2, hard, soft);
+                    if (key2 < fkey) { fkey = key2; fidx = kk; }
+                }
+            }
+            sched_block_min_key<NW>(fkey, fidx, s_key, s_idx, lane, wib);
+            if (wib == 0) { // the answer: d0 has-move, d1-2 n_scored, d3-4 best_index, d5 hard, d6 soft
+                const bool has = fkey != SC_KEY_EMPTY;
+                unsigned pay = 0;
+                if (lane == 0) pay = has ? 1u : 0u;
+                else if (lane == 1) pay = has ? (unsigned)n_scored & 0xffffu : 0u;
+                else if (lane == 2) pay = has ? (unsigned)(n_scored >> 16) : 0u;
+                else if (lane == 3) pay = has ? (unsigned)fidx & 0xffffu : 0u;
+                else if (lane == 4) pay = has ? (unsigned)(fidx >> 16) : 0u;
+                else if (lane == 5) pay = has ? (unsigned)(fkey >> 54) : 0u;
+                else if (lane == 6) pay = has ? (unsigned)((fkey >> 46) & 0xffu) : 0u;
+                if (lane < 8) __hip_atomic_store(a.link.resp + lane, (last_seq << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (lane == 0) __hip_atomic_store(&a.link.ctl->last_activity, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (c == 0 && wib == 0) poll.t_served = wall_clock64();
+    }
+    if (tid == 0) srv_block_leaves(a.link);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -1877,10 +2099,17 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
 constexpr int SCS_NW = 8; // wavefronts of the server workgroup: move lists of at most 512 entries
 
 struct SchedServer {
-    SrvHost h;
+    SrvHost h;               // the one-workgroup server (lists of <= 512 moves, single-state scores)
     unsigned state_id = 0;
     bool valid = false;
     int *shadow() const { return reinterpret_cast<int *>(h.extra()); }
+    // the resident grid (longer lists): created on demand; mailbox = 5 lines (header + 4 state lines)
+    SrvHost grid;
+    bool grid_ready = false;
+    SchedGridCtl *g = nullptr;
+    DevBuf ws;               // part_key | part_idx | chunk_counts
+    unsigned long long ready_total = 0;
+    unsigned long long grid_requests = 0;
 };
 
 bool sched_server_eligible(const ls_ctx *ctx, long long n_moves)
@@ -1892,22 +2121,29 @@ bool sched_server_eligible(const ls_ctx *ctx, long long n_moves)
 void sched_server_counters(const ls_ctx *ctx, unsigned long long out[3])
 {
     out[0] = out[1] = out[2] = 0;
-    if (const SchedServer *s = ctx->sched_server) { out[0] = s->h.requests.load(); out[1] = s->h.relaunches.load(); out[2] = s->h.slow_waits.load(); }
+    if (const SchedServer *s = ctx->sched_server) {
+        out[0] = s->h.requests.load() + s->grid_requests;
+        out[1] = s->h.relaunches.load() + s->grid.relaunches.load();
+        out[2] = s->h.slow_waits.load() + s->grid.slow_waits.load();
+    }
 }
 
 // the launch leaves (its arguments -- instance, resident stream -- are about to change, or memory is about to be released)
 void sched_server_pause(ls_ctx *ctx)
 {
     SchedServer *s = ctx->sched_server;
-    if (!s || !s->h.stream) return;
+    if (!s) return;
     s->valid = false; // whatever changes next (instance, stream) may change what the state means
-    (void)hipSetDevice(s->h.device);
-    if (!s->h.drained()) {
-        const unsigned tag = s->h.next_tag(0);
-        volatile unsigned *dst = s->h.req(0);
-        for (int d = 0; d < 16; d++) dst[d] = (tag << 16) | (d == 0 ? SRV_F_QUIT : 0u);
+    (void)hipSetDevice(ctx->device);
+    for (SrvHost *h : {&s->h, &s->grid}) {
+        if (!h->stream) continue;
+        if (!h->drained()) {
+            const unsigned tag = h->next_tag(0);
+            volatile unsigned *dst = h->req(0);
+            for (int d = 0; d < 16; d++) dst[d] = (tag << 16) | (d == 0 ? SRV_F_QUIT : 0u);
+        }
+        (void)hipStreamSynchronize(h->stream);
     }
-    (void)hipStreamSynchronize(s->h.stream);
 }
 
 void sched_server_destroy(ls_ctx *ctx)
@@ -1915,6 +2151,9 @@ void sched_server_destroy(ls_ctx *ctx)
     SchedServer *s = ctx->sched_server;
     if (!s) return;
     s->h.shutdown();
+    s->grid.shutdown();
+    if (s->g) (void)hipFree(s->g);
+    s->ws.release();
     delete s;
     ctx->sched_server = nullptr;
 }
@@ -1937,12 +2176,16 @@ static int sched_server_sync_state(ls_ctx *ctx, SchedServer *s, const int32_t *s
 
 // ls_sched_score for one state through the resident workgroup (only once it exists: the LS walk that follows then starts
 // from a state the workgroup already holds)
-bool sched_server_can_score(const ls_ctx *ctx) { return ctx->sched_server != nullptr && sched_server_eligible(ctx, 0); }
+bool sched_server_can_score(const ls_ctx *ctx) { return sched_server_eligible(ctx, 0); } // (needs the resident list: it is a launch argument)
+
+static int sched_small_server(ls_ctx *ctx, SchedServer **out);
 
 int sched_server_score(ls_ctx *ctx, const int32_t *state, int64_t *hard, int64_t *soft)
 {
-    SchedServer *s = ctx->sched_server;
-    int rc = sched_server_sync_state(ctx, s, state);
+    SchedServer *s = nullptr;
+    int rc = sched_small_server(ctx, &s);
+    if (rc != LS_OK) return rc;
+    rc = sched_server_sync_state(ctx, s, state);
     if (rc != LS_OK) return rc;
     unsigned pay[16] = {0};
     pay[0] = SCS_F_SCORE;
@@ -1958,17 +2201,19 @@ int sched_server_score(ls_ctx *ctx, const int32_t *state, int64_t *hard, int64_t
     return LS_OK;
 }
 
-// ls_sched_eval_resident through the resident workgroup; `state` is range-checked here when it is not the one the
-// workgroup holds.  n_moves <= 512 (sched_server_eligible).
-int sched_server_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out)
+// the context's one-workgroup scheduling server, created on first use
+static int sched_small_server(ls_ctx *ctx, SchedServer **out)
 {
     SchedServer *s = ctx->sched_server;
     if (!s) {
-        LS_HIP(ctx, hipSetDevice(ctx->device));
         s = new (std::nothrow) SchedServer();
         if (!s) return set_err(ctx, LS_ERR_NOMEM, "out of host memory");
+        ctx->sched_server = s;
+    }
+    if (!s->h.stream) {
+        LS_HIP(ctx, hipSetDevice(ctx->device));
         const int rc = s->h.init(ctx, "scheduling LS-step server", 1, 256);
-        if (rc != LS_OK) { delete s; return rc; }
+        if (rc != LS_OK) return rc;
         s->h.launch = [s, ctx](const SrvLink &L) {
             SchedSrvArgs a;
             a.link = L;
@@ -1982,7 +2227,19 @@ int sched_server_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long
                                  : reinterpret_cast<const void *>(&sched_server_kernel<u64, SCS_NW>);
             return hipLaunchKernel(fn, dim3(1), dim3(64 * SCS_NW), args, 0, s->h.stream);
         };
-        ctx->sched_server = s;
+    }
+    *out = s;
+    return LS_OK;
+}
+
+// ls_sched_eval_resident through the resident workgroup; `state` is range-checked here when it is not the one the
+// workgroup holds.  n_moves <= 512 (sched_server_eligible).
+int sched_server_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out)
+{
+    SchedServer *s = nullptr;
+    {
+        const int rc0 = sched_small_server(ctx, &s);
+        if (rc0 != LS_OK) return rc0;
     }
     int rc = sched_server_sync_state(ctx, s, state);
     if (rc != LS_OK) return rc;
@@ -2005,6 +2262,94 @@ int sched_server_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long
         const ls_sched_move &m = ctx->sc_resident_host[(size_t)r[2]]; // the workgroup applied it to its state
         if (m.type == 0) sh[m.a] = m.b;
         else { const int ea = sh[m.a], eb = sh[m.b]; sh[m.a] = eb; sh[m.b] = ea; }
+    }
+    return LS_OK;
+}
+
+// ---- the resident grid behind ls_sched_eval_resident for lists beyond 512 moves
+static long long sched_grid_chunks(const ls_ctx *ctx) { return (ctx->sc_resident_n + 64 * SCS_NW - 1) / (64 * SCS_NW); }
+
+bool sched_grid_eligible(const ls_ctx *ctx, long long n_moves)
+{
+    // every workgroup must be resident at once: at most two 512-thread workgroups per CU are asked for (the kernel fits four)
+    return ctx->sched_server_on && ctx->sched_delta && ctx->sched.valid && n_moves > 64 * SCS_NW && n_moves <= ctx->sc_resident_n &&
+           ctx->sched.n_employees <= 32768 && ctx->sched.n_days_stored <= 64 - SCG_STATE_AT && n_moves < (1ll << 31) &&
+           sched_grid_chunks(ctx) <= 2ll * ctx->n_cus;
+}
+
+int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out)
+{
+    SchedServer *s = ctx->sched_server;
+    if (!s) {
+        s = new (std::nothrow) SchedServer();
+        if (!s) return set_err(ctx, LS_ERR_NOMEM, "out of host memory");
+        ctx->sched_server = s;
+    }
+    const int S = ctx->sched.n_days_stored, E = ctx->sched.n_employees;
+    for (int d = 0; d < S; d++)
+        if (state[d] < 0 || state[d] >= E)
+            return set_err(ctx, LS_ERR_INVALID, "state entry %d = %d is not an employee index in [0, %d)", d, state[d], E);
+    const long long nch = sched_grid_chunks(ctx);
+    if (!s->grid.stream) {
+        LS_HIP(ctx, hipSetDevice(ctx->device));
+        const int rc = s->grid.init(ctx, "scheduling grid server", 4, 0); // four lines = one message
+        if (rc != LS_OK) return rc;
+        LS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&s->g), 512));
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(64), 0, s->grid.stream, reinterpret_cast<long long *>(s->g), 0ll, 64ll);
+        LS_HIP(ctx, hipGetLastError());
+        LS_HIP(ctx, hipStreamSynchronize(s->grid.stream));
+        s->grid.launch = [s, ctx](const SrvLink &L) {
+            const long long n = sched_grid_chunks(ctx);
+            SchedGridArgs a;
+            a.link = L;
+            a.in = make_inst(ctx);
+            a.moves = ctx->sc_resident_moves.as<ls_sched_move>();
+            a.n_resident = ctx->sc_resident_n;
+            a.g = s->g;
+            s->ready_total += (unsigned long long)n;
+            a.ready_target = s->ready_total;
+            a.part_key = s->ws.as<u64>();
+            a.part_idx = reinterpret_cast<long long *>(a.part_key + n);
+            a.chunk_counts = reinterpret_cast<int *>(a.part_idx + n);
+            void *args[] = {&a};
+            const bool m32 = ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64;
+            const void *fn = m32 ? reinterpret_cast<const void *>(&sched_grid_server_kernel<unsigned, SCS_NW>)
+                                 : reinterpret_cast<const void *>(&sched_grid_server_kernel<u64, SCS_NW>);
+            return hipLaunchKernel(fn, dim3((unsigned)n), dim3(64 * SCS_NW), args, 0, s->grid.stream);
+        };
+    }
+    {   // workspaces for the current resident list (they only change while the launch is paused: sched_server_pause)
+        const size_t need = align256((size_t)nch * 20);
+        if (need > s->ws.cap) {
+            sched_server_pause(ctx); // nothing resident may still use the old block
+            LS_HIP(ctx, hipSetDevice(ctx->device));
+            LS_RESERVE(ctx, s->ws, need);
+            s->ws.collect();
+        }
+    }
+    // the request: ONE message of four lines -- header dwords 0..15, the state from dword 16 on -- every dword with the same
+    // new tag; the master accepts a snapshot only when all 64 tags agree, so the order of these stores does not matter
+    {
+        int rc = s->grid.ensure_running(ctx);
+        if (rc != LS_OK) return rc;
+        const unsigned tag = s->grid.next_tag(0);
+        const unsigned w = (unsigned)(window > 0x7fffffffll ? 0x7fffffffll : window);
+        unsigned pay[64] = {0};
+        pay[0] = SCS_F_EVAL; pay[1] = (unsigned)n_moves & 0xffffu; pay[2] = (unsigned)n_moves >> 16; pay[3] = w & 0xffffu; pay[4] = w >> 16;
+        for (int d = 0; d < S; d++) pay[SCG_STATE_AT + d] = (unsigned)state[d] & 0xffffu;
+        volatile unsigned *dst = s->grid.req(0);
+        for (int d = 63; d >= 0; d--) dst[d] = (tag << 16) | pay[d];
+        s->grid_requests++;
+    }
+    unsigned r[8];
+    const int rc = s->grid.wait(ctx, 0, r);
+    if (rc != LS_OK) return rc;
+    if (!(r[0] & 1u)) { out->n_scored = 0; out->best_index = -1; out->best_hard = 0; out->best_soft = 0; }
+    else {
+        out->n_scored = (long long)(r[1] | (r[2] << 16));
+        out->best_index = (long long)(r[3] | (r[4] << 16));
+        out->best_hard = r[5];
+        out->best_soft = r[6];
     }
     return LS_OK;
 }

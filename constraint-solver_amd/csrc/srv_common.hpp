@@ -69,25 +69,29 @@ __device__ __forceinline__ void srv_poll_begin(SrvPoll &p, const SrvLink &L, con
     if (lane == 0) atomicMax(&L.ctl->last_activity, p.t_start); // nobody reads a stale activity stamp of an earlier launch
 }
 
-// wave 0: wait for the slot's next request.  Returns 1 when the workgroup has to leave, else 0 with the 16 payload
-// halfwords in s_req (LDS).
-__device__ __forceinline__ int srv_poll_wait(SrvPoll &p, const SrvLink &L, const unsigned *req_line, unsigned *s_req, int lane)
+// wave 0: wait for the slot's next request -- a message of ND dwords (one line: 16; up to four consecutive lines: 64).
+// Returns 1 when the workgroup has to leave, else 0 with the ND payload halfwords in s_req (LDS) and, in `raw`, this lane's
+// tagged dword as it was read.
+template <int ND = 16>
+__device__ __forceinline__ int srv_poll_wait(SrvPoll &p, const SrvLink &L, const unsigned *req_line, unsigned *s_req, int lane, unsigned *raw = nullptr)
 {
+    static_assert(ND == 16 || ND == 64, "one line or four");
     for (unsigned polls = 1;; polls++) {
         unsigned v = 0;
         unsigned long long q = 0;
-        if (lane < 16) v = srv_sys_load(req_line + lane);
-        if (lane == 16) q = __hip_atomic_load(&L.ctl->quit_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < ND) v = srv_sys_load(req_line + lane);
+        if (lane == 0) q = __hip_atomic_load(&L.ctl->quit_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned tag = v >> 16;
         const unsigned t0 = __builtin_amdgcn_readfirstlane(tag);
-        const bool whole = __builtin_amdgcn_ballot_w64(lane < 16 && tag != t0) == 0;
+        const bool whole = __builtin_amdgcn_ballot_w64(lane < ND && tag != t0) == 0;
         if (whole && t0 != p.last_tag && t0 != 0) {
-            if (lane < 16) s_req[lane] = v & 0xffffu;
+            if (lane < ND) s_req[lane] = v & 0xffffu;
+            if (raw) *raw = v;
             p.last_tag = t0;
             return (__builtin_amdgcn_readfirstlane(v) & SRV_F_QUIT) ? 1 : 0;
         }
-        const unsigned qlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)q, 16);
-        const unsigned qhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(q >> 32), 16);
+        const unsigned qlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)q);
+        const unsigned qhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(q >> 32));
         if ((((unsigned long long)qhi << 32) | qlo) == L.gen) return 1;
         const unsigned long long now = wall_clock64();
         if ((polls & 15u) == 0) { // nobody served for idle_ticks, or the launch has reached its age limit: everybody leaves

@@ -316,3 +316,61 @@ def test_sched_server_follows_any_call_sequence(monkeypatch, dates, E):
                 assert cnt["server_launches"] >= 3
         results[server] = got
     assert results["1"] == results["0"]
+
+
+def test_sched_grid_server_long_lists(monkeypatch):
+    # ls_sched_eval_resident for lists beyond one workgroup: the resident GRID (one workgroup per 512-move chunk, a device-side
+    # go record, the last workgroup finishes and scores the cut chunk again).  Windows on, just before and just after chunk
+    # boundaries' cumulative candidate counts, beyond the list, 1; short requests on a long resident list; idle relaunch;
+    # a new list under a live grid; against the oracle and against the two-launch route.
+    import ls_amd
+    monkeypatch.setenv("LS_NQ_SERVER_IDLE_US", "500")
+    rng = np.random.default_rng(2024)
+    E = 23
+    hol = {e: list(rng.choice(20, size=int(rng.integers(0, 3)), replace=False)) for e in range(E)}
+    inst = orc.Sched((2022, 5, 9), (2022, 6, 8), hol)
+    D, S = inst.n_scored_days, inst.n_scored_days + 1
+    bits = np.zeros(E, dtype=np.uint64)
+    for e, ds in hol.items():
+        for d in ds:
+            bits[e] |= np.uint64(1) << np.uint64(int(d))
+    results = {}
+    for server in ("1", "0"):
+        monkeypatch.setenv("LS_SCHED_SERVER", server)
+        prng = np.random.default_rng(9)
+        got = []
+        with ls_amd.Context(0) as c:
+            c.sched_instance_upload(D, S, inst.start_weekday, E, bits)
+            moves = _random_moves(prng, 2600, D, E)                     # 6 chunks, the last one partial
+            c.sched_moves_upload(moves)
+            state = prng.integers(0, E, size=S)
+            for it in range(40):
+                k = int(prng.choice([len(moves), len(moves) - 1, 513, 1025, int(prng.integers(513, len(moves) + 1))]))
+                exp_all = inst.neighbourhood(state, moves[:k], 10 ** 9)
+                real = exp_all["n_scored"]                               # real candidates among the first k moves
+                w = int(prng.choice([1, 2, real - 1, real, real + 1, 10 ** 9, int(prng.integers(1, real + 1)), 400, 420, 840]))
+                w = max(1, w)
+                r = c.sched_eval_resident(state, k, w)
+                exp = inst.neighbourhood(state, moves[:k], w)
+                assert (r["n_scored"], r["best_index"]) == (exp["n_scored"], exp["best_index"]), (it, k, w)
+                if exp["best_index"] >= 0:
+                    assert (r["best_hard"], r["best_soft"]) == (exp["best_hard"], exp["best_soft"])
+                got.append(r)
+                if it % 3 != 2 and r["best_index"] >= 0:
+                    t, a, b = moves[r["best_index"]]
+                    state = state.copy()
+                    if t == 0:
+                        state[a] = b
+                    else:
+                        state[a], state[b] = state[b], state[a]
+                else:
+                    state = prng.integers(0, E, size=S)
+                if it == 15:
+                    time.sleep(0.01)                                     # the grid leaves (idle) and comes back
+                if it == 25:
+                    moves = _random_moves(prng, 1500, D, E)              # a new, shorter list: another grid size
+                    c.sched_moves_upload(moves)
+            cnt = c.counters()
+            assert (cnt["server_requests"] >= 40) == (server == "1")
+        results[server] = got
+    assert results["1"] == results["0"]
