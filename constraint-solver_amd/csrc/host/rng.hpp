@@ -412,20 +412,24 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted_reference(
 // The `amount` best of `keyed` by (key descending, index ascending), in that order: a bucket histogram over the keys.
 // `key_floor` is a hint -- the buckets divide [key_floor, 1], keys below it share bucket 0 -- so that a pre-filtered
 // input (all keys in a narrow band under 1) still spreads over the buckets; short inputs use 64 buckets, not 256.
-inline void weighted_top(std::vector<WeightedKey> &keyed, uint32_t amount, std::vector<uint32_t> &out, double key_floor = 0.0)
+// `key_ceil`: the keys lie in [.., key_ceil] (1 for u^(1/w); 0 for the surrogate keys y log2(u)).  `guard` > 0: also report in
+// *ambiguous whether any two keys whose order matters -- neighbours in the result, or the last taken and the best left out --
+// are closer than `guard`.
+inline void weighted_top(std::vector<WeightedKey> &keyed, uint32_t amount, std::vector<uint32_t> &out, double key_floor = 0.0,
+                         double key_ceil = 1.0, double guard = 0.0, bool *ambiguous = nullptr)
 {
     static thread_local std::vector<WeightedKey> taken;
     static thread_local std::vector<uint8_t> bucket;
     const uint32_t length = (uint32_t)keyed.size();
     constexpr int BMAX = 256;
     const int B = length <= 512 ? 64 : BMAX;
-    if (!(key_floor >= 0.0 && key_floor < 1.0)) key_floor = 0.0;
-    const double scale = (double)B / (1.0 - key_floor);
+    if (!(key_floor < key_ceil)) key_floor = key_ceil - 1.0;
+    const double scale = (double)B / (key_ceil - key_floor);
     uint32_t hist[BMAX];
     for (int b = 0; b < B; b++) hist[b] = 0;
     bucket.resize(length);
     for (uint32_t i = 0; i < length; i++) {
-        const double k = keyed[i].key; // in [0, 1]; NaN cannot occur (w >= 0, 0 <= u < 1)
+        const double k = keyed[i].key; // <= key_ceil; NaN cannot occur (w >= 0, 0 <= u < 1)
         int b = k <= key_floor ? 0 : (int)((k - key_floor) * scale);
         b = b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
         bucket[i] = (uint8_t)b;
@@ -464,6 +468,18 @@ inline void weighted_top(std::vector<WeightedKey> &keyed, uint32_t amount, std::
     }
     out.resize(amount);
     for (uint32_t i = 0; i < amount; i++) out[i] = taken[i].index;
+    if (ambiguous) {
+        bool amb = false;
+        for (uint32_t i = 0; i + 1 < amount; i++) amb = amb || !(taken[i].key - taken[i + 1].key >= guard);
+        if (amount > 0 && amount < length) { // the best key that was left out: in the threshold bucket's remainder or in a lower bucket
+            double best_out = -1.0e300;
+            for (uint32_t i = need; i < hist[t]; i++) best_out = tb[i].key > best_out ? tb[i].key : best_out;
+            for (uint32_t i = 0; i < length; i++)
+                if (bucket[i] < t && keyed[i].key > best_out) best_out = keyed[i].key;
+            amb = amb || !(taken[amount - 1].key - best_out >= guard);
+        }
+        *ambiguous = amb;
+    }
 }
 
 // log2(u) for u = 2^e (1 + f) in (0, 1), f in [0, 1):  e + f + 0.345 f (1 - f), within NQ_LOG2_APPROX_ERR of the true
@@ -552,6 +568,48 @@ __attribute__((target("avx512f,avx512dq,avx512vl"))) inline uint32_t weighted_fi
     return n;
 }
 
+// t = y log2(u) for the kept keys, accurate to ~1e-15 absolute (u in [2^-53, 1), y in (0, 1]): u = 2^e m, m in [sqrt(1/2), sqrt 2),
+// ln m = 2 atanh(f), f = (m - 1) / (m + 1) <= 0.1716, twelve terms of the series (truncation < 1e-20).  The ORDER of the keys
+// u^y = 2^t is the order of t wherever two t differ by more than the guard of index_sample_weighted (1e-11 >> this error + pow's
+// < 1 ulp): eight keys per instruction instead of one libm pow per key.
+__attribute__((target("avx512f,avx512dq,avx512vl"))) inline void weighted_log2_keys_avx512(const double *us, const double *ys, const uint32_t *idx,
+                                                                                        uint32_t n_keep, WeightedKey *keyed)
+{
+    const __m512d v1 = _mm512_set1_pd(1.0), vhalf = _mm512_set1_pd(0.5), vsqrt2 = _mm512_set1_pd(1.4142135623730951),
+                  vlog2e2 = _mm512_set1_pd(2.0 * 1.4426950408889634);
+    uint32_t j = 0;
+    for (; j < n_keep; j += 8) {
+        const uint32_t left = n_keep - j;
+        const __mmask8 live = left >= 8 ? (__mmask8)0xff : (__mmask8)((1u << left) - 1u);
+        const __m256i vi = _mm256_maskz_loadu_epi32(live, idx + j);
+        const __m512d u = _mm512_mask_i32gather_pd(v1, live, vi, us, 8), y = _mm512_mask_i32gather_pd(v1, live, vi, ys, 8);
+        __m512d e = _mm512_getexp_pd(u);
+        __m512d m = _mm512_getmant_pd(u, _MM_MANT_NORM_1_2, _MM_MANT_SIGN_src);
+        const __mmask8 big = _mm512_cmp_pd_mask(m, vsqrt2, _CMP_GT_OQ);
+        m = _mm512_mask_mul_pd(m, big, m, vhalf);
+        e = _mm512_mask_add_pd(e, big, e, v1);
+        const __m512d f = _mm512_div_pd(_mm512_sub_pd(m, v1), _mm512_add_pd(m, v1));
+        const __m512d z = _mm512_mul_pd(f, f);
+        __m512d p = _mm512_set1_pd(1.0 / 23.0);
+        p = _mm512_fmadd_pd(p, z, _mm512_set1_pd(1.0 / 21.0));
+        p = _mm512_fmadd_pd(p, z, _mm512_set1_pd(1.0 / 19.0));
+        p = _mm512_fmadd_pd(p, z, _mm512_set1_pd(1.0 / 17.0));
+        p = _mm512_fmadd_pd(p, z, _mm512_set1_pd(1.0 / 15.0));
+        p = _mm512_fmadd_pd(p, z, _mm512_set1_pd(1.0 / 13.0));
+        p = _mm512_fmadd_pd(p, z, _mm512_set1_pd(1.0 / 11.0));
+        p = _mm512_fmadd_pd(p, z, _mm512_set1_pd(1.0 / 9.0));
+        p = _mm512_fmadd_pd(p, z, _mm512_set1_pd(1.0 / 7.0));
+        p = _mm512_fmadd_pd(p, z, _mm512_set1_pd(1.0 / 5.0));
+        p = _mm512_fmadd_pd(p, z, _mm512_set1_pd(1.0 / 3.0));
+        p = _mm512_fmadd_pd(p, z, v1);
+        const __m512d lg = _mm512_fmadd_pd(_mm512_mul_pd(f, p), vlog2e2, e); // e + 2 f p log2(e)
+        const __m512d t = _mm512_mul_pd(y, lg);
+        alignas(64) double tt[8];
+        _mm512_store_pd(tt, t);
+        for (uint32_t q = 0; q < 8 && q < left; q++) keyed[j + q] = WeightedKey{tt[q], idx[j + q]};
+    }
+}
+
 inline bool weighted_have_avx512()
 {
     static const bool v = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl") &&
@@ -559,6 +617,17 @@ inline bool weighted_have_avx512()
     return v;
 }
 #endif
+
+inline bool weighted_surrogate_on() // LS_HOST_EXACT_POW=1: order the survivors by libm pow keys (the round-2 path; tests run both)
+{
+    static const bool v = std::getenv("LS_HOST_EXACT_POW") == nullptr;
+    return v;
+}
+inline uint64_t &weighted_surrogate_fallbacks() // calls of this thread that found two keys within the guard and took the exact path
+{
+    static thread_local uint64_t n = 0;
+    return n;
+}
 
 template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, const std::vector<double> &weights, uint32_t amount)
 {
@@ -625,6 +694,23 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, co
             for (uint32_t i = 0; i < length; i++)
                 if (hi[i] >= cut) idx[n_keep++] = i;
         keyed.resize(n_keep);
+#if defined(__x86_64__)
+        if (wide && t > 0 && weighted_surrogate_on()) {
+            // Order the survivors by t = y log2(u) (weighted_log2_keys_avx512) instead of by pow(u, y): the same order wherever two t
+            // differ by more than 1e-11 (pow's < 1 ulp error and the surrogate's ~1e-15 are four orders of magnitude below it); if any
+            // two keys whose order matters are closer than that (probability ~1e-7 per call), fall through to the exact keys.
+            bool u_zero = false;
+            for (uint32_t j = 0; j < n_keep; j++) u_zero = u_zero || !(us[idx[j]] > 0.0);
+            if (!u_zero) {
+                weighted_log2_keys_avx512(us.data(), ys.data(), idx.data(), n_keep, keyed.data());
+                std::vector<uint32_t> out;
+                bool ambiguous = true;
+                weighted_top(keyed, amount, out, cut, 0.0, 1e-11, &ambiguous);
+                if (!ambiguous) return out;
+                weighted_surrogate_fallbacks()++;
+            }
+        }
+#endif
         for (uint32_t j = 0; j < n_keep; j++) {
             const uint32_t i = idx[j];
             keyed[j] = WeightedKey{std::pow(us[i], ys[i]), i};

@@ -68,6 +68,35 @@ int main()
             if (!(u < 1.0)) continue;
             if (std::fabs(approx_log2_unit(u) - std::log2(u)) > LOG2_APPROX_ERR - 4e-4) { printf("FAIL log2 bound at %a\n", u); return 1; }
         }
+#if defined(__x86_64__)
+    // the surrogate keys t = y log2(u) that order the pre-filter's survivors (round 3): accurate to well under the 1e-11 guard --
+    // against long-double log2 on a dense sweep of mantissas, every binade of gen_f64's range, exponents y = 1 / w as the proposer has them
+    if (weighted_have_avx512()) {
+        double worst = 0;
+        std::vector<double> us, ys;
+        std::vector<uint32_t> idx;
+        for (int e = -53; e <= -1; e++)
+            for (int i = 0; i < 60000; i++) {
+                const double u = std::ldexp(1.0 + ((double)i + 0.37) / 60000.0, e);
+                if (!(u < 1.0)) continue;
+                us.push_back(u);
+                ys.push_back(1.0 / (1.0 + (double)(i % 97) + 1e-4));
+                idx.push_back((uint32_t)idx.size());
+            }
+        std::vector<WeightedKey> k(us.size());
+        weighted_log2_keys_avx512(us.data(), ys.data(), idx.data(), (uint32_t)us.size(), k.data());
+        for (size_t i = 0; i < us.size(); i++) {
+            const long double t = (long double)ys[i] * log2l((long double)us[i]);
+            const double err = (double)fabsl((long double)k[i].key - t);
+            worst = err > worst ? err : worst;
+            if (k[i].index != idx[i]) { printf("FAIL surrogate index\n"); return 1; }
+        }
+        printf("surrogate keys: worst |t - y log2 u| = %.3g over %zu keys; calls that fell back to exact pow keys: %llu\n", worst, us.size(),
+               (unsigned long long)weighted_surrogate_fallbacks());
+        if (!(worst < 2e-14)) { printf("FAIL surrogate accuracy\n"); return 1; }
+        if (weighted_surrogate_on() && weighted_surrogate_fallbacks() == 0) { printf("FAIL: the guard never fired (mode 2 crowds keys within 1e-11)\n"); return 1; }
+    }
+#endif
     printf("OK\n");
     return 0;
 }
