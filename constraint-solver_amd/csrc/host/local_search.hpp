@@ -10,7 +10,7 @@
 //   Solution generate_initial_solution(Rng&)                       InitialSolutionGenerator
 //   Score    score(const Solution&)                                 SolutionScoreCalculator
 //   Solution propose_new_starting_solution(current, is_best_in_history, Rng&)   Perturbation
-//   bool     best_of_neighbourhood(current, Rng& ls_rng, window, ScoredSolution& out, const History& tabu)
+//   bool     best_of_neighbourhood(current, Rng& ls_rng, window, ScoredSolution& out, const History& tabu, bool continued)
 //            == MoveProposer + tabu filter + score + take + sort + first; `tabu` is LocalSearch's own History: its
 //            set is {current} for every configuration the reference ships (the GPU's built-in rule) and anything
 //            else it holds is handed to the GPU as an exclusion list
@@ -20,6 +20,7 @@
 #include <deque>
 #include <memory>
 #include <set>
+#include <stdexcept>
 #include <utility>
 #include <vector>
 
@@ -51,12 +52,25 @@ public:
     void seen_solution(const SS &s)
     {
         iteration_count++;
+        if (expiry_ >= 1) {
+            // Every configuration the reference ships (expiry 1000 / 10000): _pop_solution_for_age evicts every entry that is
+            // YOUNGER than the expiry (:182-195), i.e. all of them, and the solution just seen is added -- the set is {s} after
+            // every call, whatever it held before.  Nothing reads its contents while it has one element (the evaluators' built-in
+            // tabu rule IS "candidate == current"; tabu_size() is what callers ask), so the 32 KB copy, its allocation and the
+            // previous entry's release are skipped: only the fact is recorded.
+            single_ = true;
+            return;
+        }
         pop_solution_for_age();
         if (lookup_.find(s.solution) != lookup_.end()) return;
         add_solution(s);
     }
     // :197-199
-    bool is_solution_tabu(const typename P::Solution &s) const { return lookup_.find(s) != lookup_.end(); }
+    bool is_solution_tabu(const typename P::Solution &s) const
+    {
+        if (single_) throw std::logic_error("History: the single-entry set is not materialised (callers test tabu_size() == 1 first)");
+        return lookup_.find(s) != lookup_.end();
+    }
     // :201-203
     bool is_best_solution(const SS &s) const { return best_.count(s) != 0; }
     // :205-218
@@ -86,10 +100,11 @@ public:
         out = *best_.begin();
         return true;
     }
-    size_t tabu_size() const { return lookup_.size(); }
+    size_t tabu_size() const { return single_ ? 1 : lookup_.size(); }
     // visit every tabu solution (general History configurations hand them to the GPU as exclusions)
     template <class F> void for_each_tabu(F &&f) const
     {
+        if (single_) throw std::logic_error("History: the single-entry set is not materialised");
         for (const auto &sp : lookup_) f(*sp);
     }
     uint64_t iteration_count = 0;
@@ -132,6 +147,7 @@ private:
     std::deque<Entry> all_;
     std::set<SolPtr, PtrLess> lookup_;
     uint64_t expiry_;
+    bool single_ = false; // expiry >= 1: the set is {the solution last seen}, not materialised
 };
 
 // LocalSearch (local_search.rs:253-342).
@@ -152,15 +168,16 @@ public:
         SS best;
         bool best_is_current = true;
         uint64_t no_improvement_for = 0;
+        bool continued = false; // `current` is the winner the previous iteration's best_of_neighbourhood produced (nothing else touched it)
         for (uint64_t it = 0; it < max_iterations_; it++) {
             history_.seen_solution(current);
             if (P::is_best(current.score)) return current;
             // :315-325 — the GPU seam.  The evaluator's built-in tabu rule is "candidate == current"; seen_solution has
             // just made sure the current solution IS in the set (it was there, or it has been added), whatever else a
             // general History keeps.
-            SS nb;
+            SS &nb = nb_; // reused across iterations: the winner's board is copy-ASSIGNED into it (no 32 KB allocation per iteration)
             ls_iterations++;
-            if (p_->best_of_neighbourhood(current, rng_, window_size_, nb, history_)) {
+            if (p_->best_of_neighbourhood(current, rng_, window_size_, nb, history_, continued)) {
                 if (nb.score < current.score) {
                     best_is_current = true; // best = nb, which becomes current below
                     no_improvement_for = 0;
@@ -169,7 +186,8 @@ public:
                     no_improvement_for++;
                     if (no_improvement_for >= allow_no_improvement_for) break;
                 }
-                current = std::move(nb);
+                std::swap(current, nb); // current = nb; the old current's storage becomes the next iteration's nb
+                continued = true;
             } else {
                 break;
             }
@@ -184,6 +202,7 @@ private:
     size_t window_size_;
     History<P> history_;
     Rng rng_;
+    SS nb_;
 };
 
 // AcceptanceCriterion::choose (iterated_local_search.rs:51-71): weighted pick among

@@ -197,6 +197,7 @@ struct NQueensProblem {
     mutable int64_t cached_total = 0;
     mutable bool cache_valid = false;
     mutable bool last_lookup_hit = false;        // the board of the last col_scores() call IS cached_board
+    mutable bool cache_is_last_winner = false;   // cached_board is the winner board the last best_of_neighbourhood produced
     // per-iteration scratch, reused (at n = 4096 a fresh 32 KB vector per LS iteration costs microseconds)
     std::vector<int64_t> spare_cs;
     mutable std::vector<uint32_t> conflict_cols_buf;
@@ -227,9 +228,11 @@ struct NQueensProblem {
 
     // get_col_scores (lib.rs:74-87) on the GPU; also returns the sum (lib.rs:130-139)
     // (returns a reference to the cache: valid until the next call)
-    const std::vector<int64_t> &col_scores(const Solution &s, int64_t *total) const
+    // `trusted`: the caller vouches that `s` IS the cached board (LocalSearch continuing from the winner the previous call
+    // produced: local_search.hpp `continued`): the 2 x 32 KB compare is skipped
+    const std::vector<int64_t> &col_scores(const Solution &s, int64_t *total, bool trusted = false) const
     {
-        if (cache_valid && s == cached_board) {
+        if (cache_valid && ((trusted && cache_is_last_winner && s.size() == cached_board.size()) || s == cached_board)) {
             last_lookup_hit = true;
             if (total) *total = cached_total;
             return cached_cs;
@@ -256,6 +259,7 @@ struct NQueensProblem {
         }
         if (total) *total = tot;
         cached_board = s; cached_rows32 = rows; cached_cs.swap(cs); cached_total = tot; cache_valid = true;
+        cache_is_last_winner = false;
         last_lookup_hit = true;
         return cached_cs;
     }
@@ -268,48 +272,63 @@ struct NQueensProblem {
 
     // the columns with a non-zero score and their sampling weights score + 1e-4 (lib.rs:184-190), in column order
 #if defined(__x86_64__)
-    __attribute__((target("avx512f,avx512dq,avx512vl"))) static size_t nonzero_columns_avx512(const int64_t *cs, size_t n, uint32_t *cols, double *weights)
+    __attribute__((target("avx512f,avx512dq,avx512vl"))) static size_t nonzero_columns_avx512(const int64_t *cs, size_t n, uint32_t *cols, double *weights, int64_t *sum)
     {
         const __m512d eps = _mm512_set1_pd(1e-4);
         const __m512i zero = _mm512_setzero_si512();
+        __m512i acc = _mm512_setzero_si512();
         __m256i cur = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
         const __m256i eight = _mm256_set1_epi32(8);
         size_t k = 0, c = 0;
         for (; c + 8 <= n; c += 8) {
             const __m512i v = _mm512_loadu_si512(cs + c);
+            acc = _mm512_add_epi64(acc, v);
             const __mmask8 m = _mm512_cmpneq_epi64_mask(v, zero);
             _mm256_mask_compressstoreu_epi32(cols + k, m, cur);
             _mm512_mask_compressstoreu_pd(weights + k, m, _mm512_add_pd(_mm512_cvtepi64_pd(v), eps));
             k += (size_t)__builtin_popcount((unsigned)m);
             cur = _mm256_add_epi32(cur, eight);
         }
-        for (; c < n; c++)
+        int64_t total = _mm512_reduce_add_epi64(acc);
+        for (; c < n; c++) {
+            total += cs[c];
             if (cs[c] != 0) { cols[k] = (uint32_t)c; weights[k] = (double)cs[c] + 1e-4; k++; }
+        }
+        *sum = total;
         return k;
     }
 #endif
-    static size_t nonzero_columns(const int64_t *cs, size_t n, uint32_t *cols, double *weights)
+    // (also the sum of the scores: the consistency check "column scores sum to the score" rides on this pass)
+    static size_t nonzero_columns(const int64_t *cs, size_t n, uint32_t *cols, double *weights, int64_t *sum)
     {
 #if defined(__x86_64__)
-        if (weighted_have_avx512()) return nonzero_columns_avx512(cs, n, cols, weights);
+        if (weighted_have_avx512()) return nonzero_columns_avx512(cs, n, cols, weights, sum);
 #endif
         size_t k = 0;
-        for (size_t c = 0; c < n; c++)
+        int64_t total = 0;
+        for (size_t c = 0; c < n; c++) {
+            total += cs[c];
             if (cs[c] != 0) { cols[k] = (uint32_t)c; weights[k] = (double)cs[c] + 1e-4; k++; }
+        }
+        *sum = total;
         return k;
     }
 
     // NQueensMoveProposer::iter_local_moves, the part before the iterator (lib.rs:182-205):
     // columns with conflicts, Efraimidis-Spirakis weighted sample of `amount`, then a random
     // number of them in choose_multiple order.  Empty result <=> `random_cols == None`.
-    template <class R> std::vector<int32_t> propose_columns(const Solution &start, R &rng) const
+    template <class R> std::vector<int32_t> propose_columns(const Solution &start, R &rng, bool trusted = false) const
     {
-        const std::vector<int64_t> &cs = col_scores(start, nullptr);
+        int64_t want_total = 0;
+        const std::vector<int64_t> &cs = col_scores(start, &want_total, trusted);
         std::vector<uint32_t> &conflict_cols = conflict_cols_buf;
         std::vector<double> &weights = weights_buf;
         conflict_cols.resize(cs.size());
         weights.resize(cs.size());
-        const size_t n_conflict = nonzero_columns(cs.data(), cs.size(), conflict_cols.data(), weights.data());
+        int64_t sum = 0;
+        const size_t n_conflict = nonzero_columns(cs.data(), cs.size(), conflict_cols.data(), weights.data(), &sum);
+        if (sum != want_total) // fail loudly on impossible column scores (they sum to the board's score) instead of walking on from them
+            throw std::runtime_error("column scores of the current board sum to " + std::to_string(sum) + ", its score is " + std::to_string(want_total));
         conflict_cols.resize(n_conflict);
         weights.resize(n_conflict);
         if (conflict_cols.empty()) return {};
@@ -351,10 +370,12 @@ struct NQueensProblem {
         return out;
     }
 
-    template <class R> bool best_of_neighbourhood(const SS &current, R &rng, size_t window, SS &out, const History<NQueensProblem> &tabu)
+    template <class R> bool best_of_neighbourhood(const SS &current, R &rng, size_t window, SS &out, const History<NQueensProblem> &tabu,
+                                                  bool continued = false)
     {
         const auto T0 = std::chrono::steady_clock::now();
-        const std::vector<int32_t> cols = propose_columns(current.solution, rng);
+        const std::vector<int32_t> cols = propose_columns(current.solution, rng, continued);
+        cache_is_last_winner = false; // until this call has put its winner into the cache (the general-tabu route does not)
         if (cols.empty()) return false;
         // propose_columns has just looked the current board up: it is the cached one (already packed) in the steady state
         const bool cur_is_cached = last_lookup_hit && cached_rows32.size() == current.solution.size();
@@ -410,8 +431,7 @@ struct NQueensProblem {
         if (res.best_index < 0) return false;
         {   // fail loudly on an impossible record instead of walking on from it
             const int64_t n = (int64_t)rows.size();
-            int64_t sum = 0;
-            for (int64_t v : next_cs) sum += v;
+            const int64_t sum = res.best_score; // (the column scores' sum is checked by the next iteration's scan of them: propose_columns)
             const bool ok = res.best_score >= 0 && !(res.best_score & 1) && res.best_col >= 0 && res.best_col < n &&
                             res.best_value >= 0 && res.best_value < n && res.best_index / n < (int64_t)cols.size() &&
                             cols[(size_t)(res.best_index / n)] == res.best_col && res.best_index % n == res.best_value &&
@@ -435,6 +455,7 @@ struct NQueensProblem {
             cached_rows32[(size_t)res.best_col] = res.best_value;
         }
         cached_cs.swap(next_cs); cached_total = res.best_score; cache_valid = true;
+        cache_is_last_winner = true;
         return true;
     }
 
@@ -550,7 +571,7 @@ struct SchedProblem {
         }
     }
 
-    bool best_of_neighbourhood(const SS &current, ChaCha20Rng &rng, size_t window, SS &out, const History<SchedProblem> &tabu)
+    bool best_of_neighbourhood(const SS &current, ChaCha20Rng &rng, size_t window, SS &out, const History<SchedProblem> &tabu, bool = false)
     {
         if (window == 0) return false;
         if (tabu.tabu_size() != 1) return best_of_neighbourhood_general(current, rng, window, out, tabu);
