@@ -47,7 +47,7 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[]; // tables | rows[n] | slot records[NQ_STEP_MAX_SLOTS]
     __shared__ unsigned s_req[16];
-    __shared__ unsigned long long s_best[16];
+    __shared__ unsigned long long s_bestmin; // the block's minimum key: one LDS atomic per wavefront (NQ_KEY_EMPTY between requests)
     __shared__ int s_sum[16], s_cnt[16];
     __shared__ int s_leave;
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
 #define SRV_STAMP(I) do { } while (0)
 #endif
     if (wib == 0) srv_poll_begin(poll, a.link, resp, lane);
+    if (tid == 0) s_bestmin = NQ_KEY_EMPTY; // published by the first B1
     for (;;) {
         if (wib == 0) {
             const int leave = srv_poll_wait(poll, a.link, req, s_req, lane);
@@ -125,19 +126,35 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
             lds_board = board;
             __syncthreads();
         }
-        int my_scored = 0;
-        if (tid < n_slots) {
-            const int c = cv;
-            const int rc = (unsigned)c < (unsigned)n ? s_rows[c] : -1;
-            int conf_old = 0;
-            if ((unsigned)rc < (unsigned)n)
+        // Inline columns on the paired layout (every reference-shaped request: window 5n reaches six columns): no slot-record phase
+        // and no barrier for it -- a wavefront derives the record of the column it walks itself (two dependent LDS round trips),
+        // and n_scored is the window: the host has range-checked the columns and the board, no slot is ever skipped here.
+        const bool direct = PAIRS && !(flags & SRV_F_EXT_COLS);
+        auto slot_record = [&](int slot, int &c, int &rc, int &conf_old) {
+            if (direct) {
+                c = (int)s_req[6 + slot];
+                rc = s_rows[c];
                 conf_old = tab16_get(s_t16, rc) + tab16_get(s_t16, oA + rc - c + n) + tab16_get(s_t16, oB + rc + c) - 3;
-            s_slot[tid] = make_int4(c, (unsigned)rc < (unsigned)n ? rc : -1, conf_old, 0);
-            if ((unsigned)rc < (unsigned)n) my_scored = tid < n_whole ? n - 1 : rem; // a skipped slot keeps its window positions (nq_slot_scored)
+            } else {
+                const int4 si = s_slot[slot];
+                c = si.x; rc = si.y; conf_old = si.z;
+            }
+        };
+        if (!direct) { // block-uniform
+            int my_scored = 0;
+            if (tid < n_slots) {
+                const int c = cv;
+                const int rc = (unsigned)c < (unsigned)n ? s_rows[c] : -1;
+                int conf_old = 0;
+                if ((unsigned)rc < (unsigned)n)
+                    conf_old = tab16_get(s_t16, rc) + tab16_get(s_t16, oA + rc - c + n) + tab16_get(s_t16, oB + rc + c) - 3;
+                s_slot[tid] = make_int4(c, (unsigned)rc < (unsigned)n ? rc : -1, conf_old, 0);
+                if ((unsigned)rc < (unsigned)n) my_scored = tid < n_whole ? n - 1 : rem; // a skipped slot keeps its window positions (nq_slot_scored)
+            }
+            if (n_slots > 64 * wib) my_scored = wave_sum_i32(my_scored); // wave-uniform
+            if (lane == 0) s_cnt[wib] = my_scored;
+            __syncthreads(); // B2
         }
-        if (n_slots > 64 * wib) my_scored = wave_sum_i32(my_scored); // wave-uniform
-        if (lane == 0) s_cnt[wib] = my_scored;
-        __syncthreads(); // B2
         SRV_STAMP(2);
         unsigned long long best = NQ_KEY_EMPTY;
         if (step) { // block-uniform
@@ -146,16 +163,17 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
                 const int units = n_whole * parts;
                 for (int u = team; u < units; u += 16) {
                     const int slot = u / parts, part = u - slot * parts;
-                    const int4 si = s_slot[slot];
-                    const int c = __builtin_amdgcn_readfirstlane(si.x), rc = __builtin_amdgcn_readfirstlane(si.y),
-                              conf_old = __builtin_amdgcn_readfirstlane(si.z);
+                    int c0, rc0, co0;
+                    slot_record(slot, c0, rc0, co0);
+                    const int c = __builtin_amdgcn_readfirstlane(c0), rc = __builtin_amdgcn_readfirstlane(rc0),
+                              conf_old = __builtin_amdgcn_readfirstlane(co0);
                     if (rc < 0) continue;
                     nq_pairs_unit<64, false>(s_t16, n, lane, c, rc, conf_old, slot, part * per_part, per_part, nullptr, 0, best);
                 }
                 if (rem > 0) { // the slot the window cuts: per-range loops, all lanes
                     const int slot = n_whole;
-                    const int4 si = s_slot[slot];
-                    const int c = si.x, rc = si.y, conf_old = si.z;
+                    int c, rc, conf_old;
+                    slot_record(slot, c, rc, conf_old);
                     if (rc >= 0) {
                         const unsigned short *t16 = reinterpret_cast<const unsigned short *>(s_t16);
                         const NqRanges rg = nq_ranges(0, n, rc, 0, rem); // `rem` candidates are left for this column
@@ -192,17 +210,17 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
             }
         }
         best = wave_min_u64(best);
-        if (lane == 0) s_best[wib] = best;
+        if (lane == 0 && best != NQ_KEY_EMPTY) __hip_atomic_fetch_min(&s_bestmin, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         SRV_STAMP(3);
         __syncthreads(); // B3
         SRV_STAMP(4);
         if (!want_cs && wib != 0) continue; // the other wavefronts are done: wave 0 answers, then patches the LDS state
-        unsigned long long key = s_best[0];
+        const unsigned long long key = s_bestmin;
+        int n_scored = direct ? window : 0;
+        if (!direct) {
 #pragma unroll
-        for (int i = 1; i < 16; i++) key = u64min(key, s_best[i]);
-        int n_scored = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) n_scored += s_cnt[i];
+            for (int i = 0; i < 16; i++) n_scored += s_cnt[i];
+        }
         const bool has_move = key != NQ_KEY_EMPTY && n_scored != 0;
         int mc = -1, mv = -1, mq = -1;
         if (has_move) {
@@ -247,6 +265,7 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
         }
         // wave 0: the response line, then the move goes into the LDS board and tables
         {
+            if (lane == 0) s_bestmin = NQ_KEY_EMPTY; // every reader of this request's minimum has passed (B3, and B4 with column scores)
             const unsigned dl = step ? (unsigned)((int)(key >> 46)) : (unsigned)total; // delta + bias | the board's score
             unsigned pay = 0;
             if (lane == 0) pay = has_move ? 1u : 0u;
