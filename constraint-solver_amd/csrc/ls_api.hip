@@ -873,10 +873,11 @@ static int sched_check_state(ls_ctx *ctx, const int32_t *states, long long count
 int ls_sched_score(ls_ctx *ctx, int32_t n_states, const int32_t *states, int64_t *hard, int64_t *soft,
                    int64_t *terms)
 {
-    LS_BIND(ctx);
+    if (!ctx) return LS_ERR_INVALID;
     if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
     LS_REQUIRE(ctx, n_states >= 1 && states && hard && soft, "bad arguments");
     if (n_states == 1 && !terms && sched_server_can_score(ctx)) return sched_server_score(ctx, states, hard, soft); // no launch
+    LS_BIND(ctx);
     const int S = ctx->sched.n_days_stored;
     int rc = sched_check_state(ctx, states, (long long)n_states * S);
     if (rc != LS_OK) return rc;
@@ -1030,14 +1031,16 @@ int ls_sched_moves_upload(ls_ctx *ctx, const ls_sched_move *moves, int64_t n_mov
 
 int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, int64_t window, ls_sched_result *out)
 {
-    LS_BIND(ctx);
+    if (!ctx) return LS_ERR_INVALID;
     if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
     LS_REQUIRE(ctx, state && out && window >= 0, "bad arguments");
     LS_REQUIRE(ctx, n_moves >= 0 && n_moves <= ctx->sc_resident_n, "n_moves = %lld exceeds the resident list (%lld)",
                (long long)n_moves, ctx->sc_resident_n);
     const int S = ctx->sched.n_days_stored;
-    if (sched_server_eligible(ctx, n_moves)) return sched_server_eval(ctx, state, n_moves, window, out); // no launch: the resident workgroup
-    if (sched_grid_eligible(ctx, n_moves)) return sched_grid_eval(ctx, state, n_moves, window, out);       // no launch: the resident grid
+    // no launch and, in the steady state, no runtime call: the resident workgroup (<= 512 moves) or the resident grid
+    if (sched_server_eligible(ctx, n_moves)) return sched_server_eval(ctx, state, n_moves, window, out);
+    if (sched_grid_eligible(ctx, n_moves)) return sched_grid_eval(ctx, state, n_moves, window, out);
+    LS_BIND(ctx);
     int rc = sched_check_state(ctx, state, S);
     if (rc != LS_OK) return rc;
     const size_t o_nm = 0, o_st = 256, in_b = align256(o_st + (size_t)S * 4), out_b = 256;

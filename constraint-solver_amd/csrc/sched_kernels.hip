@@ -39,6 +39,8 @@
 // The vector order of <= 2-edit candidates of one base is a closed form over the edits:
 // per edit (class: lowers < none < raises, position key, new value).  Packed with the scores
 // into one 64-bit key per candidate; the last kernel takes the minimum (key, index).
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -1668,17 +1670,17 @@ __global__ __launch_bounds__(256) void sched_exhaustive_moves_kernel(const int *
 // no state, so there is nothing to apply or re-upload.  Workgroup 0 owns the host mailbox: it copies the four lines, tags and
 // all, to a device-side "go" record, which every workgroup polls in ONE 64-lane load and accepts when all tags agree (the same
 // torn-snapshot rule as over PCIe: no fence, no cache write-back between the XCDs' L2s -- the first version released and
-// acquired at agent scope and an LS iteration took 60 us).  Every workgroup scores its chunk (sched_eval_all_kernel's body),
-// records count and minimum with write-through stores and takes a ticket; the last one finishes: prefix over the counts,
-// minima of the chunks inside the window, and the chunk the window cuts is scored AGAIN by the finisher up to the window
-// (cheaper than 512 write-through key stores in every workgroup plus their acknowledgement on the critical path).
+// acquired at agent scope and an LS iteration took 60 us).  Every workgroup scores its chunk (sched_eval_all_kernel's body) and
+// writes ONE record -- eight dwords, each tagged with the request's tag: count, minimum key, its index -- with a single
+// write-through store instruction; workgroup 0, the finisher, polls the records until all carry the tag (no acknowledgement
+// wait and no ticket in the workers), takes the prefix over the counts and the minima of the chunks inside the window, and
+// scores the chunk the window cuts AGAIN up to the window (cheaper than 512 key stores in every workgroup).
 // All workgroups must be resident at once: the launcher asks for at most two per CU.
 constexpr int SCG_STATE_AT = 16; // dword of the message that holds state[0]: the state fits lines 1..3 (S <= 48)
 
 struct SchedGridCtl {        // device memory
     unsigned go[64];         // the current request, as the host wrote it (tagged dwords)
-    unsigned ticket;         // workgroups that have recorded their chunk of the current request
-    unsigned pad;
+    unsigned pad[2];
     unsigned long long ready; // workgroups that have started, over all launches of this server
 };
 
@@ -1689,7 +1691,7 @@ struct SchedGridArgs {
     long long n_resident;
     SchedGridCtl *g;
     unsigned long long ready_target; // g->ready once every workgroup of THIS launch has started (the host adds the grid size per launch)
-    u64 *part_key; long long *part_idx; int *chunk_counts; // [n_chunks] each
+    unsigned *rec;           // [n_chunks][8] every workgroup's record of the current request (tagged dwords)
 };
 
 template <typename M, int NW>
@@ -1704,16 +1706,25 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
     __shared__ long long s_idx[NW];
     __shared__ int s_cnt[NW];
     __shared__ unsigned s_req[64];
-    __shared__ int s_ctl[2]; // [0] leave, [1] last (this workgroup runs the finish step)
+    __shared__ int s_ctl[2]; // [0] leave, [1] the request's tag
     __shared__ int s_cut;
     __shared__ long long s_before;
     SchedLaneConst L{};
     if (wib < 3) L = a.in.lane_tab[lane];
+    // (Keeping the instance's holiday words in LDS -- 80 KB at 10 000 employees -- instead of gathering them from L2 per request was
+    // tried: no change, 5.5 us from request to record either way; the workgroup's time is the delta scorer's dependent chain.)
+    const SchedInst &in = a.in;
     const long long k = (long long)c * (64 * NW) + tid; // this lane's move of the resident stream: loaded once
     int mtype = -1, mma = 0, mmb = 0;
     if (k < a.n_resident) { const ls_sched_move m = a.moves[k]; mtype = m.type; mma = m.a; mmb = m.b; }
     unsigned last_seq = 0;
     SrvPoll poll{0, 0, 0};
+#ifdef LS_NQ_STAMPS
+    unsigned long long gst[6] = {0, 0, 0, 0, 0, 0}; // workgroup 0: request seen, go record out, own chunk recorded, all records in, cut chunk scored, answer
+#define SCG_STAMP(I) do { if (c == 0) gst[I] = wall_clock64(); } while (0)
+#else
+#define SCG_STAMP(I) do { } while (0)
+#endif
     if (wib == 0) {
         last_seq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.g->go[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16);
         if (c == 0) srv_poll_begin(poll, a.link, a.link.resp, lane);
@@ -1736,8 +1747,11 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
             if (c == 0) { // the master: host mailbox -> go record, verbatim
                 unsigned raw = 0;
                 leave = srv_poll_wait<64>(poll, a.link, a.link.req, s_req, lane, &raw);
-                if (!leave) __hip_atomic_store(&a.g->go[lane], raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else if (lane == 0) __hip_atomic_store(&a.link.ctl->quit_gen, a.link.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // tell the others
+                SCG_STAMP(0);
+                if (!leave) {
+                    __hip_atomic_store(&a.g->go[lane], raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    SCG_STAMP(1);
+                } else if (lane == 0) __hip_atomic_store(&a.link.ctl->quit_gen, a.link.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // tell the others
                 last_seq = poll.last_tag;
             } else {
                 for (;;) { // one 64-lane snapshot of the go record per poll; valid when all tags agree and the tag is new
@@ -1754,19 +1768,20 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
-            if (lane == 0) s_ctl[0] = leave;
+            if (lane == 0) { s_ctl[0] = leave; s_ctl[1] = (int)last_seq; }
         }
         __syncthreads();
         if (s_ctl[0]) break;
+        const unsigned last_seq_all = (unsigned)s_ctl[1]; // the request's tag, in every wavefront
         long long nm = (long long)(s_req[1] | (s_req[2] << 16));
         nm = nm < a.n_resident ? nm : a.n_resident;
         const long long window = (long long)(s_req[3] | (s_req[4] << 16));
         const int e_lane = lane < S ? (int)s_req[SCG_STATE_AT + lane] : -1 - lane;
-        const int hol_base = wib == 0 ? sched_holiday_bit(a.in, e_lane, lane) : 0;
+        const int hol_base = wib == 0 ? sched_holiday_bit(in, e_lane, lane) : 0;
         // ---- this workgroup's chunk (sched_eval_all_kernel with one batch per wavefront, keys not recorded)
         const SchedEdit ed = sched_edit_of(e_lane, S, E, k < nm ? mtype : -1, mma, mmb);
-        const int hbits = sched_edit_hbits(a.in, ed);
-        if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T);
+        const int hbits = sched_edit_hbits(in, ed);
+        if (wib < 3) sched_build_base_tab<M>(in, wib, e_lane, hol_base, L, lane, T);
         __syncthreads();
         u64 best_key = SC_KEY_EMPTY;
         long long best_idx = -1;
@@ -1778,52 +1793,63 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         }
         cnt = wave_sum_i32(cnt);
         if (lane == 0) s_cnt[wib] = cnt;
-        sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib); // synchronises the block
-        if (tid == 0) {
+        sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib); // synchronises the block; valid in wavefront 0
+        // ---- this chunk's record: eight tagged dwords (count | key in four 16-bit pieces | index in two), ONE store by eight lanes,
+        // no acknowledgement wait and no ticket: workgroup 0 -- the finisher, always -- polls the records until all carry the tag
+        if (wib == 0) {
             int total = 0;
             for (int i = 0; i < NW; i++) total += s_cnt[i];
-            __hip_atomic_store(a.part_key + c, best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.part_idx + c, best_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.chunk_counts + c, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the record's write-through stores are acknowledged before the ticket
-            const unsigned t = __hip_atomic_fetch_add(&a.g->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_ctl[1] = t == (unsigned)nch - 1;
-            if (s_ctl[1]) __hip_atomic_store(&a.g->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_cut = -1; s_before = 0;
+            unsigned pay = 0;
+            if (lane == 0) pay = (unsigned)total;
+            else if (lane <= 4) pay = (unsigned)(best_key >> (16 * (lane - 1))) & 0xffffu;
+            else if (lane == 5) pay = (unsigned)best_idx & 0xffffu;
+            else if (lane == 6) pay = (unsigned)(best_idx >> 16) & 0xffffu;
+            if (lane < 8) __hip_atomic_store(a.rec + (size_t)c * 8 + lane, (last_seq << 16) | pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (tid == 0) { s_cut = -1; s_before = 0; }
         __syncthreads();
-        if (s_ctl[1]) { // ---- the finish step (sched_finish_block on agent-scope loads; the cut chunk is scored again)
+        SCG_STAMP(2);
+        if (c == 0) { // ---- the finish step: prefix over the counts, minima of the chunks inside the window, the cut chunk scored again
             u64 fkey = SC_KEY_EMPTY;
             long long fidx = -1, run = 0;
-            if (window > 0) {
-                for (int t0 = 0; t0 < nch; t0 += 64 * NW) {
-                    const int b = t0 + tid;
-                    // the chunk's count, minimum and index are fetched together (three independent agent-scope loads in flight)
-                    const int cb = b < nch ? __hip_atomic_load(a.chunk_counts + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                    const u64 pkb = b < nch ? __hip_atomic_load(a.part_key + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SC_KEY_EMPTY;
-                    const long long pib = b < nch ? __hip_atomic_load(a.part_idx + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-                    int incl = cb;
+            // every workgroup's record of THIS request (nch <= 64 NW: one record per thread)
+            unsigned rv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (;;) {
+                bool ok = true;
+                if (tid < nch) {
 #pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const int o = __shfl_up(incl, off, 64);
-                        if (lane >= off) incl += o;
-                    }
-                    if (lane == 63) s_cnt[wib] = incl;
-                    __syncthreads();
-                    int before = 0, total = 0;
-                    for (int i = 0; i < NW; i++) {
-                        if (i < wib) before += s_cnt[i];
-                        total += s_cnt[i];
-                    }
-                    const long long through = run + before + incl; // real candidates up to and including chunk b
-                    if (b < nch) {
-                        if (through <= window) sched_min_key(fkey, fidx, pkb, pib);
-                        else if (through - cb < window) { s_cut = b; s_before = through - cb; }
-                    }
-                    __syncthreads();
-                    run += total;
-                    if (run >= window) break;
+                    for (int d = 0; d < 8; d++) rv[d] = __hip_atomic_load(a.rec + (size_t)tid * 8 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int d = 0; d < 7; d++) ok = ok && (rv[d] >> 16) == last_seq_all;
                 }
+                if (__syncthreads_and(ok ? 1 : 0)) break;
+            }
+            SCG_STAMP(3);
+            if (window > 0) {
+                const int b = tid;
+                const int cb = b < nch ? (int)(rv[0] & 0xffffu) : 0;
+                const u64 pkb = b < nch ? ((u64)(rv[1] & 0xffffu) | ((u64)(rv[2] & 0xffffu) << 16) | ((u64)(rv[3] & 0xffffu) << 32) | ((u64)(rv[4] & 0xffffu) << 48)) : SC_KEY_EMPTY;
+                const long long pib = b < nch ? (long long)((rv[5] & 0xffffu) | ((rv[6] & 0xffffu) << 16)) : -1;
+                int incl = cb;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += o;
+                }
+                if (lane == 63) s_cnt[wib] = incl;
+                __syncthreads();
+                int before = 0, total = 0;
+                for (int i = 0; i < NW; i++) {
+                    if (i < wib) before += s_cnt[i];
+                    total += s_cnt[i];
+                }
+                const long long through = before + incl; // real candidates up to and including chunk b
+                if (b < nch && cb > 0) {
+                    if (through <= window) sched_min_key(fkey, fidx, pkb, pib);
+                    else if (through - cb < window) { s_cut = b; s_before = through - cb; }
+                }
+                __syncthreads();
+                run = total;
             }
             const long long n_scored = window <= 0 ? 0 : (run < window ? run : window);
             const int cut = s_cut;
@@ -1833,7 +1859,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                 int ty = -1, xa = 0, xb = 0;
                 if (kk < nm) { const ls_sched_move m = a.moves[kk]; ty = m.type; xa = m.a; xb = m.b; }
                 const SchedEdit e2 = sched_edit_of(e_lane, S, E, ty, xa, xb);
-                const int hb2 = sched_edit_hbits(a.in, e2);
+                const int hb2 = sched_edit_hbits(in, e2);
                 const u64 bal = __ballot(e2.active);
                 __syncthreads(); // s_cnt is reused
                 if (lane == 0) s_cnt[wib] = __popcll(bal);
@@ -1848,6 +1874,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                     if (key2 < fkey) { fkey = key2; fidx = kk; }
                 }
             }
+            SCG_STAMP(4);
             sched_block_min_key<NW>(fkey, fidx, s_key, s_idx, lane, wib);
             if (wib == 0) { // the answer: d0 has-move, d1-2 n_scored, d3-4 best_index, d5 hard, d6 soft
                 const bool has = fkey != SC_KEY_EMPTY;
@@ -1859,6 +1886,11 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                 else if (lane == 4) pay = has ? (unsigned)(fidx >> 16) : 0u;
                 else if (lane == 5) pay = has ? (unsigned)(fkey >> 54) : 0u;
                 else if (lane == 6) pay = has ? (unsigned)((fkey >> 46) & 0xffu) : 0u;
+#ifdef LS_NQ_STAMPS
+                gst[5] = wall_clock64();
+                if (lane >= 8 && lane < 13) { const unsigned long long dt = gst[lane - 7] - gst[0]; pay = dt > 0xffffu ? 0xffffu : (unsigned)dt; }
+                if (lane >= 8 && lane < 13) __hip_atomic_store(a.link.resp + lane, (last_seq << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
                 if (lane < 8) __hip_atomic_store(a.link.resp + lane, (last_seq << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (lane == 0) __hip_atomic_store(&a.link.ctl->last_activity, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -2107,9 +2139,11 @@ struct SchedServer {
     SrvHost grid;
     bool grid_ready = false;
     SchedGridCtl *g = nullptr;
-    DevBuf ws;               // part_key | part_idx | chunk_counts
+    DevBuf ws;               // the chunk records [n_chunks][8]
     unsigned long long ready_total = 0;
     unsigned long long grid_requests = 0;
+    double t_wait = 0, t_call = 0;               // LS_AMD_TRACE
+    unsigned long long dev_ticks[5] = {0, 0, 0, 0, 0}; // stamps builds: the finisher's timeline
 };
 
 bool sched_server_eligible(const ls_ctx *ctx, long long n_moves)
@@ -2150,6 +2184,14 @@ void sched_server_destroy(ls_ctx *ctx)
 {
     SchedServer *s = ctx->sched_server;
     if (!s) return;
+    if (getenv("LS_AMD_TRACE") && s->grid_requests) {
+        fprintf(stderr, "scheduling grid: %llu requests, answer wait %.2f us per request (whole call %.2f us), %llu launches\n", s->grid_requests,
+                s->t_wait / s->grid_requests * 1e6, s->t_call / s->grid_requests * 1e6, s->grid.relaunches.load());
+        if (s->dev_ticks[4])
+            fprintf(stderr, "  workgroup 0, after the request was seen: go record out %.2f us, own chunk recorded %.2f, all records in %.2f, cut chunk scored %.2f, "
+                            "answer %.2f\n", s->dev_ticks[0] * 0.01 / s->grid_requests, s->dev_ticks[1] * 0.01 / s->grid_requests,
+                    s->dev_ticks[2] * 0.01 / s->grid_requests, s->dev_ticks[3] * 0.01 / s->grid_requests, s->dev_ticks[4] * 0.01 / s->grid_requests);
+    }
     s->h.shutdown();
     s->grid.shutdown();
     if (s->g) (void)hipFree(s->g);
@@ -2274,11 +2316,18 @@ bool sched_grid_eligible(const ls_ctx *ctx, long long n_moves)
     // every workgroup must be resident at once: at most two 512-thread workgroups per CU are asked for (the kernel fits four)
     return ctx->sched_server_on && ctx->sched_delta && ctx->sched.valid && n_moves > 64 * SCS_NW && n_moves <= ctx->sc_resident_n &&
            ctx->sched.n_employees <= 32768 && ctx->sched.n_days_stored <= 64 - SCG_STATE_AT && n_moves < (1ll << 31) &&
-           sched_grid_chunks(ctx) <= 2ll * ctx->n_cus;
+           sched_grid_chunks(ctx) <= 2ll * ctx->n_cus &&  // co-residency: at most two workgroups per CU are asked for
+           sched_grid_chunks(ctx) <= 64 * SCS_NW;          // one record per finisher thread
 }
 
 int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out)
 {
+    static const bool trace_call = getenv("LS_AMD_TRACE") != nullptr;
+    const auto TC0 = trace_call ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    struct CallTimer {
+        ls_ctx *c; std::chrono::steady_clock::time_point t0; bool on;
+        ~CallTimer() { if (on && c->sched_server) c->sched_server->t_call += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    } call_timer{ctx, TC0, trace_call};
     SchedServer *s = ctx->sched_server;
     if (!s) {
         s = new (std::nothrow) SchedServer();
@@ -2308,9 +2357,7 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
             a.g = s->g;
             s->ready_total += (unsigned long long)n;
             a.ready_target = s->ready_total;
-            a.part_key = s->ws.as<u64>();
-            a.part_idx = reinterpret_cast<long long *>(a.part_key + n);
-            a.chunk_counts = reinterpret_cast<int *>(a.part_idx + n);
+            a.rec = s->ws.as<unsigned>();
             void *args[] = {&a};
             const bool m32 = ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64;
             const void *fn = m32 ? reinterpret_cast<const void *>(&sched_grid_server_kernel<unsigned, SCS_NW>)
@@ -2319,12 +2366,16 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
         };
     }
     {   // workspaces for the current resident list (they only change while the launch is paused: sched_server_pause)
-        const size_t need = align256((size_t)nch * 20);
+        const size_t need = align256((size_t)nch * 32);
         if (need > s->ws.cap) {
             sched_server_pause(ctx); // nothing resident may still use the old block
             LS_HIP(ctx, hipSetDevice(ctx->device));
             LS_RESERVE(ctx, s->ws, need);
             s->ws.collect();
+            // tag 0 everywhere: an uninitialised record must not look like an answer to the current request
+            hipLaunchKernelGGL(fill_i32_kernel, dim3(8), dim3(256), 0, s->grid.stream, s->ws.as<int>(), 0, (long long)(s->ws.cap / 4));
+            LS_HIP(ctx, hipGetLastError());
+            LS_HIP(ctx, hipStreamSynchronize(s->grid.stream));
         }
     }
     // the request: ONE message of four lines -- header dwords 0..15, the state from dword 16 on -- every dword with the same
@@ -2341,9 +2392,16 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
         for (int d = 63; d >= 0; d--) dst[d] = (tag << 16) | pay[d];
         s->grid_requests++;
     }
+    static const bool trace = getenv("LS_AMD_TRACE") != nullptr;
+    const auto T1 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     unsigned r[8];
     const int rc = s->grid.wait(ctx, 0, r);
     if (rc != LS_OK) return rc;
+    if (trace) {
+        s->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - T1).count();
+        const volatile unsigned *rl = s->grid.resp(0);
+        for (int d = 0; d < 5; d++) s->dev_ticks[d] += (rl[8 + d] >> 16) == s->grid.tags[0] ? rl[8 + d] & 0xffffu : 0u;
+    }
     if (!(r[0] & 1u)) { out->n_scored = 0; out->best_index = -1; out->best_hard = 0; out->best_soft = 0; }
     else {
         out->n_scored = (long long)(r[1] | (r[2] << 16));

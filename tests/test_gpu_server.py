@@ -158,6 +158,70 @@ def test_two_contexts_two_servers_interleaved():
         assert a.counters()["server_requests"] >= 20 and b.counters()["server_requests"] >= 20
 
 
+def test_server_route_argument_errors_leave_the_slot_usable():
+    # the board of a one-restart call is range-checked where it is compared with the slot's shadow; a bad call must fail with the
+    # reference's own failure mode translated (an error code, not a panic) and leave the slot consistent for the next call
+    import ls_amd
+    rng = np.random.default_rng(11)
+    n = 600
+    with ls_amd.Context(0) as c:
+        rows = _board(rng, n, "uniform")
+        rows = _step(c, rows, rng.permutation(n)[:6], 5 * n)
+        bad = rows.copy()
+        bad[17] = n                                              # outside [0, n)
+        with pytest.raises(ls_amd.LsError) as ei:
+            c.nqueens_eval_batch_next(bad.reshape(1, -1), [0], np.arange(3).reshape(1, -1), [3], 5 * n)
+        assert ei.value.code == ls_amd._lib.LS_ERR_INVALID and "rows[17]" in str(ei.value)
+        with pytest.raises(ls_amd.LsError):
+            c.nqueens_eval_batch_next(rows.reshape(1, -1), [0], np.array([[1, n]]), [2], 5 * n)   # a column outside [0, n)
+        for _ in range(5):                                       # the slot still holds the last good board
+            rows = _step(c, rows, rng.permutation(n)[:6], 5 * n)
+        assert c.counters()["server_boards_uploaded"] == 1       # the rejected board never reached the shadow
+
+
+def test_servers_of_two_contexts_on_two_threads():
+    import threading
+    import ls_amd
+    errs = []
+
+    def work(seed, n):
+        try:
+            rng = np.random.default_rng(seed)
+            with ls_amd.Context(0) as c:
+                rows = _board(rng, n, "uniform")
+                for it in range(60):
+                    rows = _step(c, rows, rng.permutation(n)[:8][:int(rng.integers(1, 9))], 5 * n)
+                    if it % 17 == 16:
+                        rows = _board(rng, n, "perm")
+                assert c.counters()["server_requests"] == 60
+        except BaseException as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(s, n)) for s, n in ((1, 1024), (2, 4096), (3, 333))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+
+
+def test_multi_solver_more_slots_than_one_server_launch_holds():
+    # n_slots beyond what one resident launch holds (240): the slots fall back to one launch per call; results unchanged
+    import ls_amd
+    n, rounds = 24, 3
+    seeds = [str(s) for s in range(1000, 1000 + 250)]
+    p = _nq_params(n)
+    with ls_amd.Context(0) as c:
+        singles, iters = _single_runs(c, n, seeds[:12], p, rounds)
+        for slots in (250, 240):
+            m = ls_amd.MultiSolver(c, n, seeds, p, n_slots=slots, mode="free")
+            m.run(max_rounds_per_restart=rounds)
+            assert [m.best(r) for r in range(12)] == singles
+            assert [m.restart_stats(r)["ls_iterations"] for r in range(12)] == iters
+            assert (m.counters()["server_requests"] > 0) == (slots <= 240)
+            m.close()
+
+
 def _nq_params(n, expiry=10_000):
     p = dict(lo.NQUEENS_MAIN_PARAMS)
     p["window_size"] = 5 * n
