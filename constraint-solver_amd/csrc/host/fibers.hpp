@@ -17,10 +17,7 @@
 //
 // Switching is a dozen instructions (callee-saved registers + stack pointer; no signal-mask system call as in
 // swapcontext), stacks are mmap'ed with a guard page below them (an overflow faults instead of corrupting the heap) and as
-// large as a thread's (8 MB, committed lazily): a fibre calls into the HIP runtime, and with rocprofv3's tool library
-// interposed a kernel launch needs more than the 1 MB round 2 gave it -- that, not the profiler, was why the profiled
-// end-to-end run died (profiles/r03_rocprofv3_e2e_fibre_stack_overflow.stderr.txt: SIGSEGV at a page boundary under
-// hipLaunchKernel, called from a fibre).
+// large as a thread's (8 MB, committed lazily): a fibre calls into the HIP runtime, whose stack needs are not ours to bound.
 // A fibre only ever switches inside FiberPool::yield(), never inside a runtime call; after a switch it may be on another
 // thread, so nothing thread-local is cached across yield() (current_worker() is re-read, noinline).
 #pragma once
@@ -132,11 +129,13 @@ public:
 
 private:
     enum : int { SUSPENDED = 0, RUNNING = 1, DONE = 2 };
+    enum : unsigned { STALL_SPINS = 256 }; // scans of a worker's fibres with none ready (~20 us) before one is resumed anyway
     struct alignas(64) Fiber {
         std::atomic<int> state{SUSPENDED};
         std::atomic<uint64_t> priority{0};
         FiberWait wait;              // written by the fibre before it yields, read by workers while it is SUSPENDED
         int last_worker = 0;
+        uint64_t last_forced = 0;    // when it was last resumed without its answer (the worker's count)
         std::function<void()> fn;
         char *stack_base = nullptr;
         size_t stack_len = 0;
@@ -154,6 +153,7 @@ private:
         void acquire() { while (lock.test_and_set(std::memory_order_acquire)) { __builtin_ia32_pause(); } }
         void release() { lock.clear(std::memory_order_release); }
         Fiber *current = nullptr;    // the fibre this worker is running
+        uint64_t forced = 0;         // fibres resumed without their answer
 #if defined(__x86_64__)
         FiberRegs main{nullptr};
 #else
@@ -224,17 +224,24 @@ private:
     }
 
     // The fibre this worker runs next: one of its own, suspended, whose awaited answer has arrived; highest priority first.
-    Fiber *pick_mine(Worker &w)
+    // any_one: the worker has had nothing ready for a while -- the suspended fibre that has waited longest is resumed to look
+    // for itself (an answer may never arrive unless the waiter acts: SrvHost::wait launches a drained server again).
+    Fiber *pick_mine(Worker &w, bool any_one = false)
     {
         Fiber *best = nullptr;
         uint64_t best_p = 0;
         w.acquire();
         for (Fiber *f : w.mine) {
             if (f->state.load(std::memory_order_acquire) != SUSPENDED) continue;
+            if (any_one) {
+                if (!best || f->last_forced < best->last_forced) best = f;
+                continue;
+            }
             if (f->wait.words && !f->wait.ready()) continue;
             const uint64_t p = f->priority.load(std::memory_order_relaxed);
             if (!best || p > best_p) { best = f; best_p = p; }
         }
+        if (best && any_one) best->last_forced = ++w.forced;
         if (best) best->state.store(RUNNING, std::memory_order_relaxed); // under the lock: a thief cannot take it any more
         w.release();
         return best;
@@ -269,6 +276,7 @@ private:
         }
         v.release();
         if (!best) return nullptr;
+        best->last_forced = 0;
         Worker &w = *workers_[(size_t)self];
         w.acquire();
         w.mine.push_back(best);
@@ -282,9 +290,10 @@ private:
     {
         Worker &w = *workers_[(size_t)self];
         set_current_worker(&w);
-        unsigned idle = 0;
+        unsigned idle = 0, stalled = 0;
         for (;;) {
             Fiber *f = pick_mine(w);
+            if (!f && w.n_mine.load(std::memory_order_relaxed) != 0 && ++stalled >= STALL_SPINS) f = pick_mine(w, true);
             if (!f) {
                 if (w.n_mine.load(std::memory_order_relaxed) == 0) {
                     if (live_.load(std::memory_order_acquire) == 0) break;
@@ -298,7 +307,7 @@ private:
                 }
                 continue;
             }
-            idle = 0;
+            idle = 0; stalled = 0;
             w.current = f;
             switch_to(w.main, f->regs);
             w.current = nullptr;

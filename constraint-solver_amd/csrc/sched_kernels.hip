@@ -1720,8 +1720,8 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
     unsigned last_seq = 0;
     SrvPoll poll{0, 0, 0};
 #ifdef LS_NQ_STAMPS
-    unsigned long long gst[6] = {0, 0, 0, 0, 0, 0}; // workgroup 0: request seen, go record out, own chunk recorded, all records in, cut chunk scored, answer
-#define SCG_STAMP(I) do { if (c == 0) gst[I] = wall_clock64(); } while (0)
+    unsigned long long gst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // workgroup 0: request seen, go record out, edit + holiday bits in, table built, chunk scored, own chunk recorded, all records in, cut chunk scored, answer
+#define SCG_STAMP(I) do { gst[I] = wall_clock64(); } while (0)
 #else
 #define SCG_STAMP(I) do { } while (0)
 #endif
@@ -1760,6 +1760,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                     if (t0 != last_seq && t0 != 0 && __builtin_amdgcn_ballot_w64((v >> 16) != t0) == 0) {
                         s_req[lane] = v & 0xffffu;
                         last_seq = t0;
+                        SCG_STAMP(0);
                         break;
                     }
                     unsigned long long q = 0;
@@ -1776,13 +1777,18 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         long long nm = (long long)(s_req[1] | (s_req[2] << 16));
         nm = nm < a.n_resident ? nm : a.n_resident;
         const long long window = (long long)(s_req[3] | (s_req[4] << 16));
+        const int fin = (int)s_req[5] < nch ? (int)s_req[5] : 0; // the finisher of THIS request: the chunk the host expects the window to cut
         const int e_lane = lane < S ? (int)s_req[SCG_STATE_AT + lane] : -1 - lane;
         const int hol_base = wib == 0 ? sched_holiday_bit(in, e_lane, lane) : 0;
         // ---- this workgroup's chunk (sched_eval_all_kernel with one batch per wavefront, keys not recorded)
         const SchedEdit ed = sched_edit_of(e_lane, S, E, k < nm ? mtype : -1, mma, mmb);
         const int hbits = sched_edit_hbits(in, ed);
+#ifdef LS_NQ_STAMPS
+        { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); gst[2] = wall_clock64(); }
+#endif
         if (wib < 3) sched_build_base_tab<M>(in, wib, e_lane, hol_base, L, lane, T);
         __syncthreads();
+        SCG_STAMP(3);
         u64 best_key = SC_KEY_EMPTY;
         long long best_idx = -1;
         int cnt = 0;
@@ -1791,11 +1797,17 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
             best_key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft);
             best_idx = k; cnt = 1;
         }
-        cnt = wave_sum_i32(cnt);
+        SCG_STAMP(4);
+        const u64 my_key = best_key; // this lane's own candidate: what the finisher needs if the window cuts ITS chunk
+        const u64 my_bal = __ballot(ed.active);
+        cnt = __popcll(my_bal);
         if (lane == 0) s_cnt[wib] = cnt;
         sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib); // synchronises the block; valid in wavefront 0
+        int my_rank = __popcll(my_bal & ((2ull << lane) - 1)); // 1-based among the chunk's real candidates
+        for (int i = 0; i < NW; i++)
+            if (i < wib) my_rank += s_cnt[i];
         // ---- this chunk's record: eight tagged dwords (count | key in four 16-bit pieces | index in two), ONE store by eight lanes,
-        // no acknowledgement wait and no ticket: workgroup 0 -- the finisher, always -- polls the records until all carry the tag
+        // no acknowledgement wait and no ticket: the request's finisher polls the records until all carry the tag
         if (wib == 0) {
             int total = 0;
             for (int i = 0; i < NW; i++) total += s_cnt[i];
@@ -1808,8 +1820,8 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         }
         if (tid == 0) { s_cut = -1; s_before = 0; }
         __syncthreads();
-        SCG_STAMP(2);
-        if (c == 0) { // ---- the finish step: prefix over the counts, minima of the chunks inside the window, the cut chunk scored again
+        SCG_STAMP(5);
+        if (c == fin) { // ---- the finish step: prefix over the counts, minima of the chunks inside the window, the cut chunk up to the window
             u64 fkey = SC_KEY_EMPTY;
             long long fidx = -1, run = 0;
             // every workgroup's record of THIS request (nch <= 64 NW: one record per thread)
@@ -1824,7 +1836,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                 }
                 if (__syncthreads_and(ok ? 1 : 0)) break;
             }
-            SCG_STAMP(3);
+            SCG_STAMP(6);
             if (window > 0) {
                 const int b = tid;
                 const int cb = b < nch ? (int)(rv[0] & 0xffffu) : 0;
@@ -1853,7 +1865,10 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
             }
             const long long n_scored = window <= 0 ? 0 : (run < window ? run : window);
             const int cut = s_cut;
-            if (cut >= 0) { // the chunk the window cuts: scored again here (same state, same table), up to the window
+            if (cut == c) { // the window cuts the finisher's own chunk, as the host expected: the keys are still in the lanes
+                const long long need = window - s_before;
+                if (ed.active && my_rank <= need && my_key < fkey) { fkey = my_key; fidx = k; }
+            } else if (cut >= 0) { // another chunk: scored again here (same state, same table), up to the window
                 const long long need = window - s_before;
                 const long long kk = (long long)cut * (64 * NW) + tid;
                 int ty = -1, xa = 0, xb = 0;
@@ -1874,9 +1889,9 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                     if (key2 < fkey) { fkey = key2; fidx = kk; }
                 }
             }
-            SCG_STAMP(4);
+            SCG_STAMP(7);
             sched_block_min_key<NW>(fkey, fidx, s_key, s_idx, lane, wib);
-            if (wib == 0) { // the answer: d0 has-move, d1-2 n_scored, d3-4 best_index, d5 hard, d6 soft
+            if (wib == 0) { // the answer: d0 has-move, d1-2 n_scored, d3-4 best_index, d5 hard, d6 soft, d7 the cut chunk + 1 (0: none)
                 const bool has = fkey != SC_KEY_EMPTY;
                 unsigned pay = 0;
                 if (lane == 0) pay = has ? 1u : 0u;
@@ -1886,10 +1901,11 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                 else if (lane == 4) pay = has ? (unsigned)(fidx >> 16) : 0u;
                 else if (lane == 5) pay = has ? (unsigned)(fkey >> 54) : 0u;
                 else if (lane == 6) pay = has ? (unsigned)((fkey >> 46) & 0xffu) : 0u;
+                else if (lane == 7) pay = (unsigned)(cut + 1);
 #ifdef LS_NQ_STAMPS
-                gst[5] = wall_clock64();
-                if (lane >= 8 && lane < 13) { const unsigned long long dt = gst[lane - 7] - gst[0]; pay = dt > 0xffffu ? 0xffffu : (unsigned)dt; }
-                if (lane >= 8 && lane < 13) __hip_atomic_store(a.link.resp + lane, (last_seq << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                gst[8] = wall_clock64();
+                if (lane >= 8 && lane < 16) { const unsigned long long dt = gst[lane - 7] - gst[0]; pay = dt > 0xffffu ? 0xffffu : (unsigned)dt; }
+                if (lane >= 8 && lane < 16) __hip_atomic_store(a.link.resp + lane, (last_seq << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
                 if (lane < 8) __hip_atomic_store(a.link.resp + lane, (last_seq << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (lane == 0) __hip_atomic_store(&a.link.ctl->last_activity, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2143,7 +2159,9 @@ struct SchedServer {
     unsigned long long ready_total = 0;
     unsigned long long grid_requests = 0;
     double t_wait = 0, t_call = 0;               // LS_AMD_TRACE
-    unsigned long long dev_ticks[5] = {0, 0, 0, 0, 0}; // stamps builds: the finisher's timeline
+    unsigned long long dev_ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // stamps builds: the finisher's timeline
+    int grid_fin = 0;                     // the chunk the window cut in the last answer: the next request's finisher
+    unsigned long long grid_fin_hits = 0; // requests whose window cut the finisher's own chunk
 };
 
 bool sched_server_eligible(const ls_ctx *ctx, long long n_moves)
@@ -2185,12 +2203,14 @@ void sched_server_destroy(ls_ctx *ctx)
     SchedServer *s = ctx->sched_server;
     if (!s) return;
     if (getenv("LS_AMD_TRACE") && s->grid_requests) {
-        fprintf(stderr, "scheduling grid: %llu requests, answer wait %.2f us per request (whole call %.2f us), %llu launches\n", s->grid_requests,
-                s->t_wait / s->grid_requests * 1e6, s->t_call / s->grid_requests * 1e6, s->grid.relaunches.load());
+        fprintf(stderr, "scheduling grid: %llu requests, answer wait %.2f us per request (whole call %.2f us), %llu launches, the window cut the finisher's chunk in %llu\n",
+                s->grid_requests, s->t_wait / s->grid_requests * 1e6, s->t_call / s->grid_requests * 1e6, s->grid.relaunches.load(), s->grid_fin_hits);
         if (s->dev_ticks[4])
-            fprintf(stderr, "  workgroup 0, after the request was seen: go record out %.2f us, own chunk recorded %.2f, all records in %.2f, cut chunk scored %.2f, "
-                            "answer %.2f\n", s->dev_ticks[0] * 0.01 / s->grid_requests, s->dev_ticks[1] * 0.01 / s->grid_requests,
-                    s->dev_ticks[2] * 0.01 / s->grid_requests, s->dev_ticks[3] * 0.01 / s->grid_requests, s->dev_ticks[4] * 0.01 / s->grid_requests);
+            fprintf(stderr, "  the finisher, after it saw the request: go record out (workgroup 0 only) %.2f us, edit + holiday bits in %.2f, table built %.2f, chunk scored %.2f, "
+                            "own chunk recorded %.2f, all records in %.2f, cut chunk scored %.2f, answer %.2f\n", s->dev_ticks[0] * 0.01 / s->grid_requests,
+                    s->dev_ticks[1] * 0.01 / s->grid_requests, s->dev_ticks[2] * 0.01 / s->grid_requests, s->dev_ticks[3] * 0.01 / s->grid_requests,
+                    s->dev_ticks[4] * 0.01 / s->grid_requests, s->dev_ticks[5] * 0.01 / s->grid_requests, s->dev_ticks[6] * 0.01 / s->grid_requests,
+                    s->dev_ticks[7] * 0.01 / s->grid_requests);
     }
     s->h.shutdown();
     s->grid.shutdown();
@@ -2387,6 +2407,7 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
         const unsigned w = (unsigned)(window > 0x7fffffffll ? 0x7fffffffll : window);
         unsigned pay[64] = {0};
         pay[0] = SCS_F_EVAL; pay[1] = (unsigned)n_moves & 0xffffu; pay[2] = (unsigned)n_moves >> 16; pay[3] = w & 0xffffu; pay[4] = w >> 16;
+        pay[5] = (unsigned)s->grid_fin; // the finisher: the chunk the window cut last time (its lanes still hold the keys the cut needs)
         for (int d = 0; d < S; d++) pay[SCG_STATE_AT + d] = (unsigned)state[d] & 0xffffu;
         volatile unsigned *dst = s->grid.req(0);
         for (int d = 63; d >= 0; d--) dst[d] = (tag << 16) | pay[d];
@@ -2400,7 +2421,11 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
     if (trace) {
         s->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - T1).count();
         const volatile unsigned *rl = s->grid.resp(0);
-        for (int d = 0; d < 5; d++) s->dev_ticks[d] += (rl[8 + d] >> 16) == s->grid.tags[0] ? rl[8 + d] & 0xffffu : 0u;
+        for (int d = 0; d < 8; d++) s->dev_ticks[d] += (rl[8 + d] >> 16) == s->grid.tags[0] ? rl[8 + d] & 0xffffu : 0u;
+    }
+    if (r[7] != 0) {
+        if ((int)r[7] - 1 == s->grid_fin) s->grid_fin_hits++;
+        s->grid_fin = (int)r[7] - 1;
     }
     if (!(r[0] & 1u)) { out->n_scored = 0; out->best_index = -1; out->best_hard = 0; out->best_soft = 0; }
     else {

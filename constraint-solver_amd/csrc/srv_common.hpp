@@ -263,7 +263,7 @@ struct SrvHost {
             else __builtin_ia32_pause();
 #endif
             if (ctx->yield_while_waiting && spins >= 64) sched_yield();
-            if ((spins & 15u) == 15u) {
+            if ((spins & 15u) == 15u || ctx->wait_hook) { // behind a hook every return here may have been a long absence
                 // has the launch drained under the request (idle time-out, age limit)?  Then it is launched again and finds the request.
                 if (drained()) {
                     slow_waits.fetch_add(1, std::memory_order_relaxed);

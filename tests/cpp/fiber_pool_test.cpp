@@ -121,6 +121,25 @@ int main()
         pool.run();
         if (order != std::vector<int>({0, 0, 2, 3, 1, 0})) { for (int x : order) printf("%d ", x); return fail("priority / readiness order"); }
     }
+    // an answer that only arrives once the waiter acts (a drained server is launched again by the waiter, srv_common.hpp
+    // SrvHost::wait): a worker whose fibres all wait resumes them anyway after a while, the one that has waited longest first
+    for (int workers : {1, 3}) {
+        FiberPool pool(workers);
+        static volatile uint32_t never[6];
+        for (auto &x : never) x = 0;
+        std::vector<int> resumed(6, 0);
+        for (int id = 0; id < 6; id++)
+            pool.add([&resumed, id]() {
+                lshost::FiberWait w; w.words = never + id; w.n_words = 1; w.tag = 9;
+                while ((never[id] >> 16) != 9) {
+                    FiberPool::yield(&w);
+                    if (++resumed[(size_t)id] == 5) never[id] = 9u << 16; // the waiter's own doing, on its fifth look
+                }
+            }, id);
+        pool.run();
+        for (int id = 0; id < 6; id++)
+            if (resumed[(size_t)id] < 5) return fail("a fibre whose answer never came on its own was not resumed");
+    }
     // yield() outside any fibre is a no-op
     FiberPool::yield();
     printf("OK\n");

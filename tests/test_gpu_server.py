@@ -273,6 +273,36 @@ def test_multi_solver_server_slots_equal_single_launched_runs(monkeypatch, n, n_
         assert s4 == singles[:3] and i4 == iters[:3]
 
 
+def test_multi_solver_fibres_survive_server_relaunches(monkeypatch):
+    # A launch of the server that ages out (or idles out) while requests are posted is started again by whoever waits on it
+    # (SrvHost::wait).  Under the fibre pool a waiter is only resumed early when its answer HAS arrived -- so a worker whose
+    # fibres all wait must resume them anyway after a while, or nobody ever relaunches (this hung config 4 on 4 host cores).
+    # 4 cores, 16 slots, an age limit of 3 ms: dozens of relaunches under load; results as on the launch-per-call route.
+    import os
+    import ls_amd
+    n, rounds = 1024, 2
+    seeds = [str(s) for s in range(42, 42 + 16)]
+    p = _nq_params(n)
+    monkeypatch.setenv("LS_NQ_STEP", "3")
+    with ls_amd.Context(0) as c3:
+        singles, iters = _single_runs(c3, n, seeds, p, rounds)
+    monkeypatch.setenv("LS_NQ_STEP", "4")
+    monkeypatch.setenv("LS_NQ_SERVER_LIMIT_MS", "3")
+    monkeypatch.setenv("LS_NQ_SERVER_IDLE_US", "100")
+    before = os.sched_getaffinity(0)
+    os.sched_setaffinity(0, set(sorted(before)[:4]))
+    try:
+        with ls_amd.Context(0) as c:
+            m = ls_amd.MultiSolver(c, n, seeds, p, n_slots=16, mode="free")
+            m.run(max_rounds_per_restart=rounds)
+            assert [m.best(r) for r in range(len(seeds))] == singles
+            assert m.stats()["ls_iterations"] == sum(iters)
+            assert m.counters()["server_launches"] >= 5
+            m.close()
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_multi_solver_server_n1024_follows_the_oracle_driver():
     # one restart of the multi-solver (server slots, fibres) against the oracle's literal Python driver, round for round
     import ls_amd

@@ -33,7 +33,7 @@ def main():
         if args.step_mode is not None:
             env["LS_NQ_STEP"] = args.step_mode
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_config4.py"), "--restarts-per-gpu", str(args.restarts)],
-                           capture_output=True, text=True, timeout=600, env=env, preexec_fn=lambda: os.sched_setaffinity(0, cores))
+                           capture_output=True, text=True, timeout=150, env=env, preexec_fn=lambda: os.sched_setaffinity(0, cores))
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not line:
             print(json.dumps({"host_cores": k, "error": r.stderr[-500:]}), flush=True)
