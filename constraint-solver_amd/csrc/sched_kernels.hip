@@ -921,14 +921,20 @@ __device__ __forceinline__ void wave_value_sets_u32(unsigned onehot, unsigned &b
 template <typename M>
 __device__ __forceinline__ void sched_build_base_tab(const SchedInst &in, int part, int e /* employee of day `lane`; -1 - lane beyond S */,
                                                      int hol /* holiday bit of (e, lane), gathered by the caller (part 0) */,
-                                                     const SchedLaneConst &L, int lane, SchedBaseTab<M> &T)
+                                                     const SchedLaneConst &L, int lane, SchedBaseTab<M> &T, M *emp = nullptr)
 {
     typedef SchedMaskOps<M> O;
     const int D = in.D;
     M eq = 0;
+    if (emp) { // the employee -> scored-days table (all zero between requests): every calling wavefront ORs the same bits in, then reads its own back
+        if (lane < D && e >= 0) __hip_atomic_fetch_or(&emp[e], (M)1 << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (e >= 0) eq = __hip_atomic_load(&emp[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
 #pragma unroll
-    for (int q = 0; q < (int)sizeof(M) * 8; q++)
-        if (q < D && e == __builtin_amdgcn_readlane(e, q)) eq |= (M)1 << q;
+        for (int q = 0; q < (int)sizeof(M) * 8; q++)
+            if (q < D && e == __builtin_amdgcn_readlane(e, q)) eq |= (M)1 << q;
+    }
     LS_SC_STAMP(8);
     const bool scored = L.flags & 1;
     const M low = ((M)1 << (lane & ((int)sizeof(M) * 8 - 1))) - 1;
@@ -1020,7 +1026,7 @@ __device__ __forceinline__ B sched_replace_values(const B *b, bool hXo, int vXo,
 // of (n1, p1) | (n2, p2) << 1.  Only called for well-formed, non-tabu candidates.
 template <typename M>
 __device__ __forceinline__ void sched_delta_score(const SchedBaseTab<M> &T, int e_lane, int D, bool swap, int p1, int p2, int n1,
-                                                  int hbits, int &hard_out, int &soft_out)
+                                                  int hbits, int &hard_out, int &soft_out, const M *emp = nullptr)
 {
     typedef SchedMaskOps<M> O;
     const M bit1 = p1 < D ? (M)1 << p1 : 0, bit2 = (swap && p2 < D) ? (M)1 << p2 : 0;
@@ -1031,8 +1037,11 @@ __device__ __forceinline__ void sched_delta_score(const SchedBaseTab<M> &T, int 
     if (swap) {
         mY = T.eq[p2];
         gY = T.g[p2];
+    } else if (emp) {
+        mY = emp[n1]; // the day set of an arbitrary employee, from the block's employee -> scored-days table
+        gY = mY ? T.g[O::lsb(mY)] : 0;
     } else {
-        mY = 0; // the day set of an arbitrary employee: compare with every scored day (e_lane: lane d holds day d)
+        mY = 0; // ... or by comparing with every scored day (e_lane: lane d holds day d)
 #pragma unroll
         for (int d = 0; d < (int)sizeof(M) * 8; d++)
             if (d < D && __builtin_amdgcn_readlane(e_lane, d) == n1) mY |= (M)1 << d;
@@ -1112,7 +1121,7 @@ __device__ __forceinline__ int sched_edit_hbits(const SchedInst &in, const Sched
 // the argmin key of an active candidate (and its scores)
 template <typename M>
 __device__ __forceinline__ u64 sched_delta_key(const SchedBaseTab<M> &T, int D, int e_lane, const SchedEdit &ed, int hbits, int &hard,
-                                               int &soft)
+                                               int &soft, const M *emp = nullptr)
 {
     u64 e1, e2 = (u64)1 << 21; // "no second edit" sorts between lowering and raising edits
     if (!ed.swap) e1 = sc_edit_key(ed.p1, ed.new1, ed.ea);
@@ -1121,7 +1130,7 @@ __device__ __forceinline__ u64 sched_delta_key(const SchedBaseTab<M> &T, int D, 
         e1 = a_first ? sc_edit_key(ed.p1, ed.new1, ed.ea) : sc_edit_key(ed.p2, ed.new2, ed.eb);
         e2 = a_first ? sc_edit_key(ed.p2, ed.new2, ed.eb) : sc_edit_key(ed.p1, ed.new1, ed.ea);
     }
-    sched_delta_score<M>(T, e_lane, D, ed.swap, ed.p1, ed.p2, ed.new1, hbits, hard, soft);
+    sched_delta_score<M>(T, e_lane, D, ed.swap, ed.p1, ed.p2, ed.new1, hbits, hard, soft, emp);
     return ((u64)(unsigned)hard << 54) | ((u64)(unsigned)soft << 46) | (e1 << 23) | e2;
 }
 
@@ -1305,6 +1314,7 @@ struct SchedSrvArgs {
     const ls_sched_move *moves; // the resident stream (device memory), fixed while the launch lives
     long long n_resident;
     const int *shadow;          // pinned host: the state of the current request [64]
+    int emp_entries;            // entries of the employee -> scored-days table in dynamic LDS (0: none)
 };
 
 template <typename M, int NW>
@@ -1320,6 +1330,10 @@ __global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
     __shared__ unsigned s_req[16];
     __shared__ int s_state[64];
     __shared__ int s_leave;
+    // employee -> scored days of the current state (see sched_grid_server_kernel): zero between requests
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    M *const emp = a.emp_entries > 0 ? reinterpret_cast<M *>(s_dyn) : nullptr;
+    for (int i = tid; i < a.emp_entries; i += 64 * NW) emp[i] = 0;
     SchedLaneConst L{};
     if (wib < 3) L = a.in.lane_tab[lane];
     // this lane's move of the resident stream: loaded once, the stream is fixed while the launch lives
@@ -1362,7 +1376,7 @@ __global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
         const u64 bal = __ballot(ed.active);
         if (lane == 0) s_wcnt[wib] = __popcll(bal);
         const int hbits = sched_edit_hbits(a.in, ed);
-        if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T);
+        if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T, emp);
         __syncthreads();
         int before = 0, total = 0;
 #pragma unroll
@@ -1375,11 +1389,12 @@ __global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
         long long best_idx = -1;
         if (ed.active && rank <= window) {
             int hard, soft;
-            best_key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft);
+            best_key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft, emp);
             best_idx = k;
         }
         sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib); // valid in wavefront 0 afterwards
         if (wib == 0) {
+            if (emp && lane < D && e_lane >= 0) emp[e_lane] = 0; // every scorer is past the barrier above: the table is all zero again
             const bool has = best_key != SC_KEY_EMPTY;
             const long long n_scored = window <= 0 || !has ? 0 : (total < window ? total : window);
             unsigned pay = 0;
@@ -1692,6 +1707,7 @@ struct SchedGridArgs {
     SchedGridCtl *g;
     unsigned long long ready_target; // g->ready once every workgroup of THIS launch has started (the host adds the grid size per launch)
     unsigned *rec;           // [n_chunks][8] every workgroup's record of the current request (tagged dwords)
+    int emp_entries;         // entries of the workgroup's employee -> scored-days table in dynamic LDS (0: none, the scorers compare day by day)
 };
 
 template <typename M, int NW>
@@ -1709,6 +1725,12 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
     __shared__ int s_ctl[2]; // [0] leave, [1] the request's tag
     __shared__ int s_cut;
     __shared__ long long s_before;
+    // Which scored days an employee works in the current state, for every employee: the table's day-equality rows and the day
+    // set of a ChangeDay's new employee are one LDS read each instead of a 64-step compare loop (a third of the scorer's
+    // instructions).  Zero between requests: the <= 64 entries a state touches are set before and cleared after its scoring.
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    M *const emp = a.emp_entries > 0 ? reinterpret_cast<M *>(s_dyn) : nullptr;
+    for (int i = tid; i < a.emp_entries; i += 64 * NW) emp[i] = 0;
     SchedLaneConst L{};
     if (wib < 3) L = a.in.lane_tab[lane];
     // (Keeping the instance's holiday words in LDS -- 80 KB at 10 000 employees -- instead of gathering them from L2 per request was
@@ -1786,7 +1808,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
 #ifdef LS_NQ_STAMPS
         { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); gst[2] = wall_clock64(); }
 #endif
-        if (wib < 3) sched_build_base_tab<M>(in, wib, e_lane, hol_base, L, lane, T);
+        if (wib < 3) sched_build_base_tab<M>(in, wib, e_lane, hol_base, L, lane, T, emp);
         __syncthreads();
         SCG_STAMP(3);
         u64 best_key = SC_KEY_EMPTY;
@@ -1794,7 +1816,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         int cnt = 0;
         if (ed.active) {
             int hard, soft;
-            best_key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft);
+            best_key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft, emp);
             best_idx = k; cnt = 1;
         }
         SCG_STAMP(4);
@@ -1885,7 +1907,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                 const long long rank = before + __popcll(bal & ((2ull << lane) - 1)); // 1-based among the chunk's real candidates
                 if (e2.active && rank <= need) {
                     int hard, soft;
-                    const u64 key2 = sched_delta_key<M>(T, D, e_lane, e2, hb2, hard, soft);
+                    const u64 key2 = sched_delta_key<M>(T, D, e_lane, e2, hb2, hard, soft, emp);
                     if (key2 < fkey) { fkey = key2; fidx = kk; }
                 }
             }
@@ -1911,6 +1933,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                 if (lane == 0) __hip_atomic_store(&a.link.ctl->last_activity, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        if (emp && wib == 0 && lane < D && e_lane >= 0) emp[e_lane] = 0; // the table is all zero again (every scorer of this request is past a barrier)
         if (c == 0 && wib == 0) poll.t_served = wall_clock64();
     }
     if (tid == 0) srv_block_leaves(a.link);
@@ -2144,6 +2167,21 @@ int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const
 }
 
 // ------------------------------------------------------------------------------------------ resident scheduling LS step
+// Dynamic LDS for a resident workgroup's employee -> scored-days table (one mask per employee), or 0 when it does not fit
+// beside the static LDS of the kernel (160 KB per CU on gfx950) or is switched off (LS_SCHED_NO_EMP_TABLE=1: the scorers then
+// compare day by day, as the launched kernels do).
+static size_t sched_emp_table_bytes(const ls_ctx *ctx, const void *fn, bool m32)
+{
+    const bool no_table = getenv("LS_SCHED_NO_EMP_TABLE") != nullptr; // read per launch
+    const size_t dyn = (size_t)ctx->sched.n_employees * (m32 ? 4 : 8);
+    if (no_table || dyn == 0 || dyn > ((size_t)96 << 10)) return 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return dyn;
+}
+
 constexpr int SCS_NW = 8; // wavefronts of the server workgroup: move lists of at most 512 entries
 
 struct SchedServer {
@@ -2206,8 +2244,8 @@ void sched_server_destroy(ls_ctx *ctx)
         fprintf(stderr, "scheduling grid: %llu requests, answer wait %.2f us per request (whole call %.2f us), %llu launches, the window cut the finisher's chunk in %llu\n",
                 s->grid_requests, s->t_wait / s->grid_requests * 1e6, s->t_call / s->grid_requests * 1e6, s->grid.relaunches.load(), s->grid_fin_hits);
         if (s->dev_ticks[4])
-            fprintf(stderr, "  the finisher, after it saw the request: go record out (workgroup 0 only) %.2f us, edit + holiday bits in %.2f, table built %.2f, chunk scored %.2f, "
-                            "own chunk recorded %.2f, all records in %.2f, cut chunk scored %.2f, answer %.2f\n", s->dev_ticks[0] * 0.01 / s->grid_requests,
+            fprintf(stderr, "  the finisher, after it saw the request: edit + holiday bits in %.2f us, table built %.2f, chunk scored %.2f, "
+                            "own chunk recorded %.2f, all records in %.2f, cut chunk scored %.2f, answer %.2f\n",
                     s->dev_ticks[1] * 0.01 / s->grid_requests, s->dev_ticks[2] * 0.01 / s->grid_requests, s->dev_ticks[3] * 0.01 / s->grid_requests,
                     s->dev_ticks[4] * 0.01 / s->grid_requests, s->dev_ticks[5] * 0.01 / s->grid_requests, s->dev_ticks[6] * 0.01 / s->grid_requests,
                     s->dev_ticks[7] * 0.01 / s->grid_requests);
@@ -2287,7 +2325,9 @@ static int sched_small_server(ls_ctx *ctx, SchedServer **out)
             const bool m32 = ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64;
             const void *fn = m32 ? reinterpret_cast<const void *>(&sched_server_kernel<unsigned, SCS_NW>)
                                  : reinterpret_cast<const void *>(&sched_server_kernel<u64, SCS_NW>);
-            return hipLaunchKernel(fn, dim3(1), dim3(64 * SCS_NW), args, 0, s->h.stream);
+            const size_t dyn = sched_emp_table_bytes(ctx, fn, m32);
+            a.emp_entries = dyn ? ctx->sched.n_employees : 0;
+            return hipLaunchKernel(fn, dim3(1), dim3(64 * SCS_NW), args, dyn, s->h.stream);
         };
     }
     *out = s;
@@ -2382,7 +2422,10 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
             const bool m32 = ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64;
             const void *fn = m32 ? reinterpret_cast<const void *>(&sched_grid_server_kernel<unsigned, SCS_NW>)
                                  : reinterpret_cast<const void *>(&sched_grid_server_kernel<u64, SCS_NW>);
-            return hipLaunchKernel(fn, dim3((unsigned)n), dim3(64 * SCS_NW), args, 0, s->grid.stream);
+            // the employee -> scored-days table: when no CU has to hold two workgroups
+            const size_t dyn = n > ctx->n_cus ? 0 : sched_emp_table_bytes(ctx, fn, m32);
+            a.emp_entries = dyn ? ctx->sched.n_employees : 0;
+            return hipLaunchKernel(fn, dim3((unsigned)n), dim3(64 * SCS_NW), args, dyn, s->grid.stream);
         };
     }
     {   // workspaces for the current resident list (they only change while the launch is paused: sched_server_pause)
@@ -2409,8 +2452,10 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
         pay[0] = SCS_F_EVAL; pay[1] = (unsigned)n_moves & 0xffffu; pay[2] = (unsigned)n_moves >> 16; pay[3] = w & 0xffffu; pay[4] = w >> 16;
         pay[5] = (unsigned)s->grid_fin; // the finisher: the chunk the window cut last time (its lanes still hold the keys the cut needs)
         for (int d = 0; d < S; d++) pay[SCG_STATE_AT + d] = (unsigned)state[d] & 0xffffu;
+        alignas(64) unsigned msg[64];
+        for (int d = 0; d < 64; d++) msg[d] = (tag << 16) | pay[d];
         volatile unsigned *dst = s->grid.req(0);
-        for (int d = 63; d >= 0; d--) dst[d] = (tag << 16) | pay[d];
+        for (int l = 3; l >= 0; l--) srv_store_line(dst + 16 * l, msg + 16 * l);
         s->grid_requests++;
     }
     static const bool trace = getenv("LS_AMD_TRACE") != nullptr;

@@ -22,6 +22,9 @@
 // waits for resident kernels whatever the stream: the servers are asked to leave before their memory is released).
 #pragma once
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <sched.h>
 
 #include <atomic>
@@ -130,6 +133,24 @@ __device__ __forceinline__ void srv_block_leaves(const SrvLink &L)
 #endif // __HIPCC__
 
 // ---------------------------------------------------------------------------------------------------------------- host
+// One 64-byte line of the mailbox, written by the host.  The device polls these lines over PCIe, so every separate store to a
+// line it has just read costs the core a fresh ownership request: one 64-byte store per line where the CPU has one (the
+// dwords' tags still decide what the reader accepts -- nothing here relies on the store being indivisible).
+#if defined(__x86_64__)
+__attribute__((target("avx512f"))) inline void srv_store_line_wide(volatile unsigned *dst, const unsigned *line)
+{
+    _mm512_store_si512(const_cast<unsigned *>(dst), _mm512_loadu_si512(line));
+}
+#endif
+inline void srv_store_line(volatile unsigned *dst, const unsigned *line)
+{
+#if defined(__x86_64__)
+    static const bool wide = __builtin_cpu_supports("avx512f") && getenv("LS_HOST_NO_AVX512") == nullptr;
+    if (wide) { srv_store_line_wide(dst, line); return; }
+#endif
+    for (int d = 0; d < 16; d++) dst[d] = line[d];
+}
+
 struct SrvHost {
     int device = 0, n_slots = 0;
     const char *what = "server";
@@ -230,8 +251,7 @@ struct SrvHost {
         alignas(64) unsigned line[16];
         for (int d = 0; d < 16; d++) line[d] = (tag << 16) | (pay[d] & 0xffffu);
         __atomic_thread_fence(__ATOMIC_RELEASE); // the bulk data is written before the line that announces it
-        volatile unsigned *dst = req(slot);
-        for (int d = 0; d < 16; d++) dst[d] = line[d];
+        srv_store_line(req(slot), line);
         requests.fetch_add(1, std::memory_order_relaxed);
     }
     // Poll the slot's answer line for the tag of the request just posted (the same hooks as the completion-word wait of a

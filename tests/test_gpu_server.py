@@ -367,8 +367,12 @@ def test_sched_server_follows_any_call_sequence(monkeypatch, dates, E):
         for d in ds:
             bits[e] |= np.uint64(1) << np.uint64(int(d))
     results = {}
-    for server in ("1", "0"):
-        monkeypatch.setenv("LS_SCHED_SERVER", server)
+    for server in ("1", "1 day-by-day", "0"):   # resident (employee table in LDS) | resident, scorers compare day by day | launch per call
+        monkeypatch.setenv("LS_SCHED_SERVER", server[0])
+        if server == "1 day-by-day":
+            monkeypatch.setenv("LS_SCHED_NO_EMP_TABLE", "1")
+        else:
+            monkeypatch.delenv("LS_SCHED_NO_EMP_TABLE", raising=False)
         prng = np.random.default_rng(5)
         got = []
         with ls_amd.Context(0) as c:
@@ -405,11 +409,11 @@ def test_sched_server_follows_any_call_sequence(monkeypatch, dates, E):
                 if it == 45:
                     c.sched_instance_upload(D, S, inst.start_weekday, E, bits)   # the instance again: the launch is restarted
             cnt = c.counters()
-            assert (cnt["server_requests"] > 60) == (server == "1")
-            if server == "1":
+            assert (cnt["server_requests"] > 60) == (server != "0")
+            if server != "0":
                 assert cnt["server_launches"] >= 3
         results[server] = got
-    assert results["1"] == results["0"]
+    assert results["1"] == results["0"] == results["1 day-by-day"]
 
 
 def test_sched_grid_server_long_lists(monkeypatch):
@@ -429,8 +433,12 @@ def test_sched_grid_server_long_lists(monkeypatch):
         for d in ds:
             bits[e] |= np.uint64(1) << np.uint64(int(d))
     results = {}
-    for server in ("1", "0"):
-        monkeypatch.setenv("LS_SCHED_SERVER", server)
+    for server in ("1", "1 day-by-day", "0"):   # resident (employee table in LDS) | resident, scorers compare day by day | launch per call
+        monkeypatch.setenv("LS_SCHED_SERVER", server[0])
+        if server == "1 day-by-day":
+            monkeypatch.setenv("LS_SCHED_NO_EMP_TABLE", "1")
+        else:
+            monkeypatch.delenv("LS_SCHED_NO_EMP_TABLE", raising=False)
         prng = np.random.default_rng(9)
         got = []
         with ls_amd.Context(0) as c:
@@ -465,6 +473,6 @@ def test_sched_grid_server_long_lists(monkeypatch):
                     moves = _random_moves(prng, 1500, D, E)              # a new, shorter list: another grid size
                     c.sched_moves_upload(moves)
             cnt = c.counters()
-            assert (cnt["server_requests"] >= 40) == (server == "1")
+            assert (cnt["server_requests"] >= 40) == (server != "0")
         results[server] = got
-    assert results["1"] == results["0"]
+    assert results["1"] == results["0"] == results["1 day-by-day"]
