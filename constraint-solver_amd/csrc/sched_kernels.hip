@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void sched_score_kernel(SchedInst in, int n_st
 
 // --------------------------------------------------------------- neighbourhood
 struct SchedEvalArgs {
+    int emp_entries = 0;   // entries of a block's employee -> scored-days table in dynamic LDS (sched_eval_all_kernel; 0: none)
     SchedInst in;
     int n_restarts;
     const int *states;          // [n_restarts][S]
@@ -1461,7 +1462,15 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_all_kernel(SchedEvalArgs a
     LS_SC_STAMP(1);
     int hbits = sched_edit_hbits(a.in, ed);
     LS_SC_STAMP(2);
-    if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T);
+    // employee -> scored days of the base state (see sched_grid_server_kernel), zeroed by the whole block while its loads fly
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    M *const emp = a.emp_entries > 0 ? reinterpret_cast<M *>(s_dyn) : nullptr;
+    if (emp) {
+        const int n16 = (int)(((size_t)a.emp_entries * sizeof(M) + 15) / 16); // the launcher rounds the allocation up to 16 bytes
+        for (int i = (int)threadIdx.x; i < n16; i += 64 * NW) reinterpret_cast<uint4 *>(s_dyn)[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
+    if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T, emp);
     LS_SC_STAMP(3);
     __syncthreads();
     LS_SC_STAMP(4);
@@ -1475,7 +1484,7 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_all_kernel(SchedEvalArgs a
         u64 key = SC_KEY_EMPTY;
         if (ed.active) {
             int hard, soft;
-            key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft);
+            key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft, emp);
             if (key < best_key) { best_key = key; best_idx = k; }
             cnt++;
         }
@@ -1988,8 +1997,19 @@ bool sched_is_fused_launch(const ls_ctx *ctx, long long max_moves)
 static int sched_launch_delta_pipeline(ls_ctx *ctx, SchedEvalArgs a, bool gen)
 {
     constexpr int DW = 8;
-    static const int bpw = getenv("LS_SCHED_DELTA_BPW") ? atoi(getenv("LS_SCHED_DELTA_BPW")) : 1; // batches per wavefront: measurement knob
-    a.chunk_moves = 64LL * DW * (bpw < 1 ? 1 : bpw);
+    // Batches of 64 candidates per wavefront: one while every CU gets at most two blocks (a block lives ~5 us, mostly latency);
+    // beyond that the dispatcher's ~2 ns per wavefront is the limit and each wavefront takes 2 or 3 batches behind one base
+    // table (exhaustive 320 k candidates: 16.8 / 14.5 / 14.1 us for 1 / 2 / 3; window 65 536 of 82 k: 10.2 / 12.4 / 16.3).
+    // LS_SCHED_DELTA_BPW pins it (measurement knob).
+    const char *bpw_s = getenv("LS_SCHED_DELTA_BPW"); // read per launch
+    const int bpw_env = bpw_s ? atoi(bpw_s) : 0;
+    int bpw = bpw_env;
+    if (bpw < 1)
+        for (bpw = 1; bpw < 3; bpw++) {
+            const long long cm = 64LL * DW * bpw;
+            if ((a.max_moves + cm - 1) / cm * a.n_restarts <= 2LL * ctx->n_cus) break;
+        }
+    a.chunk_moves = 64LL * DW * bpw;
     const long long nch = a.max_moves > 0 ? (a.max_moves + a.chunk_moves - 1) / a.chunk_moves : 1;
     if (nch * a.n_restarts > 0x7fffffffLL) return set_err(ctx, LS_ERR_UNSUPPORTED, "max_moves = %lld is too large", a.max_moves);
     const size_t parts = (size_t)a.n_restarts * (size_t)nch;
@@ -2006,9 +2026,13 @@ static int sched_launch_delta_pipeline(ls_ctx *ctx, SchedEvalArgs a, bool gen)
     a.n_scored = nullptr;
     const bool m32 = ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64;
     const dim3 g1((unsigned)(nch * a.n_restarts)), g2((unsigned)a.n_restarts), b(64 * DW);
+    // the employee -> scored-days table of a block: when three blocks of a CU can still hold one each
+    size_t dyn = ((size_t)ctx->sched.n_employees * (m32 ? 4 : 8) + 15) & ~(size_t)15;
+    if (dyn > ((size_t)48 << 10) || getenv("LS_SCHED_NO_EMP_TABLE")) dyn = 0;
+    a.emp_entries = dyn ? ctx->sched.n_employees : 0;
 #define LS_LAUNCH2(MT, GEN)                                                                             \
     {                                                                                                   \
-        hipLaunchKernelGGL((sched_eval_all_kernel<MT, DW, GEN>), g1, b, 0, ctx->stream, a);             \
+        hipLaunchKernelGGL((sched_eval_all_kernel<MT, DW, GEN>), g1, b, dyn, ctx->stream, a);           \
         LS_HIP(ctx, hipGetLastError());                                                                 \
     }
     const bool one_launch = ctx->sched_one_launch;

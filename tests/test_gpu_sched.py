@@ -318,6 +318,47 @@ def test_config5_random_stream_at_launch_size(ctx, window):
                (exp["n_scored"], exp["best_index"], exp["best_hard"], exp["best_soft"])
 
 
+@pytest.mark.parametrize("bpw", ["1", "2", "3", None])
+@pytest.mark.parametrize("table", [True, False])
+def test_two_launch_pipeline_batches_per_wavefront_and_employee_table(monkeypatch, bpw, table):
+    # sched_eval_all_kernel's two tuning dimensions leave every result alone: 1 / 2 / 3 batches of 64 candidates per wavefront
+    # (LS_SCHED_DELTA_BPW; unset = chosen from the grid size) and the employee -> scored-days look-up table in LDS against
+    # the day-by-day compare loops (LS_SCHED_NO_EMP_TABLE=1).  700 employees x 32 days: 22 400 exhaustive candidates.
+    if bpw is None:
+        monkeypatch.delenv("LS_SCHED_DELTA_BPW", raising=False)
+    else:
+        monkeypatch.setenv("LS_SCHED_DELTA_BPW", bpw)
+    if table:
+        monkeypatch.delenv("LS_SCHED_NO_EMP_TABLE", raising=False)
+    else:
+        monkeypatch.setenv("LS_SCHED_NO_EMP_TABLE", "1")
+    import ls_amd
+    monkeypatch.setenv("LS_SCHED_SERVER", "0")                        # the launched pipeline, not the resident grid
+    rng = np.random.default_rng(31)
+    E = 700
+    hol = {int(e): list(rng.choice(31, size=2, replace=False)) for e in rng.choice(E, size=200, replace=False)}
+    with ls_amd.Context(0) as c:
+        inst, D, S = _upload(c, (2022, 5, 9), (2022, 6, 8), E, hol)
+        for trial in range(2):
+            states = np.stack([rng.integers(0, E, size=S), rng.integers(0, 9, size=S), rng.integers(0, E, size=S)])
+            for window in (10 ** 9, 22_000, 1537, 1536, 511, 1):
+                got = c.sched_eval_exhaustive(states, window)
+                for r in range(len(states)):
+                    moves = orc.Sched.exhaustive_moves(states[r], range(E))
+                    exp = inst.neighbourhood(states[r], moves, window)
+                    assert (got[r]["n_scored"], got[r]["best_index"]) == (exp["n_scored"], exp["best_index"]), (trial, window, r)
+                    assert (got[r]["best_hard"], got[r]["best_soft"]) == (exp["best_hard"], exp["best_soft"])
+            state = states[1]
+            moves = _random_moves(rng, 5000, D, 12, state)            # a caller's stream with many SwapDays and no-ops
+            c.sched_moves_upload(moves)
+            for window in (10 ** 9, 3000, 1025):
+                exp = inst.neighbourhood(state, moves, window)
+                res = c.sched_eval_resident(state, len(moves), window)
+                assert (res["n_scored"], res["best_index"], res["best_hard"], res["best_soft"]) == \
+                       (exp["n_scored"], exp["best_index"], exp["best_hard"], exp["best_soft"])
+        assert c.counters()["server_requests"] == 0
+
+
 def test_skip_moves_for_a_general_tabu_set(ctx):
     # LS_SCHED_MOVE_SKIP: how a caller whose History keeps more than the current solution tabu
     # (all_solution_iteration_expiry == 0, local_search.rs:155-199) tells the GPU that a move leads to a tabu solution:
