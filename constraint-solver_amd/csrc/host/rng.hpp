@@ -140,6 +140,26 @@ public:
     }
     // Standard f64: 53 random bits scaled into [0, 1)
     double gen_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+    // n consecutive gen_f64() draws: eight per step wherever sixteen words of the position's group lie ahead
+    void fill_f64(double *out, uint32_t n)
+    {
+        uint32_t i = 0;
+#if defined(__x86_64__)
+        if (have_avx512dq())
+            while (i + 8 <= n) {
+                const uint64_t g = pos_ >> 8;
+                const unsigned w = (unsigned)(pos_ & 255);
+                if (w + 16 > 256) { out[i++] = gen_f64(); continue; } // fewer than eight draws left in this group: one at a time up to the seam
+                if (g >= hi_group_) { generate_group(g); hi_group_ = g + 1; }
+                unsigned take = (256 - w) / 16;                        // steps of eight draws left in this group
+                if (take > (n - i) / 8) take = (n - i) / 8;
+                f64_from_words(pool_[(size_t)(g % GROUPS)] + w, out + i, take);
+                i += 8 * take;
+                pos_ += 16 * (uint64_t)take;
+            }
+#endif
+        for (; i < n; i++) out[i] = gen_f64();
+    }
     uint64_t words_drawn() const { return pos_; }
     // Compute one more group of the key stream ahead of the position (idle time of the caller, e.g. while a launch is in
     // flight): the stream is a pure function of (key, block number), so this changes nothing but when the work is done.
@@ -156,9 +176,9 @@ public:
 
 private:
     // word k of the stream = word k mod 16 of block k / 16.  The pool is a ring of GROUPS groups of sixteen blocks
-    // (group g = blocks 16 g .. 16 g + 15, in slot g mod GROUPS; valid: the position's group up to hi_group_), each
-    // WORD-MAJOR (slot[w * 16 + b] = word w of block 16 g + b): that is how the lanes of the vectorised block function
-    // lie, so a group is stored as its sixteen vectors -- no transposition.  Access is sequential.
+    // (group g = blocks 16 g .. 16 g + 15, in slot g mod GROUPS; valid: the position's group up to hi_group_), each in STREAM
+    // order (slot[16 b + w] = word w of block 16 g + b: the vectorised block function's word-major lanes are transposed when a
+    // group is generated -- mostly in the caller's idle time --, so that runs of draws are contiguous loads: fill_f64).
     static constexpr int GROUPS = 16;
     uint32_t word(uint64_t k)
     {
@@ -167,7 +187,7 @@ private:
             generate_group(g);
             hi_group_ = g + 1;
         }
-        return pool_[(size_t)(g % GROUPS)][(size_t)(((k & 15) << 4) | ((k >> 4) & 15))];
+        return pool_[(size_t)(g % GROUPS)][(size_t)(k & 255)];
     }
     // One 32-bit lane per block (compiler vector extension): four blocks at a time, eight with AVX2, sixteen with
     // AVX-512 (single-instruction rotates).  The word sequence is that of chacha20_block called block by block
@@ -189,20 +209,42 @@ private:
         LS_QR(0, 4, 8, 12) LS_QR(1, 5, 9, 13) LS_QR(2, 6, 10, 14) LS_QR(3, 7, 11, 15)                \
         LS_QR(0, 5, 10, 15) LS_QR(1, 6, 11, 12) LS_QR(2, 7, 8, 13) LS_QR(3, 4, 9, 14)                \
     }                                                                                                \
-    for (int i = 0; i < 16; i++) {                                                                   \
-        const vL o = x[i] + s[i];                                                                    \
-        std::memcpy(dst + 16 * i, &o, sizeof o);                                                     \
-    }
+    for (int i = 0; i < 16; i++) x[i] += s[i];                                                       \
+    LS_CHACHA_STORE(L)
 #define LS_QR(a, b, c, d)                                                            \
     x[a] += x[b]; x[d] = ((x[d] ^ x[a]) << 16) | ((x[d] ^ x[a]) >> 16);              \
     x[c] += x[d]; x[b] = ((x[b] ^ x[c]) << 12) | ((x[b] ^ x[c]) >> 20);              \
     x[a] += x[b]; x[d] = ((x[d] ^ x[a]) << 8) | ((x[d] ^ x[a]) >> 24);               \
     x[c] += x[d]; x[b] = ((x[b] ^ x[c]) << 7) | ((x[b] ^ x[c]) >> 25);
-    // blocks first .. first + L - 1 into columns of a word-major slot (dst = slot + first block's column)
+    // blocks first .. first + L - 1 in stream order (dst = the first block's sixteen words): x[i] holds word i of the L blocks
+#define LS_CHACHA_STORE(L)                                                                           \
+    for (int i = 0; i < 16; i++)                                                                     \
+        for (int b = 0; b < L; b++) dst[16 * b + i] = x[i][b];
     void blocks4(uint64_t first, uint32_t *dst) { LS_CHACHA_LANES(4) }
 #if defined(__x86_64__)
     __attribute__((target("avx2"))) void blocks8(uint64_t first, uint32_t *dst) { LS_CHACHA_LANES(8) }
+#undef LS_CHACHA_STORE
+    // sixteen blocks: a 16 x 16 transposition of 32-bit words in registers (unpack 32, unpack 64, two 128-bit lane shuffles)
+#define LS_CHACHA_STORE(L)                                                                           \
+    __m512i r[16], t[16];                                                                            \
+    for (int i = 0; i < 16; i++) std::memcpy(&r[i], &x[i], 64);                                      \
+    for (int i = 0; i < 16; i += 2) { t[i] = _mm512_unpacklo_epi32(r[i], r[i + 1]); t[i + 1] = _mm512_unpackhi_epi32(r[i], r[i + 1]); } \
+    for (int i = 0; i < 16; i += 4) {                                                                \
+        r[i] = _mm512_unpacklo_epi64(t[i], t[i + 2]); r[i + 1] = _mm512_unpackhi_epi64(t[i], t[i + 2]); \
+        r[i + 2] = _mm512_unpacklo_epi64(t[i + 1], t[i + 3]); r[i + 3] = _mm512_unpackhi_epi64(t[i + 1], t[i + 3]); \
+    }                                                                                                \
+    for (int h = 0; h < 16; h += 8)                                                                  \
+        for (int i = 0; i < 4; i++) {                                                                \
+            t[h + i] = _mm512_shuffle_i32x4(r[h + i], r[h + i + 4], 0x88);                           \
+            t[h + i + 4] = _mm512_shuffle_i32x4(r[h + i], r[h + i + 4], 0xdd);                       \
+        }                                                                                            \
+    for (int i = 0; i < 8; i++) {                                                                    \
+        r[i] = _mm512_shuffle_i32x4(t[i], t[i + 8], 0x88);                                           \
+        r[i + 8] = _mm512_shuffle_i32x4(t[i], t[i + 8], 0xdd);                                       \
+    }                                                                                                \
+    for (int b = 0; b < 16; b++) _mm512_store_si512(dst + 16 * b, r[b]);
     __attribute__((target("avx512f"))) void blocks16(uint64_t first, uint32_t *dst) { LS_CHACHA_LANES(16) }
+#undef LS_CHACHA_STORE
     static bool have_avx2() // LS_HOST_NO_AVX2=1 forces the four-lane path (tests run all three)
     {
         static const bool v = __builtin_cpu_supports("avx2") && std::getenv("LS_HOST_NO_AVX2") == nullptr;
@@ -213,6 +255,20 @@ private:
         static const bool v = have_avx2() && __builtin_cpu_supports("avx512f") && std::getenv("LS_HOST_NO_AVX512") == nullptr;
         return v;
     }
+    static bool have_avx512dq()
+    {
+        static const bool v = have_avx512() && __builtin_cpu_supports("avx512dq");
+        return v;
+    }
+    // (double)(u64 >> 11) * 2^-53 for `steps` x 8 consecutive u64 of the stream (word pairs, low word first): gen_f64's value
+    __attribute__((target("avx512f,avx512dq"))) static void f64_from_words(const uint32_t *w, double *out, unsigned steps)
+    {
+        const __m512d scale = _mm512_set1_pd(1.0 / 9007199254740992.0);
+        for (unsigned s = 0; s < steps; s++) {
+            const __m512i v = _mm512_loadu_si512(w + 16 * s);
+            _mm512_storeu_pd(out + 8 * s, _mm512_mul_pd(_mm512_cvtepu64_pd(_mm512_srli_epi64(v, 11)), scale));
+        }
+    }
 #endif
 #undef LS_QR
 #undef LS_CHACHA_LANES
@@ -222,9 +278,9 @@ private:
         const uint64_t first = g << 4;
 #if defined(__x86_64__)
         if (have_avx512()) { blocks16(first, slot); return; }
-        if (have_avx2()) { blocks8(first, slot); blocks8(first + 8, slot + 8); return; }
+        if (have_avx2()) { blocks8(first, slot); blocks8(first + 8, slot + 8 * 16); return; }
 #endif
-        for (int q = 0; q < 4; q++) blocks4(first + 4 * (uint64_t)q, slot + 4 * q);
+        for (int q = 0; q < 4; q++) blocks4(first + 4 * (uint64_t)q, slot + 4 * q * 16);
     }
     uint32_t key_[8];
     uint64_t pos_ = 0;      // next word of the stream
@@ -618,6 +674,30 @@ inline bool weighted_have_avx512()
 }
 #endif
 
+#if defined(__x86_64__)
+// y = 1 / w for every weight (IEEE division, the scalar path's quotient); false if a weight is negative or NaN
+__attribute__((target("avx512f,avx512dq,avx512vl"))) inline bool weighted_exponents_avx512(const double *w, uint32_t length, double *ys, bool *all_ge1)
+{
+    const __m512d v1 = _mm512_set1_pd(1.0), v0 = _mm512_setzero_pd();
+    __mmask8 bad = 0, small = 0;
+    uint32_t i = 0;
+    for (; i + 8 <= length; i += 8) {
+        const __m512d x = _mm512_loadu_pd(w + i);
+        bad |= _mm512_cmp_pd_mask(x, v0, _CMP_NGE_UQ);   // !(w >= 0)
+        small |= _mm512_cmp_pd_mask(x, v1, _CMP_NGE_UQ); // !(w >= 1)
+        _mm512_storeu_pd(ys + i, _mm512_div_pd(v1, x));
+    }
+    bool bad_tail = false, small_tail = false;
+    for (; i < length; i++) {
+        bad_tail = bad_tail || !(w[i] >= 0.0);
+        small_tail = small_tail || !(w[i] >= 1.0);
+        ys[i] = 1.0 / w[i];
+    }
+    *all_ge1 = !small && !small_tail;
+    return !bad && !bad_tail;
+}
+#endif
+
 inline bool weighted_surrogate_on() // LS_HOST_EXACT_POW=1: order the survivors by libm pow keys (the round-2 path; tests run both)
 {
     static const bool v = std::getenv("LS_HOST_EXACT_POW") == nullptr;
@@ -652,14 +732,27 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, co
         for (int k = 0; k < 1024; k++) t[(size_t)k] = 1.0 / (double)k;
         return t;
     }();
-    for (uint32_t i = 0; i < length; i++) {
-        const double w = weights[i];
-        if (!(w >= 0.0)) throw std::runtime_error("invalid weight");
-        us[i] = rng.gen_f64();
-        const int wi = w < 1024.0 ? (int)w : -1;
-        ys[i] = (wi >= 0 && (double)wi == w) ? inv_small[(size_t)wi] : 1.0 / w;
-        prefilter = prefilter && w >= 1.0;
+    bool bulk = false;
+#if defined(__x86_64__)
+    if constexpr (std::is_same<R, ChaCha20Rng>::value) {
+        if (weighted_have_avx512()) { // the draws in one run of vector conversions, the exponents by vector division (the same IEEE quotients)
+            bool all_ge1 = true;
+            if (!weighted_exponents_avx512(weights.data(), length, ys.data(), &all_ge1)) throw std::runtime_error("invalid weight");
+            rng.fill_f64(us.data(), length);
+            prefilter = prefilter && all_ge1;
+            bulk = true;
+        }
     }
+#endif
+    if (!bulk)
+        for (uint32_t i = 0; i < length; i++) {
+            const double w = weights[i];
+            if (!(w >= 0.0)) throw std::runtime_error("invalid weight");
+            us[i] = rng.gen_f64();
+            const int wi = w < 1024.0 ? (int)w : -1;
+            ys[i] = (wi >= 0 && (double)wi == w) ? inv_small[(size_t)wi] : 1.0 / w;
+            prefilter = prefilter && w >= 1.0;
+        }
     double key_floor = 0.0; // where the surviving keys start (a hint for the bucket mapping of weighted_top)
     if (!prefilter) {
         keyed.resize(length);

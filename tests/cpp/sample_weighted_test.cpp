@@ -97,6 +97,24 @@ int main()
         if (weighted_surrogate_on() && weighted_surrogate_fallbacks() == 0) { printf("FAIL: the guard never fired (mode 2 crowds keys within 1e-11)\n"); return 1; }
     }
 #endif
+    // fill_f64 = n gen_f64 draws, from any position of the stream (odd word positions, runs across group seams, n < 8)
+    {
+        ChaCha20Rng pick = ChaCha20Rng::from_seed_string("fill");
+        for (int rep = 0; rep < 4000; rep++) {
+            ChaCha20Rng a = ChaCha20Rng::from_seed_string(("f" + std::to_string(rep % 7)).c_str());
+            const uint32_t skip = pick.next_u32() % 700, n = pick.next_u32() % (rep % 10 == 0 ? 5000 : 300);
+            for (uint32_t i = 0; i < skip; i++) (void)a.next_u32();
+            if (rep % 3 == 0) while (a.prefetch()) { }
+            ChaCha20Rng b = a;
+            std::vector<double> x(n), y(n);
+            a.fill_f64(x.data(), n);
+            for (uint32_t i = 0; i < n; i++) y[i] = b.gen_f64();
+            if (x != y || a.words_drawn() != b.words_drawn() || a.next_u64() != b.next_u64()) {
+                printf("fill_f64 differs from gen_f64: skip %u n %u\n", skip, n);
+                return 1;
+            }
+        }
+    }
     printf("OK\n");
     return 0;
 }
