@@ -87,7 +87,9 @@ def main():
         state = rng.integers(0, E, size=(1, S)).astype(np.int32)
         for _ in range(reps):
             r0 = ctx.sched_eval_exhaustive(state, 10 ** 9)[0]
-        blocks_ex = (S * E + 511) // 512
+        # the launcher takes 1 / 2 / 3 batches of 64 per wavefront: the first that leaves at most two blocks per CU (sched_launch_delta_pipeline)
+        bpw_ex = next((b for b in (1, 2) if (S * E + 512 * b - 1) // (512 * b) <= 2 * 256), 3)
+        blocks_ex = (S * E + 512 * bpw_ex - 1) // (512 * bpw_ex)
         meta["sched_eval_all_kernel_exhaustive"] = dict(candidates_per_launch=int(r0["n_scored"]),
                                                         workload="10 000 employees, exhaustive 32 x 10 000, candidates generated in the kernel",
                                                         match="sched_eval_all_kernel<unsigned int, 8, true>", grid_blocks=blocks_ex)
