@@ -279,13 +279,14 @@ def run_rank(args, rank, world, device, sync, launcher):
                 # what LS_NQ_ALGO_AUTO (the library default) gives a caller, next to the headline scan kernel: kept inside
                 # `roofline` so that it survives consumers that drop `extra`
                 tb, e2e = ex.get("table_full_neighbourhood", {}), ex.get("config4_end_to_end_64_restarts_one_gpu", {})
-                st1 = ex.get("fused_ls_step_host_round_trip_1_restarts", {})
+                st1 = ex.get("fused_ls_step_host_round_trip_1_restarts", {})  # (bare C entry where measured)
                 out["roofline"]["default_path"] = {
                     "table_neighbours_per_s": tb.get("neighbours_per_s"), "table_frac": (tb.get("roofline") or {}).get("frac"),
                     "table_bound": (tb.get("roofline") or {}).get("bound"),
                     "table_64_restarts_neighbours_per_s": ex.get("table_full_neighbourhood_64_restarts", {}).get("neighbours_per_s"),
                     "table_64_restarts_frac": (ex.get("table_full_neighbourhood_64_restarts", {}).get("roofline") or {}).get("frac"),
-                    "ls_step_round_trip_us_one_restart": st1.get("us_per_call"),
+                    "ls_step_round_trip_us_one_restart": st1.get("us_per_call_bare_c_entry") or st1.get("us_per_call"),
+                    "ls_step_round_trip_us_one_restart_through_the_python_wrapper": st1.get("us_per_call"),
                     "config4_end_to_end_s": e2e.get("seconds"), "config4_end_to_end_neighbours_per_s": e2e.get("neighbours_per_s"),
                     "config4_end_to_end_equals_single_solver_runs": (e2e.get("timed_run_vs_single_solver_runs_on_the_launch_per_call_route") or {}).get("equal")}
                 out["roofline"]["int_formulation"] = ex.get("scan_int_formulation_packed_u16")
@@ -666,9 +667,37 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True):
             step()
         s = (time.perf_counter() - t0) / reps
         c = kc.get(f"nq_step_kernel_r{RR}") or {}
+        raw_us = None
+        if RR == 1:
+            # the same loop on the bare C entry (arguments marshalled once): what a C / Rust caller pays per call
+            import ctypes as C
+            import ls_amd as _la
+            rows1, cur1 = np.ascontiguousarray(b_h[:1], np.int32), np.ascontiguousarray(c_h[:1], np.int64)
+            cols1, nc1 = np.ascontiguousarray(cols_h[:1], np.int32), np.ascontiguousarray(ncols_h[:1], np.int32)
+            res1, nxt1 = (_la.NqResult * 1)(), np.empty((1, n), dtype=np.int64)
+            vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+            cargs = (ctx._h, 1, n, vp(rows1), vp(cur1), vp(cols1), vp(nc1), int(cols1.shape[1]), 5 * n, C.cast(res1, C.c_void_p), vp(nxt1))
+            fn = ctx._l.ls_nqueens_eval_batch_next
+
+            def raw_step():
+                if fn(*cargs) != 0:
+                    raise RuntimeError(ctx._l.ls_last_error(ctx._h).decode())
+                r = res1[0]
+                if r.best_index >= 0:
+                    rows1[0, r.best_col] = r.best_value
+                    cur1[0] = r.best_score
+
+            for _ in range(200):
+                raw_step()
+            t0 = time.perf_counter()
+            for _ in range(5000):
+                raw_step()
+            raw_us = (time.perf_counter() - t0) / 5000 * 1e6
         out[f"fused_ls_step_host_round_trip_{RR}_restarts"] = {
             "us_per_call": s * 1e6, "candidates_per_call": RR * min(5 * n, mc * (n - 1)),
-            "note": "includes ctypes/numpy marshalling of the Python wrapper",
+            "us_per_call_bare_c_entry": raw_us,
+            "note": "us_per_call includes ctypes/numpy marshalling of the Python wrapper (about 8 us); us_per_call_bare_c_entry calls the C entry "
+                    "with arguments marshalled once (still a Python loop: about 1 us of interpreter per call)",
             "route": "resident LS-step server (no launch per call)" if RR == 1 and ctx.counters()["server_requests"] else "one fused LS-step launch per call",
             # a latency-bound launch: one 1024-thread block per restart; its issue bounds on the CUs it can occupy are a small
             # fraction of the kernel time, which is PCIe-free set-up, LDS round trips and the completion word
