@@ -1464,7 +1464,10 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_all_kernel(SchedEvalArgs a
     LS_SC_STAMP(2);
     // employee -> scored days of the base state (see sched_grid_server_kernel), zeroed by the whole block while its loads fly
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    M *const emp = a.emp_entries > 0 ? reinterpret_cast<M *>(s_dyn) : nullptr;
+    // (a device-resident state is not validated by the host entry: with an entry outside [0, E) the block compares day by day,
+    // as without the table -- the same answer for the same garbage, and no LDS access out of range; every wavefront decides alike)
+    const bool e_bad = lane < S && (unsigned)e_lane >= (unsigned)E;
+    M *const emp = a.emp_entries > 0 && __builtin_amdgcn_ballot_w64(e_bad) == 0 ? reinterpret_cast<M *>(s_dyn) : nullptr;
     if (emp) {
         const int n16 = (int)(((size_t)a.emp_entries * sizeof(M) + 15) / 16); // the launcher rounds the allocation up to 16 bytes
         for (int i = (int)threadIdx.x; i < n16; i += 64 * NW) reinterpret_cast<uint4 *>(s_dyn)[i] = make_uint4(0, 0, 0, 0);
