@@ -838,7 +838,7 @@ __global__ __launch_bounds__(256 * TEAMS) void nq_table_teams_kernel(NqArgs a, i
 
 
 template <int NT, int TL, bool WANT_SCORES>
-__global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts)
+__global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts, int whole_max /* min(window / (n - 1), max_cols): divided on the host */)
 {
     extern __shared__ unsigned s_t16[]; // packed u16: R[n] | R1[n] | A[2n+2] | B[2n+2], then int4 records [NQ_REC_CAP]
     constexpr int TEAMS = NT / TL;            // a team = TL lanes (one wavefront or four) walking one column
@@ -855,11 +855,11 @@ __global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts)
     const int *__restrict__ cols = a.cols + (long long)restart * a.max_cols;
     int ncols = a.n_cols[restart];
     ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
-    long long n_whole = a.window / (n - 1);
-    if (n_whole > ncols) n_whole = ncols;
-    const long long rem = n_whole < ncols ? a.window - n_whole * (n - 1) : 0;
-    const long long units = n_whole * parts;
-    const long long u0 = units * chunk / n_chunks, u1 = units * (chunk + 1) / n_chunks;
+    // (32-bit arithmetic: units <= 12288 columns x 24 parts and at most 1024 chunks -- a 64-bit division costs ~150 scalar instructions)
+    const int n_whole = whole_max < ncols ? whole_max : ncols;
+    const long long rem = n_whole < ncols ? a.window - (long long)n_whole * (n - 1) : 0;
+    const unsigned units = (unsigned)n_whole * (unsigned)parts;
+    const long long u0 = units * (unsigned)chunk / (unsigned)n_chunks, u1 = units * (unsigned)(chunk + 1) / (unsigned)n_chunks;
     const bool do_partial = rem > 0 && chunk == n_chunks - 1;
     unsigned long long best = NQ_KEY_EMPTY;
     LS_STAMP(0);
@@ -869,8 +869,8 @@ __global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts)
         int4 *s_rec = reinterpret_cast<int4 *>(s_t16 + words);
         // every global read of the set-up is issued before the first LDS store: the board (NT == 1024: into registers) and
         // the first pass's slot columns with their rows -- one memory latency instead of three in a row
-        const int slot_lo0 = (int)(u0 / parts);
-        const int slot_hi0 = u0 < u1 ? (int)((u1 - 1) / parts) : slot_lo0 - 1;
+        const int slot_lo0 = (int)((unsigned)u0 / (unsigned)parts);
+        const int slot_hi0 = u0 < u1 ? (int)((unsigned)(u1 - 1) / (unsigned)parts) : slot_lo0 - 1;
         int pre_c = -1, pre_rc = -1;
         if (tid < NQ_REC_CAP && slot_lo0 + tid <= slot_hi0) {
             pre_c = cols[slot_lo0 + tid];
@@ -910,8 +910,7 @@ __global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts)
         const long long cur = WANT_SCORES ? a.cur_scores[restart] : 0;
         const int steps = (n + 2 * TL - 1) >> (SH + 1);    // 2 TL values (TL pairs) per step
         const int per_part = (steps + parts - 1) / parts;
-        const int slot_lo = (int)(u0 / parts);
-        const int slot_hi = u0 < u1 ? (int)((u1 - 1) / parts) : slot_lo - 1; // inclusive
+        const int slot_lo = slot_lo0, slot_hi = slot_hi0; // inclusive
         for (int pass_lo = slot_lo; pass_lo <= slot_hi; pass_lo += NQ_REC_CAP) {
             const int pass_hi = pass_lo + NQ_REC_CAP - 1 < slot_hi ? pass_lo + NQ_REC_CAP - 1 : slot_hi;
             __syncthreads(); // the previous pass's records are no longer read
@@ -928,8 +927,13 @@ __global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts)
             long long ua = (long long)pass_lo * parts, ub = (long long)(pass_hi + 1) * parts;
             ua = ua < u0 ? u0 : ua;
             ub = ub > u1 ? u1 : ub;
-            for (long long u = ua + team; u < ub; u += TEAMS) { // team-uniform (team is an SGPR)
-                const int slot = (int)(u / parts), part = (int)(u - (long long)slot * parts);
+            // team-uniform (team is an SGPR).  (slot, part) of unit u are carried along instead of divided out per unit: a
+            // 64-bit division is ~150 scalar instructions, once per 32-step column walk it was a sixth of a wavefront's time
+            const unsigned first = (unsigned)(ua + team);
+            int slot = (int)(first / (unsigned)parts), part = (int)(first - (unsigned)slot * (unsigned)parts);
+            const int dq = TEAMS / parts, dr = TEAMS - dq * parts;
+            for (long long u = ua + team; u < ub; u += TEAMS, slot += dq, part += dr) {
+                if (part >= parts) { part -= parts; slot++; }
                 const int4 rec = s_rec[slot - pass_lo];
                 const int c = __builtin_amdgcn_readfirstlane(rec.x), rc = __builtin_amdgcn_readfirstlane(rec.y),
                           conf_old = __builtin_amdgcn_readfirstlane(rec.z);
@@ -1653,10 +1657,11 @@ static int launch_table_teams_t(ls_ctx *ctx, const NqArgs &a, long long window)
     long long want_blocks = (n_whole * parts + TEAMS - 1) / TEAMS;
     if (want_blocks < 1) want_blocks = 1;
     if (bpr > want_blocks) bpr = want_blocks;
+    while (bpr > 1 && n_whole * parts * bpr >= (1ll << 32)) bpr /= 2; // the kernels split units x chunk in 32 bits
+    if (n_whole * parts >= (1ll << 32)) return set_err(ctx, LS_ERR_UNSUPPORTED, "max_cols = %d is too large for the count-table kernels", a.max_cols);
     const dim3 grid((unsigned)(bpr * a.n_restarts));
-    void *args[] = {const_cast<NqArgs *>(&a), &parts};
-    int parts_i = (int)parts;
-    args[1] = &parts_i;
+    int parts_i = (int)parts, whole_max = (int)n_whole; // n_whole = min(window / (n - 1), max_cols) from above
+    void *args[] = {const_cast<NqArgs *>(&a), &parts_i, &whole_max}; // (the teams kernel takes the first two)
     LS_HIP(ctx, hipLaunchKernel(a.scores_out ? k_scores : k_plain, grid, dim3(NT), args, lds, ctx->stream));
     return LS_OK;
 }
