@@ -884,14 +884,20 @@ def sched_measurements(ctx, torch, dev, timed, issue_roofline):
                                                                  else "sched_eval_all_kernel_random65536", s)}
     # the same exhaustive neighbourhood through the host entry that generates the move list on the device:
     # only the 128-byte state and the 32-byte result cross PCIe (round trip incl. sync and the Python wrapper)
-    ctx.sched_eval_exhaustive(state_np, 10 ** 9)
+    before = ctx.counters()["server_requests"]
+    for _ in range(20):
+        ctx.sched_eval_exhaustive(state_np, 10 ** 9)
     t0 = time.perf_counter()
-    reps = 100
+    reps = 500
     for _ in range(reps):
         r0 = ctx.sched_eval_exhaustive(state_np, 10 ** 9)[0]
     s = (time.perf_counter() - t0) / reps
+    on_grid = ctx.counters()["server_requests"] - before >= reps
     out["sched10k_exhaustive_320k_host_round_trip_generated_on_device"] = {
-        "neighbours_per_s": r0["n_scored"] / s, "us_per_call": s * 1e6, "candidates_per_call": r0["n_scored"]}
+        "neighbours_per_s": r0["n_scored"] / s, "us_per_call": s * 1e6, "candidates_per_call": r0["n_scored"],
+        "route": "resident grid (no launch per call; candidates generated in the kernel, one workgroup per three 512-candidate chunks)" if on_grid
+                 else "two launches per call (sched_eval_all_kernel + sched_finish_kernel)",
+        "note": "includes about 4 us of ctypes / numpy marshalling in the Python wrapper (tools/exhaustive_grid_trace.py times the bare C entry)"}
     return out
 
 

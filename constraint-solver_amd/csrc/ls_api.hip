@@ -1108,6 +1108,8 @@ int ls_sched_eval_exhaustive(ls_ctx *ctx, int32_t n_restarts, const int32_t *sta
     int rc = sched_check_state(ctx, states, (long long)n_restarts * S);
     if (rc != LS_OK) return rc;
     const long long per = (long long)S * ctx->sched.n_employees;
+    // one state: the resident grid generates and scores the S x E candidates without a launch (sched_grid_server_kernel<GEN>)
+    if (n_restarts == 1 && sched_xgrid_eligible(ctx)) return sched_grid_eval(ctx, states, per, window, results, true);
     const size_t st_b = (size_t)n_restarts * S * 4, mv_b = (size_t)n_restarts * per * sizeof(ls_sched_move),
                  nm_b = (size_t)n_restarts * 8, res_b = (size_t)n_restarts * sizeof(ls_sched_result);
     bool handled = false;

@@ -229,7 +229,8 @@ void sched_server_counters(const ls_ctx *ctx, unsigned long long out[3]); // req
 bool sched_server_can_score(const ls_ctx *ctx);
 int sched_server_score(ls_ctx *ctx, const int32_t *state, int64_t *hard, int64_t *soft);
 bool sched_grid_eligible(const ls_ctx *ctx, long long n_moves);
-int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out);
+int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out, bool gen = false);
+bool sched_xgrid_eligible(const ls_ctx *ctx);
 int sched_server_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out);
 // ls_api.hip
 int nq_ctx_server(ls_ctx *ctx, int n, NqServer **out);

@@ -1702,7 +1702,7 @@ __global__ __launch_bounds__(256) void sched_exhaustive_moves_kernel(const int *
 // write-through store instruction; workgroup 0, the finisher, polls the records until all carry the tag (no acknowledgement
 // wait and no ticket in the workers), takes the prefix over the counts and the minima of the chunks inside the window, and
 // scores the chunk the window cuts AGAIN up to the window (cheaper than 512 key stores in every workgroup).
-// All workgroups must be resident at once: the launcher asks for at most two per CU.
+// All workgroups must be resident at once: the launcher asks for at most ONE per CU (the kernel needs 180-200 VGPRs).
 constexpr int SCG_STATE_AT = 16; // dword of the message that holds state[0]: the state fits lines 1..3 (S <= 48)
 
 struct SchedGridCtl {        // device memory
@@ -1720,9 +1720,13 @@ struct SchedGridArgs {
     unsigned long long ready_target; // g->ready once every workgroup of THIS launch has started (the host adds the grid size per launch)
     unsigned *rec;           // [n_chunks][8] every workgroup's record of the current request (tagged dwords)
     int emp_entries;         // entries of the workgroup's employee -> scored-days table in dynamic LDS (0: none, the scorers compare day by day)
+    int cpw;                 // 512-candidate chunks per workgroup (consecutive ones): 1 for a resident stream, up to four for the exhaustive proposer
 };
 
-template <typename M, int NW>
+// GEN: the candidates are those of the exhaustive proposer (ScheduleMoveProposer::iter_local_moves, lib.rs:493-559), generated in
+// place from the request's state -- no move list; a workgroup then takes a.cpw <= MAXC CONSECUTIVE chunks (32 x 10 000 candidates
+// are 625 chunks: three per workgroup on 209 CUs), still one record per workgroup.
+template <typename M, int NW, bool GEN, int MAXC>
 __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArgs a)
 {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1733,6 +1737,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
     __shared__ u64 s_key[NW];
     __shared__ long long s_idx[NW];
     __shared__ int s_cnt[NW];
+    __shared__ int s_cntc[MAXC][NW]; // real candidates per chunk and wavefront
     __shared__ unsigned s_req[64];
     __shared__ int s_ctl[2]; // [0] leave, [1] the request's tag
     __shared__ int s_cut;
@@ -1748,9 +1753,17 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
     // (Keeping the instance's holiday words in LDS -- 80 KB at 10 000 employees -- instead of gathering them from L2 per request was
     // tried: no change, 5.5 us from request to record either way; the workgroup's time is the delta scorer's dependent chain.)
     const SchedInst &in = a.in;
-    const long long k = (long long)c * (64 * NW) + tid; // this lane's move of the resident stream: loaded once
-    int mtype = -1, mma = 0, mmb = 0;
-    if (k < a.n_resident) { const ls_sched_move m = a.moves[k]; mtype = m.type; mma = m.a; mmb = m.b; }
+    const int cpw = a.cpw;
+    const long long k0 = (long long)c * cpw * (64 * NW) + tid; // this lane's candidates: k0 + 512 j, j < cpw
+    int mtype[MAXC], mma[MAXC], mmb[MAXC]; // resident stream: this lane's moves, loaded once
+#pragma unroll
+    for (int j = 0; j < MAXC; j++) {
+        mtype[j] = -1; mma[j] = 0; mmb[j] = 0;
+        if constexpr (!GEN) {
+            const long long k = k0 + (long long)j * (64 * NW);
+            if (j < cpw && k < a.n_resident) { const ls_sched_move m = a.moves[k]; mtype[j] = m.type; mma[j] = m.a; mmb[j] = m.b; }
+        }
+    }
     unsigned last_seq = 0;
     SrvPoll poll{0, 0, 0};
 #ifdef LS_NQ_STAMPS
@@ -1814,9 +1827,21 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         const int fin = (int)s_req[5] < nch ? (int)s_req[5] : 0; // the finisher of THIS request: the chunk the host expects the window to cut
         const int e_lane = lane < S ? (int)s_req[SCG_STATE_AT + lane] : -1 - lane;
         const int hol_base = wib == 0 ? sched_holiday_bit(in, e_lane, lane) : 0;
-        // ---- this workgroup's chunk (sched_eval_all_kernel with one batch per wavefront, keys not recorded)
-        const SchedEdit ed = sched_edit_of(e_lane, S, E, k < nm ? mtype : -1, mma, mmb);
-        const int hbits = sched_edit_hbits(in, ed);
+        // ---- this workgroup's chunks (sched_eval_all_kernel with one batch per wavefront and chunk, keys not recorded)
+        SchedEdit ed[MAXC];
+        int hbits[MAXC];
+#pragma unroll
+        for (int j = 0; j < MAXC; j++) {
+            const long long k = k0 + (long long)j * (64 * NW);
+            int ty = -1, xa = 0, xb = 0;
+            if (j < cpw) { // block-uniform
+                if constexpr (GEN) sched_gen_exhaustive(e_lane, E, k, ty, xa, xb); // every lane takes part in the shuffle
+                else { ty = mtype[j]; xa = mma[j]; xb = mmb[j]; }
+                if (k >= nm) ty = -1;
+            }
+            ed[j] = sched_edit_of(e_lane, S, E, ty, xa, xb);
+            hbits[j] = sched_edit_hbits(in, ed[j]);
+        }
 #ifdef LS_NQ_STAMPS
         { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); gst[2] = wall_clock64(); }
 #endif
@@ -1825,28 +1850,34 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         SCG_STAMP(3);
         u64 best_key = SC_KEY_EMPTY;
         long long best_idx = -1;
-        int cnt = 0;
-        if (ed.active) {
-            int hard, soft;
-            best_key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft, emp);
-            best_idx = k; cnt = 1;
+        u64 my_key[MAXC], my_bal[MAXC]; // this lane's own candidates: what the finisher needs if the window cuts ITS chunks
+#pragma unroll
+        for (int j = 0; j < MAXC; j++) {
+            my_key[j] = SC_KEY_EMPTY;
+            if (ed[j].active) {
+                int hard, soft;
+                my_key[j] = sched_delta_key<M>(T, D, e_lane, ed[j], hbits[j], hard, soft, emp);
+                if (my_key[j] < best_key) { best_key = my_key[j]; best_idx = k0 + (long long)j * (64 * NW); }
+            }
+            my_bal[j] = __ballot(ed[j].active);
+            if (lane == 0) s_cntc[j][wib] = __popcll(my_bal[j]);
         }
         SCG_STAMP(4);
-        const u64 my_key = best_key; // this lane's own candidate: what the finisher needs if the window cuts ITS chunk
-        const u64 my_bal = __ballot(ed.active);
-        cnt = __popcll(my_bal);
-        if (lane == 0) s_cnt[wib] = cnt;
         sched_block_min_key<NW>(best_key, best_idx, s_key, s_idx, lane, wib); // synchronises the block; valid in wavefront 0
-        int my_rank = __popcll(my_bal & ((2ull << lane) - 1)); // 1-based among the chunk's real candidates
-        for (int i = 0; i < NW; i++)
-            if (i < wib) my_rank += s_cnt[i];
+        int my_rank[MAXC], total = 0; // 1-based among the workgroup's real candidates, in candidate order (chunk, wavefront, lane)
+#pragma unroll
+        for (int j = 0; j < MAXC; j++) {
+            my_rank[j] = total + __popcll(my_bal[j] & ((2ull << lane) - 1));
+            for (int i = 0; i < NW; i++) {
+                if (i < wib) my_rank[j] += s_cntc[j][i];
+                total += s_cntc[j][i];
+            }
+        }
         // ---- this chunk's record: eight tagged dwords (count | key in four 16-bit pieces | index in two), ONE store by eight lanes,
         // no acknowledgement wait and no ticket: the request's finisher polls the records until all carry the tag
         if (wib == 0) {
-            int total = 0;
-            for (int i = 0; i < NW; i++) total += s_cnt[i];
             unsigned pay = 0;
-            if (lane == 0) pay = (unsigned)total;
+            if (lane == 0) pay = (unsigned)total; // <= 512 MAXC
             else if (lane <= 4) pay = (unsigned)(best_key >> (16 * (lane - 1))) & 0xffffu;
             else if (lane == 5) pay = (unsigned)best_idx & 0xffffu;
             else if (lane == 6) pay = (unsigned)(best_idx >> 16) & 0xffffu;
@@ -1899,28 +1930,37 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
             }
             const long long n_scored = window <= 0 ? 0 : (run < window ? run : window);
             const int cut = s_cut;
-            if (cut == c) { // the window cuts the finisher's own chunk, as the host expected: the keys are still in the lanes
+            if (cut == c) { // the window cuts the finisher's own chunks, as the host expected: the keys are still in the lanes
                 const long long need = window - s_before;
-                if (ed.active && my_rank <= need && my_key < fkey) { fkey = my_key; fidx = k; }
-            } else if (cut >= 0) { // another chunk: scored again here (same state, same table), up to the window
+#pragma unroll
+                for (int j = 0; j < MAXC; j++)
+                    if (ed[j].active && my_rank[j] <= need && my_key[j] < fkey) { fkey = my_key[j]; fidx = k0 + (long long)j * (64 * NW); }
+            } else if (cut >= 0) { // another workgroup's: scored again here (same state, same table), up to the window
                 const long long need = window - s_before;
-                const long long kk = (long long)cut * (64 * NW) + tid;
-                int ty = -1, xa = 0, xb = 0;
-                if (kk < nm) { const ls_sched_move m = a.moves[kk]; ty = m.type; xa = m.a; xb = m.b; }
-                const SchedEdit e2 = sched_edit_of(e_lane, S, E, ty, xa, xb);
-                const int hb2 = sched_edit_hbits(in, e2);
-                const u64 bal = __ballot(e2.active);
-                __syncthreads(); // s_cnt is reused
-                if (lane == 0) s_cnt[wib] = __popcll(bal);
-                __syncthreads();
-                int before = 0;
-                for (int i = 0; i < NW; i++)
-                    if (i < wib) before += s_cnt[i];
-                const long long rank = before + __popcll(bal & ((2ull << lane) - 1)); // 1-based among the chunk's real candidates
-                if (e2.active && rank <= need) {
-                    int hard, soft;
-                    const u64 key2 = sched_delta_key<M>(T, D, e_lane, e2, hb2, hard, soft, emp);
-                    if (key2 < fkey) { fkey = key2; fidx = kk; }
+                int done = 0; // real candidates of the chunks already walked
+                for (int j = 0; j < cpw && done < need; j++) { // block-uniform
+                    const long long kk = ((long long)cut * cpw + j) * (64 * NW) + tid;
+                    int ty = -1, xa = 0, xb = 0;
+                    if constexpr (GEN) sched_gen_exhaustive(e_lane, E, kk, ty, xa, xb);
+                    else if (kk < nm) { const ls_sched_move m = a.moves[kk]; ty = m.type; xa = m.a; xb = m.b; }
+                    if (kk >= nm) ty = -1;
+                    const SchedEdit e2 = sched_edit_of(e_lane, S, E, ty, xa, xb);
+                    const int hb2 = sched_edit_hbits(in, e2);
+                    const u64 bal = __ballot(e2.active);
+                    __syncthreads(); // s_cnt is reused
+                    if (lane == 0) s_cnt[wib] = __popcll(bal);
+                    __syncthreads();
+                    int before = done;
+                    for (int i = 0; i < NW; i++) {
+                        if (i < wib) before += s_cnt[i];
+                        done += s_cnt[i];
+                    }
+                    const long long rank = before + __popcll(bal & ((2ull << lane) - 1)); // 1-based among the workgroup's real candidates
+                    if (e2.active && rank <= need) {
+                        int hard, soft;
+                        const u64 key2 = sched_delta_key<M>(T, D, e_lane, e2, hb2, hard, soft, emp);
+                        if (key2 < fkey) { fkey = key2; fidx = kk; }
+                    }
                 }
             }
             SCG_STAMP(7);
@@ -2225,6 +2265,7 @@ struct SchedServer {
     unsigned long long grid_requests = 0;
     double t_wait = 0, t_call = 0;               // LS_AMD_TRACE
     unsigned long long dev_ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // stamps builds: the finisher's timeline
+    bool grid_gen = false;                // what the resident grid serves: the resident stream | the exhaustive proposer (one at a time)
     int grid_fin = 0;                     // the chunk the window cut in the last answer: the next request's finisher
     unsigned long long grid_fin_hits = 0; // requests whose window cut the finisher's own chunk
 };
@@ -2396,18 +2437,47 @@ int sched_server_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long
 }
 
 // ---- the resident grid behind ls_sched_eval_resident for lists beyond 512 moves
-static long long sched_grid_chunks(const ls_ctx *ctx) { return (ctx->sc_resident_n + 64 * SCS_NW - 1) / (64 * SCS_NW); }
+constexpr int SCG_MAXC = 4; // chunks per workgroup of the exhaustive grid, at most
+
+// workgroups of the grid and the chunks each takes.  Stream: one per 512 moves of the resident list.  Exhaustive proposer
+// (gen): S x E candidates, consecutive chunks per workgroup -- as few as leave one workgroup per CU.  (All workgroups must be
+// resident at once and the kernel needs 180-200 VGPRs: a CU holds ONE 512-thread workgroup of it, whatever the LDS says.)
+static long long sched_grid_workgroups(const ls_ctx *ctx, bool gen, int *cpw_out)
+{
+    const long long total = gen ? (long long)ctx->sched.n_days_stored * ctx->sched.n_employees : ctx->sc_resident_n;
+    const long long chunks = (total + 64 * SCS_NW - 1) / (64 * SCS_NW);
+    int cpw = 1;
+    if (gen) {
+        cpw = (int)((chunks + ctx->n_cus - 1) / ctx->n_cus);
+        if (cpw < 1) cpw = 1;
+    }
+    if (cpw_out) *cpw_out = cpw;
+    return (chunks + cpw - 1) / cpw;
+}
+static long long sched_grid_chunks(const ls_ctx *ctx) { return sched_grid_workgroups(ctx, false, nullptr); }
+
+// ls_sched_eval_exhaustive for one state on the resident grid: S x E candidates in at most 4 chunks for each of <= 2 x CUs workgroups
+bool sched_xgrid_eligible(const ls_ctx *ctx)
+{
+    int cpw = 1;
+    const long long per = (long long)ctx->sched.n_days_stored * ctx->sched.n_employees;
+    if (!(ctx->sched_server_on && ctx->sched_delta && ctx->sched.valid && per > 64 * SCS_NW && per < (1ll << 31) &&
+          ctx->sched.n_employees <= 32768 && ctx->sched.n_days_stored <= 64 - SCG_STATE_AT))
+        return false;
+    const long long wgs = sched_grid_workgroups(ctx, true, &cpw);
+    return cpw <= SCG_MAXC && wgs <= ctx->n_cus && wgs <= 64 * SCS_NW;
+}
 
 bool sched_grid_eligible(const ls_ctx *ctx, long long n_moves)
 {
-    // every workgroup must be resident at once: at most two 512-thread workgroups per CU are asked for (the kernel fits four)
+    // every workgroup must be resident at once: one 512-thread workgroup per CU
     return ctx->sched_server_on && ctx->sched_delta && ctx->sched.valid && n_moves > 64 * SCS_NW && n_moves <= ctx->sc_resident_n &&
            ctx->sched.n_employees <= 32768 && ctx->sched.n_days_stored <= 64 - SCG_STATE_AT && n_moves < (1ll << 31) &&
-           sched_grid_chunks(ctx) <= 2ll * ctx->n_cus &&  // co-residency: at most two workgroups per CU are asked for
+           sched_grid_chunks(ctx) <= ctx->n_cus &&        // co-residency: one workgroup per CU (180-200 VGPRs x 512 threads)
            sched_grid_chunks(ctx) <= 64 * SCS_NW;          // one record per finisher thread
 }
 
-int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out)
+int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out, bool gen)
 {
     static const bool trace_call = getenv("LS_AMD_TRACE") != nullptr;
     const auto TC0 = trace_call ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
@@ -2425,7 +2495,18 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
     for (int d = 0; d < S; d++)
         if (state[d] < 0 || state[d] >= E)
             return set_err(ctx, LS_ERR_INVALID, "state entry %d = %d is not an employee index in [0, %d)", d, state[d], E);
-    const long long nch = sched_grid_chunks(ctx);
+    if (s->grid.stream && s->grid_gen != gen) { // the grid serves the other kind of request: it leaves, the launch below is of this kind
+        LS_HIP(ctx, hipSetDevice(ctx->device));
+        if (!s->grid.drained()) {
+            const unsigned tag = s->grid.next_tag(0);
+            volatile unsigned *dst = s->grid.req(0);
+            for (int d = 0; d < 16; d++) dst[d] = (tag << 16) | (d == 0 ? SRV_F_QUIT : 0u);
+        }
+        LS_HIP(ctx, hipStreamSynchronize(s->grid.stream));
+        s->grid_fin = 0;
+    }
+    s->grid_gen = gen;
+    const long long nch = sched_grid_workgroups(ctx, gen, nullptr);
     if (!s->grid.stream) {
         LS_HIP(ctx, hipSetDevice(ctx->device));
         const int rc = s->grid.init(ctx, "scheduling grid server", 4, 0); // four lines = one message
@@ -2435,22 +2516,26 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
         LS_HIP(ctx, hipGetLastError());
         LS_HIP(ctx, hipStreamSynchronize(s->grid.stream));
         s->grid.launch = [s, ctx](const SrvLink &L) {
-            const long long n = sched_grid_chunks(ctx);
+            const bool gen = s->grid_gen;
+            int cpw = 1;
+            const long long n = sched_grid_workgroups(ctx, gen, &cpw);
             SchedGridArgs a;
             a.link = L;
             a.in = make_inst(ctx);
-            a.moves = ctx->sc_resident_moves.as<ls_sched_move>();
-            a.n_resident = ctx->sc_resident_n;
+            a.moves = gen ? nullptr : ctx->sc_resident_moves.as<ls_sched_move>();
+            a.n_resident = gen ? (long long)ctx->sched.n_days_stored * ctx->sched.n_employees : ctx->sc_resident_n;
+            a.cpw = cpw;
             a.g = s->g;
             s->ready_total += (unsigned long long)n;
             a.ready_target = s->ready_total;
             a.rec = s->ws.as<unsigned>();
             void *args[] = {&a};
             const bool m32 = ctx->sched.n_days_stored <= 32 && !ctx->sched_force_64;
-            const void *fn = m32 ? reinterpret_cast<const void *>(&sched_grid_server_kernel<unsigned, SCS_NW>)
-                                 : reinterpret_cast<const void *>(&sched_grid_server_kernel<u64, SCS_NW>);
-            // the employee -> scored-days table: when no CU has to hold two workgroups
-            const size_t dyn = n > ctx->n_cus ? 0 : sched_emp_table_bytes(ctx, fn, m32);
+            const void *fn = gen ? (m32 ? reinterpret_cast<const void *>(&sched_grid_server_kernel<unsigned, SCS_NW, true, SCG_MAXC>)
+                                        : reinterpret_cast<const void *>(&sched_grid_server_kernel<u64, SCS_NW, true, SCG_MAXC>))
+                                 : (m32 ? reinterpret_cast<const void *>(&sched_grid_server_kernel<unsigned, SCS_NW, false, 1>)
+                                        : reinterpret_cast<const void *>(&sched_grid_server_kernel<u64, SCS_NW, false, 1>));
+            const size_t dyn = sched_emp_table_bytes(ctx, fn, m32); // the employee -> scored-days table (one workgroup per CU: it has the LDS to itself)
             a.emp_entries = dyn ? ctx->sched.n_employees : 0;
             return hipLaunchKernel(fn, dim3((unsigned)n), dim3(64 * SCS_NW), args, dyn, s->grid.stream);
         };

@@ -476,3 +476,65 @@ def test_sched_grid_server_long_lists(monkeypatch):
             assert (cnt["server_requests"] >= 40) == (server != "0")
         results[server] = got
     assert results["1"] == results["0"] == results["1 day-by-day"]
+
+
+def test_sched_exhaustive_grid(monkeypatch):
+    # ls_sched_eval_exhaustive for ONE state on the resident grid (sched_grid_server_kernel<GEN>): the S x E candidates of the
+    # exhaustive proposer (lib.rs:493-559) are generated in place, a workgroup takes up to four consecutive 512-candidate
+    # chunks, one record per workgroup, the finisher is the workgroup the window cut last time.  Windows that cut inside the
+    # first / a middle / the last chunk of a workgroup, on workgroup seams, beyond everything, 1; states with few distinct
+    # employees (many no-ops per chunk); alternating with the resident-STREAM grid (one grid at a time: each switch relaunches);
+    # a new instance under a live grid.  Against the oracle and against the launched pipeline (LS_SCHED_SERVER=0).
+    import ls_amd
+    monkeypatch.setenv("LS_NQ_SERVER_IDLE_US", "500")
+    rng = np.random.default_rng(4242)
+    results = {}
+    for server in ("1", "1 day-by-day", "0"):
+        monkeypatch.setenv("LS_SCHED_SERVER", server[0])
+        if server == "1 day-by-day":
+            monkeypatch.setenv("LS_SCHED_NO_EMP_TABLE", "1")
+        else:
+            monkeypatch.delenv("LS_SCHED_NO_EMP_TABLE", raising=False)
+        prng = np.random.default_rng(17)
+        got = []
+        with ls_amd.Context(0) as c:
+            for E, span in ((9000, ((2022, 5, 9), (2022, 6, 8))), (700, ((2022, 5, 9), (2022, 6, 8))), (300, ((2022, 5, 9), (2022, 6, 20)))):
+                hol = {int(e): list(prng.choice(20, size=2, replace=False)) for e in prng.choice(E, size=E // 3, replace=False)}
+                inst = orc.Sched(span[0], span[1], hol)
+                D, S = inst.n_scored_days, inst.n_scored_days + 1
+                bits = np.zeros(E, dtype=np.uint64)
+                for e, ds in hol.items():
+                    for d in ds:
+                        bits[e] |= np.uint64(1) << np.uint64(int(d))
+                c.sched_instance_upload(D, S, inst.start_weekday, E, bits)
+                per = S * E
+                stream = _random_moves(prng, 3000, D, E)
+                c.sched_moves_upload(stream)
+                state = prng.integers(0, E, size=S)
+                for it in range(10 if E == 9000 else 14):
+                    if it % 4 == 3:
+                        state = prng.integers(0, 5, size=S)                # few distinct employees
+                    real = S * (E - 1)
+                    w = int(prng.choice([10 ** 9, real, real - 1, 1, 511, 512, 513, 1536, 1537, per // 2, int(prng.integers(1, real)),
+                                         int(prng.integers(1, real))]))
+                    r = c.sched_eval_exhaustive(state[None, :], w)[0]
+                    exp = inst.neighbourhood(state, orc.Sched.exhaustive_moves(state, range(E)), w)
+                    assert (r["n_scored"], r["best_index"]) == (exp["n_scored"], exp["best_index"]), (server, E, it, w)
+                    if exp["best_index"] >= 0:
+                        assert (r["best_hard"], r["best_soft"]) == (exp["best_hard"], exp["best_soft"])
+                    got.append(r)
+                    if it % 3 == 1:                                        # the stream grid in between: the other kind of request
+                        rs = c.sched_eval_resident(state, len(stream), 2500)
+                        es = inst.neighbourhood(state, stream, 2500)
+                        assert (rs["n_scored"], rs["best_index"]) == (es["n_scored"], es["best_index"])
+                        got.append(rs)
+                    if r["best_index"] >= 0 and it % 2 == 0:               # continue from the winner
+                        d, i = divmod(r["best_index"], E)
+                        state = state.copy()
+                        state[d] = (state[d] + 1 + i) % E
+                    if it == 6:
+                        time.sleep(0.01)                                   # the launch leaves (idle) and comes back
+            cnt = c.counters()
+            assert (cnt["server_requests"] > 30) == (server != "0")
+        results[server] = got
+    assert results["1"] == results["0"] == results["1 day-by-day"]
