@@ -701,7 +701,8 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True):
             "route": "resident LS-step server (no launch per call)" if RR == 1 and ctx.counters()["server_requests"] else "one fused LS-step launch per call",
             # a latency-bound launch: one 1024-thread block per restart; its issue bounds on the CUs it can occupy are a small
             # fraction of the kernel time, which is PCIe-free set-up, LDS round trips and the completion word
-            "kernel": {k: c.get(k) for k in ("duration_us", "valu_issue_bound_us", "lds_array_bound_us", "cus_usable", "roofline", "source")} if c else None}
+            ("launched_kernel_of_the_launch_per_call_route_LS_NQ_STEP_3" if RR == 1 and ctx.counters()["server_requests"] else "kernel"):
+                {k: c.get(k) for k in ("duration_us", "valu_issue_bound_us", "lds_array_bound_us", "cus_usable", "roofline", "source")} if c else None}
     if e2e:
         out["config4_end_to_end_64_restarts_one_gpu"] = config4_end_to_end(ctx, n)
         out.update(single_restart_end_to_end(ctx))
