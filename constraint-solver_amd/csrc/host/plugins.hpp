@@ -339,12 +339,10 @@ struct NQueensProblem {
         const_cast<NQueensProblem *>(this)->n_conf += conflict_cols.size();
         const std::vector<uint32_t> picked = index_sample_weighted(rng, weights, (uint32_t)amount);
         const_cast<NQueensProblem *>(this)->t_samp += std::chrono::duration<double>(std::chrono::steady_clock::now() - TA).count();
-        std::vector<uint32_t> cols;
-        for (uint32_t i : picked) cols.push_back(conflict_cols[i]);
-        const uint64_t num_cols = gen_range_u64_incl(rng, 1, cols.size());
-        const std::vector<uint32_t> order = index_sample(rng, (uint32_t)cols.size(), (uint32_t)num_cols);
-        std::vector<int32_t> out;
-        for (uint32_t i : order) out.push_back((int32_t)cols[i]);
+        const uint64_t num_cols = gen_range_u64_incl(rng, 1, picked.size());
+        const std::vector<uint32_t> order = index_sample(rng, (uint32_t)picked.size(), (uint32_t)num_cols);
+        std::vector<int32_t> out(order.size());
+        for (size_t k = 0; k < order.size(); k++) out[k] = (int32_t)conflict_cols[picked[order[k]]]; // cols[i] = conflict_cols[picked[i]]
         return out;
     }
 

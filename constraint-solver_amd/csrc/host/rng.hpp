@@ -382,16 +382,24 @@ template <class R> inline std::vector<uint32_t> index_sample(R &rng, uint32_t le
         const bool floyd_shuffle = amount < 50;
         std::vector<uint32_t> idx;
         idx.reserve(amount);
+        // membership by bitmap (the reference scans the vector: the same answer; the N-queens proposer draws ~100 of ~200 here
+        // every LS iteration, ~5000 compares per call otherwise); the position is only searched for when it is needed
+        uint64_t small_map[64] = {0};
+        std::vector<uint64_t> big_map;
+        uint64_t *map = small_map;
+        if (length > 64 * 64) { big_map.assign(((size_t)length + 63) / 64, 0); map = big_map.data(); }
+        auto has = [&](uint32_t v) { return (map[v >> 6] >> (v & 63)) & 1u; };
+        auto put = [&](uint32_t v) { map[v >> 6] |= 1ull << (v & 63); };
         for (uint32_t j = length - amount; j < length; j++) {
             const uint32_t t = gen_range_u32_incl(rng, 0, j);
-            if (floyd_shuffle) {
-                auto pos = std::find(idx.begin(), idx.end(), t);
-                if (pos != idx.end()) { idx.insert(pos, j); continue; }
-            } else if (std::find(idx.begin(), idx.end(), t) != idx.end()) {
-                idx.push_back(j);
+            if (has(t)) {
+                if (floyd_shuffle) idx.insert(std::find(idx.begin(), idx.end(), t), j);
+                else idx.push_back(j);
+                put(j);
                 continue;
             }
             idx.push_back(t);
+            put(t);
         }
         if (!floyd_shuffle)
             for (uint32_t i = amount; i-- > 1;) std::swap(idx[i], idx[gen_range_u32_incl(rng, 0, i)]);
