@@ -208,6 +208,7 @@ struct NQueensProblem {
     // while it waits for a launch of this context (here: computing the generator's key stream ahead); fn returns false
     // once there is nothing left to do.  nullptr arguments clear it.
     void (*set_idle_work)(ls_ctx *, bool (*fn)(void *), void *arg) = nullptr;
+    int64_t last_move_col = -1; // the column the previous best_of_neighbourhood call moved (fast route), -1: none
 
     static const int64_t *rows_dummy() { static const int64_t z = 0; return &z; }
     std::vector<int32_t> pack(const Solution &s) const
@@ -374,6 +375,8 @@ struct NQueensProblem {
         const auto T0 = std::chrono::steady_clock::now();
         const std::vector<int32_t> cols = propose_columns(current.solution, rng, continued);
         cache_is_last_winner = false; // until this call has put its winner into the cache (the general-tabu route does not)
+        const int64_t prev_move_col = last_move_col;
+        last_move_col = -1;           // until this call has moved a queen on the fast route below
         if (cols.empty()) return false;
         // propose_columns has just looked the current board up: it is the cached one (already packed) in the steady state
         const bool cur_is_cached = last_lookup_hit && cached_rows32.size() == current.solution.size();
@@ -440,9 +443,16 @@ struct NQueensProblem {
                                          " best_col " + std::to_string(res.best_col) + " best_value " + std::to_string(res.best_value) +
                                          " cur " + std::to_string(current.score) + " sum(next col scores) " + std::to_string(sum));
         }
-        out.solution = current.solution;
+        // `continued`: LocalSearch vouches that `out` still holds the board `current` was derived from (it swaps the two after
+        // every accepted move, local_search.hpp) -- they differ in the one column of the previous move, so one entry is
+        // repaired instead of 8n bytes copied
+        if (continued && prev_move_col >= 0 && out.solution.size() == current.solution.size())
+            out.solution[(size_t)prev_move_col] = current.solution[(size_t)prev_move_col];
+        else
+            out.solution = current.solution;
         out.solution[(size_t)res.best_col] = res.best_value; // MoveIterator, lib.rs:226-228
         out.score = res.best_score;
+        last_move_col = res.best_col;
         // the loop continues from this board (local_search.rs:335): its column scores came back with the result
         if (cur_is_cached) { // cached_board == current.solution: apply the move in place
             cached_board[(size_t)res.best_col] = res.best_value;

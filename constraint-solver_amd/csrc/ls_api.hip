@@ -92,7 +92,13 @@ int nq_ctx_server(ls_ctx *ctx, int n, NqServer **out)
     *out = nullptr;
     if (ctx->server && nq_server_n(ctx->server) == n) { *out = ctx->server; return LS_OK; }
     if (ctx->server && !ctx->server_owned) return LS_OK;
-    if (ctx->server) { nq_server_destroy(ctx->server); ctx->server = nullptr; }
+    if (ctx->server) { // another n: the context's own server is replaced; its counters stay in the context's totals
+        unsigned long long c4[4];
+        nq_server_counters(ctx->server, c4);
+        for (int i = 0; i < 4; i++) ctx->server_retired[i] += c4[i];
+        nq_server_destroy(ctx->server);
+        ctx->server = nullptr;
+    }
     NqServer *s = nullptr;
     const int rc = nq_server_create(ctx, n, 1, &s);
     if (rc != LS_OK) return rc;
@@ -262,7 +268,12 @@ int ls_ctx_get_counters(const ls_ctx *ctx, uint64_t out[LS_N_COUNTERS])
 {
     if (!ctx || !out) return LS_ERR_INVALID;
     for (int i = 0; i < LS_N_COUNTERS; i++) out[i] = 0;
-    if (ctx->server) {
+    for (int i = 0; i < 4; i++) out[i] = ctx->server_retired[i]; // servers of earlier board sizes
+    if (ctx->server && ctx->server_owned) {
+        unsigned long long c4[4];
+        nq_server_counters(ctx->server, c4);
+        for (int i = 0; i < 4; i++) out[i] += c4[i];
+    } else if (ctx->server) {
         unsigned long long c4[4];
         nq_server_counters(ctx->server, c4);
         for (int i = 0; i < 4; i++) out[i] = c4[i];

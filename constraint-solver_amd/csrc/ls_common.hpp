@@ -157,6 +157,7 @@ struct ls_ctx {
     lsamd::NqServer *server = nullptr; // the server this context's one-restart LS steps go to (own: started on demand; or a slot of a shared one)
     int server_slot = 0;
     bool server_owned = false;
+    unsigned long long server_retired[4] = {0, 0, 0, 0}; // counters of this context's earlier LS-step servers (one per board size)
     unsigned long long n_done_fallbacks = 0;   // completion-word waits that fell back to hipStreamSynchronize (2 ms without the word)
     unsigned long long n_resident_uploads = 0; // LS_NQ_STEP=3: boards uploaded because they were not the one resident on the device
     // Argmin keys: every entry of nq_keys holds NQ_KEY_EMPTY whenever no N-queens call is in flight (filled once, in
