@@ -486,7 +486,7 @@ inline void weighted_top(std::vector<WeightedKey> &keyed, uint32_t amount, std::
     static thread_local std::vector<uint8_t> bucket;
     const uint32_t length = (uint32_t)keyed.size();
     constexpr int BMAX = 256;
-    const int B = length <= 512 ? 64 : BMAX;
+    const int B = length <= 128 ? 64 : BMAX; // (256 buckets from 129 keys on: the proposer's ~280 survivors crowd 64 buckets unevenly)
     if (!(key_floor < key_ceil)) key_floor = key_ceil - 1.0;
     const double scale = (double)B / (key_ceil - key_floor);
     uint32_t hist[BMAX];
