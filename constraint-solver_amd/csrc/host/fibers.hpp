@@ -24,6 +24,7 @@
 
 #include <sched.h>
 #include <sys/mman.h>
+#include <time.h>
 
 #include <atomic>
 #include <cstdint>
@@ -299,9 +300,15 @@ private:
                     if (live_.load(std::memory_order_acquire) == 0) break;
                     (void)steal(self);
                     if (w.n_mine.load(std::memory_order_relaxed) == 0) { // nothing to take: the others run one fibre each
-                        if (++idle > 64) { sched_yield(); idle = 0; }
-                        else for (int k = 0; k < 32; k++) __builtin_ia32_pause();
-                    }
+                        // back off: spin, then yield, then sleep -- at the tail of a run most workers are here while the longest
+                        // restarts finish on the others, and a spinning hyper-thread takes issue slots from its busy sibling
+                        if (++idle <= 64) { for (int k = 0; k < 32; k++) __builtin_ia32_pause(); }
+                        else if (idle <= 64 + 16) sched_yield();
+                        else {
+                            struct timespec ts = {0, 20000}; // 20 us
+                            nanosleep(&ts, nullptr);
+                        }
+                    } else idle = 0;
                 } else {
                     __builtin_ia32_pause(); // all of this worker's fibres wait for the GPU
                 }

@@ -170,19 +170,24 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
                     if (rc < 0) continue;
                     nq_pairs_unit<64, false>(s_t16, n, lane, c, rc, conf_old, slot, part * per_part, per_part, nullptr, 0, best);
                 }
-                if (rem > 0) { // the slot the window cuts: per-range loops, all lanes
+                // the slot the window cuts: per-range loops.  A short remainder (window 5n leaves FIVE candidates for the sixth
+                // column) is one wavefront's job -- the one the unit round-robin reaches next, idle or least loaded -- instead of
+                // three dependent LDS round trips in all sixteen; a long one is walked by all lanes.
+                const bool rem_one_wave = rem <= 256;
+                if (rem > 0 && (!rem_one_wave || team == (units & 15))) { // wave-uniform
                     const int slot = n_whole;
                     int c, rc, conf_old;
                     slot_record(slot, c, rc, conf_old);
                     if (rc >= 0) {
                         const unsigned short *t16 = reinterpret_cast<const unsigned short *>(s_t16);
                         const NqRanges rg = nq_ranges(0, n, rc, 0, rem); // `rem` candidates are left for this column
+                        const int first = rem_one_wave ? lane : tid, stride = rem_one_wave ? 64 : 1024;
                         unsigned m = NQ_KEY32_EMPTY;
-                        for (int v = rg.d0 + tid; v < rg.d1; v += 1024) {
+                        for (int v = rg.d0 + first; v < rg.d1; v += stride) {
                             const unsigned kk = (((unsigned)t16[v] + (unsigned)t16[oA + v - c + n] + (unsigned)t16[oB + v + c]) << 15) | (unsigned)v;
                             m = kk < m ? kk : m;
                         }
-                        for (int v = rg.u0 + tid; v < rg.u1; v += 1024) {
+                        for (int v = rg.u0 + first; v < rg.u1; v += stride) {
                             const unsigned kk = (((unsigned)t16[v] + (unsigned)t16[oA + v - c + n] + (unsigned)t16[oB + v + c]) << 15) | (unsigned)v;
                             m = kk < m ? kk : m;
                         }
