@@ -1050,7 +1050,10 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
     const int S = ctx->sched.n_days_stored;
     // no launch and, in the steady state, no runtime call: the resident workgroup (<= 512 moves) or the resident grid
     if (sched_server_eligible(ctx, n_moves)) return sched_server_eval(ctx, state, n_moves, window, out);
-    if (sched_grid_eligible(ctx, n_moves)) return sched_grid_eval(ctx, state, n_moves, window, out);
+    if (sched_grid_eligible(ctx, n_moves)) {
+        const int rc_g = sched_grid_eval(ctx, state, n_moves, window, out);
+        if (rc_g != SRV_RC_GIVE_UP) return rc_g; // else: the grid cannot be resident now -- the launched pipeline below
+    }
     LS_BIND(ctx);
     int rc = sched_check_state(ctx, state, S);
     if (rc != LS_OK) return rc;
@@ -1120,7 +1123,10 @@ int ls_sched_eval_exhaustive(ls_ctx *ctx, int32_t n_restarts, const int32_t *sta
     if (rc != LS_OK) return rc;
     const long long per = (long long)S * ctx->sched.n_employees;
     // one state: the resident grid generates and scores the S x E candidates without a launch (sched_grid_server_kernel<GEN>)
-    if (n_restarts == 1 && sched_xgrid_eligible(ctx)) return sched_grid_eval(ctx, states, per, window, results, true);
+    if (n_restarts == 1 && sched_xgrid_eligible(ctx)) {
+        const int rc_g = sched_grid_eval(ctx, states, per, window, results, true);
+        if (rc_g != SRV_RC_GIVE_UP) return rc_g; // else: the grid cannot be resident now -- the launched pipeline below
+    }
     const size_t st_b = (size_t)n_restarts * S * 4, mv_b = (size_t)n_restarts * per * sizeof(ls_sched_move),
                  nm_b = (size_t)n_restarts * 8, res_b = (size_t)n_restarts * sizeof(ls_sched_result);
     bool handled = false;

@@ -136,6 +136,7 @@ struct NqResident {
 // The resident LS-step server (nq_server.hip): one never-ending launch per device whose workgroups are the slots.
 struct NqServer;
 struct SchedServer; // sched_kernels.hip: the resident scheduling LS step (one workgroup per context)
+constexpr int SRV_RC_GIVE_UP = 1; // internal (never crosses the ABI): a resident launch could not serve the request, the caller takes the launched route
 
 struct SchedInstance {
     bool valid = false;

@@ -1738,6 +1738,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
     __shared__ long long s_idx[NW];
     __shared__ int s_cnt[NW];
     __shared__ int s_cntc[MAXC][NW]; // real candidates per chunk and wavefront
+    __shared__ int s_quit;           // the finisher: the launch is leaving, the records will not come
     __shared__ unsigned s_req[64];
     __shared__ int s_ctl[2]; // [0] leave, [1] the request's tag
     __shared__ int s_cut;
@@ -1765,6 +1766,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         }
     }
     unsigned last_seq = 0;
+    bool abort_launch = false; // workgroup 0: the workgroups of this launch are not all resident -- nothing is served, everybody leaves
     SrvPoll poll{0, 0, 0};
 #ifdef LS_NQ_STAMPS
     unsigned long long gst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // workgroup 0: request seen, go record out, edit + holiday bits in, table built, chunk scored, own chunk recorded, all records in, cut chunk scored, answer
@@ -1784,7 +1786,11 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                 if (all || wall_clock64() - t0 > a.link.idle_ticks) break;
                 __builtin_amdgcn_s_sleep(8);
             }
-            if (!all && lane == 0) // they cannot all be resident: everybody leaves (the polls below see the quit word)
+            // they cannot all be resident: everybody leaves -- the others when their poll sees the quit word, this workgroup
+            // WITHOUT looking at the mailbox (srv_poll_wait hands out a pending request before it looks at the quit word, and a
+            // request served without the other workgroups would never see their records)
+            abort_launch = !all;
+            if (!all && lane == 0)
                 __hip_atomic_store(&a.link.ctl->quit_gen, a.link.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -1793,7 +1799,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
             int leave = 0;
             if (c == 0) { // the master: host mailbox -> go record, verbatim
                 unsigned raw = 0;
-                leave = srv_poll_wait<64>(poll, a.link, a.link.req, s_req, lane, &raw);
+                leave = abort_launch ? 1 : srv_poll_wait<64>(poll, a.link, a.link.req, s_req, lane, &raw);
                 SCG_STAMP(0);
                 if (!leave) {
                     __hip_atomic_store(&a.g->go[lane], raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1891,6 +1897,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
             long long fidx = -1, run = 0;
             // every workgroup's record of THIS request (nch <= 64 NW: one record per thread)
             unsigned rv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            bool given_up = false;
             for (;;) {
                 bool ok = true;
                 if (tid < nch) {
@@ -1899,8 +1906,13 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
 #pragma unroll
                     for (int d = 0; d < 7; d++) ok = ok && (rv[d] >> 16) == last_seq_all;
                 }
+                // the exit every poll loop of a resident kernel needs: records that never come (the launch is leaving)
+                if (tid == 0) s_quit = __hip_atomic_load(&a.link.ctl->quit_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.link.gen;
                 if (__syncthreads_and(ok ? 1 : 0)) break;
+                if (s_quit) { given_up = true; break; } // block-uniform: written before the barrier above
+                __syncthreads(); // ... and read by everybody before thread 0 writes it again
             }
+            if (given_up) continue; // no answer: the host's wait finds the launch drained
             SCG_STAMP(6);
             if (window > 0) {
                 const int b = tid;
@@ -2265,6 +2277,7 @@ struct SchedServer {
     unsigned long long grid_requests = 0;
     double t_wait = 0, t_call = 0;               // LS_AMD_TRACE
     unsigned long long dev_ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // stamps builds: the finisher's timeline
+    bool grid_unavailable = false;        // the grid's workgroups could not all be resident (another context's grid holds the CUs): not tried again
     bool grid_gen = false;                // what the resident grid serves: the resident stream | the exhaustive proposer (one at a time)
     int grid_fin = 0;                     // the chunk the window cut in the last answer: the next request's finisher
     unsigned long long grid_fin_hits = 0; // requests whose window cut the finisher's own chunk
@@ -2459,6 +2472,7 @@ static long long sched_grid_chunks(const ls_ctx *ctx) { return sched_grid_workgr
 // ls_sched_eval_exhaustive for one state on the resident grid: S x E candidates in at most 4 chunks for each of <= 2 x CUs workgroups
 bool sched_xgrid_eligible(const ls_ctx *ctx)
 {
+    if (ctx->sched_server && ctx->sched_server->grid_unavailable) return false;
     int cpw = 1;
     const long long per = (long long)ctx->sched.n_days_stored * ctx->sched.n_employees;
     if (!(ctx->sched_server_on && ctx->sched_delta && ctx->sched.valid && per > 64 * SCS_NW && per < (1ll << 31) &&
@@ -2470,6 +2484,7 @@ bool sched_xgrid_eligible(const ls_ctx *ctx)
 
 bool sched_grid_eligible(const ls_ctx *ctx, long long n_moves)
 {
+    if (ctx->sched_server && ctx->sched_server->grid_unavailable) return false;
     // every workgroup must be resident at once: one 512-thread workgroup per CU
     return ctx->sched_server_on && ctx->sched_delta && ctx->sched.valid && n_moves > 64 * SCS_NW && n_moves <= ctx->sc_resident_n &&
            ctx->sched.n_employees <= 32768 && ctx->sched.n_days_stored <= 64 - SCG_STATE_AT && n_moves < (1ll << 31) &&
@@ -2511,6 +2526,7 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
         LS_HIP(ctx, hipSetDevice(ctx->device));
         const int rc = s->grid.init(ctx, "scheduling grid server", 4, 0); // four lines = one message
         if (rc != LS_OK) return rc;
+        s->grid.relaunch_limit = 2;
         LS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&s->g), 512));
         hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(64), 0, s->grid.stream, reinterpret_cast<long long *>(s->g), 0ll, 64ll);
         LS_HIP(ctx, hipGetLastError());
@@ -2574,6 +2590,10 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
     const auto T1 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     unsigned r[8];
     const int rc = s->grid.wait(ctx, 0, r);
+    if (rc == SRV_RC_GIVE_UP) { // the workgroups could not all be resident (twice): this context launches per call from now on
+        s->grid_unavailable = true;
+        return SRV_RC_GIVE_UP;
+    }
     if (rc != LS_OK) return rc;
     if (trace) {
         s->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - T1).count();

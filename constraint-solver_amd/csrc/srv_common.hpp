@@ -163,6 +163,7 @@ struct SrvHost {
     std::atomic<unsigned long long> launch_gen{0};
     std::atomic<unsigned long long> relaunches{0}, slow_waits{0}, requests{0};
     bool failed = false;
+    unsigned relaunch_limit = 0;  // wait(): give up (SRV_RC_GIVE_UP) after this many relaunches under one request; 0: never
     std::vector<unsigned> tags;   // last tag posted per slot
     std::function<hipError_t(const SrvLink &)> launch; // set by the owner: starts the resident kernel on `stream`
 
@@ -268,6 +269,7 @@ struct SrvHost {
         bool idle_work = ctx->idle_hook != nullptr;
         std::chrono::steady_clock::time_point t0;
         bool timed = false;
+        unsigned relaunched_here = 0;
         for (unsigned spins = 0;; spins++) {
             unsigned v[8];
             bool ok = true;
@@ -287,6 +289,9 @@ struct SrvHost {
                 // has the launch drained under the request (idle time-out, age limit)?  Then it is launched again and finds the request.
                 if (drained()) {
                     slow_waits.fetch_add(1, std::memory_order_relaxed);
+                    // a launch whose workgroups wait for each other (the scheduling grid) leaves unanswered when they cannot
+                    // all be resident -- another context's grid holds the CUs: the owner then takes another route
+                    if (relaunch_limit && ++relaunched_here > relaunch_limit) return SRV_RC_GIVE_UP;
                     const int rc = ensure_running(ctx);
                     if (rc != LS_OK) return rc;
                 }

@@ -514,7 +514,7 @@ def test_sched_exhaustive_grid(monkeypatch):
                     if it % 4 == 3:
                         state = prng.integers(0, 5, size=S)                # few distinct employees
                     real = S * (E - 1)
-                    w = int(prng.choice([10 ** 9, real, real - 1, 1, 511, 512, 513, 1536, 1537, per // 2, int(prng.integers(1, real)),
+                    w = int(prng.choice([10 ** 9, real, real - 1, 1, 0, 511, 512, 513, 1536, 1537, per // 2, int(prng.integers(1, real)),
                                          int(prng.integers(1, real))]))
                     r = c.sched_eval_exhaustive(state[None, :], w)[0]
                     exp = inst.neighbourhood(state, orc.Sched.exhaustive_moves(state, range(E)), w)
@@ -537,3 +537,65 @@ def test_sched_exhaustive_grid(monkeypatch):
             assert (cnt["server_requests"] > 30) == (server != "0")
         results[server] = got
     assert results["1"] == results["0"] == results["1 day-by-day"]
+
+
+def test_two_scheduling_grids_that_cannot_both_be_resident():
+    # The grid's workgroups wait for each other, one per CU: two contexts with 70 000-move lists (137 workgroups each) do not
+    # fit a 256-CU device together.  Taking turns, each finds the CUs free after the other's idle time-out (a relaunch per turn);
+    # with one context BUSY on another thread, the second one's launches leave unanswered (its workgroups are never all
+    # resident), it gives the grid up after two of them and answers through the launched pipeline: same results, no error, no
+    # hang (the first version of this test hung: an aborting launch served the pending request).
+    import threading
+    import ls_amd
+    rng = np.random.default_rng(606)
+    E = 500
+    hol = {int(e): [int(rng.integers(0, 31))] for e in rng.choice(E, size=100, replace=False)}
+    inst = orc.Sched((2022, 5, 9), (2022, 6, 8), hol)
+    D, S = inst.n_scored_days, inst.n_scored_days + 1
+    bits = np.zeros(E, dtype=np.uint64)
+    for e, ds in hol.items():
+        for d in ds:
+            bits[e] |= np.uint64(1) << np.uint64(int(d))
+    moves = _random_moves(rng, 70_000, D, E)
+    state = rng.integers(0, E, size=S)
+    exp = {w: inst.neighbourhood(state, moves, w) for w in (65_536, 10 ** 9)}
+
+    def check(c, tag):
+        for w, e in exp.items():
+            r = c.sched_eval_resident(state, len(moves), w)
+            assert (r["n_scored"], r["best_index"], r["best_hard"], r["best_soft"]) == \
+                   (e["n_scored"], e["best_index"], e["best_hard"], e["best_soft"]), (tag, w)
+
+    with ls_amd.Context(0) as a, ls_amd.Context(0) as b:
+        for c in (a, b):
+            c.sched_instance_upload(D, S, inst.start_weekday, E, bits)
+            c.sched_moves_upload(moves)
+        for it in range(3):                                            # taking turns
+            check(a, ("turns a", it))
+            check(b, ("turns b", it))
+        assert a.counters()["server_requests"] >= 6 and b.counters()["server_requests"] >= 6
+        stop, errors = threading.Event(), []
+
+        def busy():
+            try:
+                while not stop.is_set():
+                    check(a, "busy a")
+            except Exception as e:  # noqa: BLE001 - reported by the main thread
+                errors.append(e)
+
+        t = threading.Thread(target=busy)
+        t.start()
+        try:
+            time.sleep(0.02)                                           # a's grid is resident and stays busy
+            before = b.counters()
+            for it in range(4):
+                check(b, ("b beside a busy a", it))
+            after = b.counters()
+        finally:
+            stop.set()
+            t.join()
+        assert not errors, errors
+        # b's launches left unanswered at least twice, then it stopped asking its grid (4 x 2 calls, at most a few requests)
+        assert after["server_waits_on_drained_launch"] - before["server_waits_on_drained_launch"] >= 2
+        assert after["server_requests"] - before["server_requests"] <= 2
+        assert a.counters()["completion_word_fallbacks"] == 0 and after["completion_word_fallbacks"] == 0
