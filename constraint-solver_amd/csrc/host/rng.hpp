@@ -479,26 +479,36 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted_reference(
 // `key_ceil`: the keys lie in [.., key_ceil] (1 for u^(1/w); 0 for the surrogate keys y log2(u)).  `guard` > 0: also report in
 // *ambiguous whether any two keys whose order matters -- neighbours in the result, or the last taken and the best left out --
 // are closer than `guard`.
+// weighted_top's bucket of a key, as a function the vectorised key computation can evaluate as well: B = weighted_top_buckets(n)
+inline int weighted_top_buckets(uint32_t length) { return length <= 128 ? 64 : 256; } // (256 from 129 keys on: ~280 survivors crowd 64 buckets unevenly)
+
 inline void weighted_top(std::vector<WeightedKey> &keyed, uint32_t amount, std::vector<uint32_t> &out, double key_floor = 0.0,
-                         double key_ceil = 1.0, double guard = 0.0, bool *ambiguous = nullptr)
+                         double key_ceil = 1.0, double guard = 0.0, bool *ambiguous = nullptr, const uint8_t *pre_bucket = nullptr)
 {
     static thread_local std::vector<WeightedKey> taken;
     static thread_local std::vector<uint8_t> bucket;
     const uint32_t length = (uint32_t)keyed.size();
     constexpr int BMAX = 256;
-    const int B = length <= 128 ? 64 : BMAX; // (256 buckets from 129 keys on: the proposer's ~280 survivors crowd 64 buckets unevenly)
+    const int B = weighted_top_buckets(length);
     if (!(key_floor < key_ceil)) key_floor = key_ceil - 1.0;
     const double scale = (double)B / (key_ceil - key_floor);
     uint32_t hist[BMAX];
     for (int b = 0; b < B; b++) hist[b] = 0;
     bucket.resize(length);
-    for (uint32_t i = 0; i < length; i++) {
-        const double k = keyed[i].key; // <= key_ceil; NaN cannot occur (w >= 0, 0 <= u < 1)
-        int b = k <= key_floor ? 0 : (int)((k - key_floor) * scale);
-        b = b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
-        bucket[i] = (uint8_t)b;
-        hist[b]++;
-    }
+    if (pre_bucket) { // computed with the keys (weighted_log2_keys_avx512): any non-decreasing map of the key into [0, B) serves
+        for (uint32_t i = 0; i < length; i++) {
+            const uint8_t b = pre_bucket[i] < B ? pre_bucket[i] : (uint8_t)(B - 1);
+            bucket[i] = b;
+            hist[b]++;
+        }
+    } else
+        for (uint32_t i = 0; i < length; i++) {
+            const double k = keyed[i].key; // <= key_ceil; NaN cannot occur (w >= 0, 0 <= u < 1)
+            int b = k <= key_floor ? 0 : (int)((k - key_floor) * scale);
+            b = b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
+            bucket[i] = (uint8_t)b;
+            hist[b]++;
+        }
     int t = B - 1; // threshold bucket: the buckets above it hold fewer than `amount` keys, with it at least `amount`
     uint32_t above = 0;
     while (above + hist[t] < amount) { above += hist[t]; t--; }
@@ -509,21 +519,23 @@ inline void weighted_top(std::vector<WeightedKey> &keyed, uint32_t amount, std::
         start[t] = off;
     }
     taken.resize((size_t)above + hist[t]);
+    double best_below = -1.0e300; // the best key of the buckets under the threshold bucket (for the ambiguity check)
     {
         uint32_t fill[BMAX];
         for (int b = t; b < B; b++) fill[b] = start[b];
         for (uint32_t i = 0; i < length; i++) {
             const int b = bucket[i];
             if (b >= t) taken[fill[b]++] = keyed[i];
+            else if (keyed[i].key > best_below) best_below = keyed[i].key;
         }
     }
     WeightedKey *tb = taken.data() + start[t]; // the threshold bucket: only its best (amount - above) survive
     const uint32_t need = amount - above;
     if (need < hist[t]) std::nth_element(tb, tb + need, tb + hist[t], weighted_key_before);
-    for (int b = B - 1; b >= t; b--) { // order inside every bucket (a handful of elements each)
-        WeightedKey *p = taken.data() + start[b];
-        const uint32_t cnt = b == t ? need : hist[b];
-        for (uint32_t i = 1; i < cnt; i++) { // insertion sort
+    {   // order inside the buckets: `taken` is in bucket order already, so ONE insertion pass over the `amount` survivors moves
+        // an element only past its own bucket's earlier members (a bucket holds a handful; a loop per bucket cost more than the sorting)
+        WeightedKey *p = taken.data();
+        for (uint32_t i = 1; i < amount; i++) {
             const WeightedKey x = p[i];
             uint32_t j = i;
             while (j > 0 && weighted_key_before(x, p[j - 1])) { p[j] = p[j - 1]; j--; }
@@ -538,8 +550,7 @@ inline void weighted_top(std::vector<WeightedKey> &keyed, uint32_t amount, std::
         if (amount > 0 && amount < length) { // the best key that was left out: in the threshold bucket's remainder or in a lower bucket
             double best_out = -1.0e300;
             for (uint32_t i = need; i < hist[t]; i++) best_out = tb[i].key > best_out ? tb[i].key : best_out;
-            for (uint32_t i = 0; i < length; i++)
-                if (bucket[i] < t && keyed[i].key > best_out) best_out = keyed[i].key;
+            best_out = best_below > best_out ? best_below : best_out;
             amb = amb || !(taken[amount - 1].key - best_out >= guard);
         }
         *ambiguous = amb;
@@ -637,8 +648,10 @@ __attribute__((target("avx512f,avx512dq,avx512vl"))) inline uint32_t weighted_fi
 // u^y = 2^t is the order of t wherever two t differ by more than the guard of index_sample_weighted (1e-11 >> this error + pow's
 // < 1 ulp): eight keys per instruction instead of one libm pow per key.
 __attribute__((target("avx512f,avx512dq,avx512vl"))) inline void weighted_log2_keys_avx512(const double *us, const double *ys, const uint32_t *idx,
-                                                                                        uint32_t n_keep, WeightedKey *keyed)
+                                                                                        uint32_t n_keep, WeightedKey *keyed, uint8_t *bkt8 = nullptr,
+                                                                                        double floor_t = 0.0, double scale = 0.0, int B = 0)
 {
+    const __m512d vfloor = _mm512_set1_pd(floor_t), vscale = _mm512_set1_pd(scale), vtop = _mm512_set1_pd((double)(B - 1)), vzero = _mm512_setzero_pd();
     const __m512d v1 = _mm512_set1_pd(1.0), vhalf = _mm512_set1_pd(0.5), vsqrt2 = _mm512_set1_pd(1.4142135623730951),
                   vlog2e2 = _mm512_set1_pd(2.0 * 1.4426950408889634);
     uint32_t j = 0;
@@ -671,6 +684,11 @@ __attribute__((target("avx512f,avx512dq,avx512vl"))) inline void weighted_log2_k
         alignas(64) double tt[8];
         _mm512_store_pd(tt, t);
         for (uint32_t q = 0; q < 8 && q < left; q++) keyed[j + q] = WeightedKey{tt[q], idx[j + q]};
+        if (bkt8) { // weighted_top's bucket of every key: clamp((t - floor) scale, 0, B - 1), non-decreasing in t
+            __m512d b = _mm512_mul_pd(_mm512_sub_pd(t, vfloor), vscale);
+            b = _mm512_min_pd(_mm512_max_pd(b, vzero), vtop);
+            _mm_storel_epi64(reinterpret_cast<__m128i *>(bkt8 + j), _mm256_cvtepi32_epi8(_mm512_cvttpd_epi32(b))); // eight bytes: the caller pads by 8
+        }
     }
 }
 
@@ -717,8 +735,19 @@ inline uint64_t &weighted_surrogate_fallbacks() // calls of this thread that fou
     return n;
 }
 
+// -DLS_SAMPLER_PROFILE (tools/sampler_bench.cpp only): time-stamp-counter ticks per section of index_sample_weighted
+#ifdef LS_SAMPLER_PROFILE
+inline unsigned long long *sampler_prof() { static thread_local unsigned long long t[8] = {0}; return t; }
+#define LS_SP_BEGIN unsigned long long sp_last_ = __builtin_ia32_rdtsc()
+#define LS_SP(i) do { const unsigned long long now_ = __builtin_ia32_rdtsc(); sampler_prof()[i] += now_ - sp_last_; sp_last_ = now_; } while (0)
+#else
+#define LS_SP_BEGIN do { } while (0)
+#define LS_SP(i) do { } while (0)
+#endif
+
 template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, const std::vector<double> &weights, uint32_t amount)
 {
+    LS_SP_BEGIN;
     const uint32_t length = (uint32_t)weights.size();
     if (amount == 0) return {};
     if (amount > length) throw std::runtime_error("`amount` of samples must be less than or equal to `length`");
@@ -761,6 +790,7 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, co
             ys[i] = (wi >= 0 && (double)wi == w) ? inv_small[(size_t)wi] : 1.0 / w;
             prefilter = prefilter && w >= 1.0;
         }
+    LS_SP(0); // draws + exponents
     double key_floor = 0.0; // where the surviving keys start (a hint for the bucket mapping of weighted_top)
     if (!prefilter) {
         keyed.resize(length);
@@ -781,6 +811,7 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, co
                 weighted_bracket(us[i], ys[i], hi[i], b);
                 bkt[i] = b;
             }
+        LS_SP(1); // brackets
         for (uint32_t i = 0; i < length; i++) hist[bkt[i]]++;
         int t = B - 1;
         uint32_t above = 0;
@@ -788,6 +819,7 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, co
         // at least `amount` lower brackets are >= the lower edge of bucket t (bucket 0 has no lower edge: keep everything)
         const double cut = t == 0 ? -2.0e300 : (double)t / 32.0 - 8.0 - 1e-9;
         uint32_t n_keep = 0;
+        LS_SP(2); // histogram + threshold
 #if defined(__x86_64__)
         if (wide) n_keep = weighted_filter_avx512(hi.data(), length, cut, idx.data());
         else
@@ -795,6 +827,7 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, co
             for (uint32_t i = 0; i < length; i++)
                 if (hi[i] >= cut) idx[n_keep++] = i;
         keyed.resize(n_keep);
+        LS_SP(3); // filter
 #if defined(__x86_64__)
         if (wide && t > 0 && weighted_surrogate_on()) {
             // Order the survivors by t = y log2(u) (weighted_log2_keys_avx512) instead of by pow(u, y): the same order wherever two t
@@ -803,10 +836,15 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, co
             bool u_zero = false;
             for (uint32_t j = 0; j < n_keep; j++) u_zero = u_zero || !(us[idx[j]] > 0.0);
             if (!u_zero) {
-                weighted_log2_keys_avx512(us.data(), ys.data(), idx.data(), n_keep, keyed.data());
+                static thread_local std::vector<uint8_t> bkt8;
+                bkt8.resize((size_t)n_keep + 8);
+                const int TB = weighted_top_buckets(n_keep);
+                weighted_log2_keys_avx512(us.data(), ys.data(), idx.data(), n_keep, keyed.data(), bkt8.data(), cut, (double)TB / (0.0 - cut), TB);
+                LS_SP(4); // log2 keys of the survivors
                 std::vector<uint32_t> out;
                 bool ambiguous = true;
-                weighted_top(keyed, amount, out, cut, 0.0, 1e-11, &ambiguous);
+                weighted_top(keyed, amount, out, cut, 0.0, 1e-11, &ambiguous, bkt8.data());
+                LS_SP(5); // top `amount` in order
                 if (!ambiguous) return out;
                 weighted_surrogate_fallbacks()++;
             }

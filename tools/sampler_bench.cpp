@@ -1,5 +1,6 @@
 // Diagnostic: where the N-queens proposer's weighted sample (1100 keys, 204 picks) spends its host time.
 //   g++ -O3 -std=c++17 -I constraint-solver_amd/csrc -o /tmp/sampler_bench tools/sampler_bench.cpp && /tmp/sampler_bench
+#define LS_SAMPLER_PROFILE 1
 #include "host/rng.hpp"
 #include <chrono>
 #include <cstdio>
@@ -13,7 +14,14 @@ int main(){
     unsigned long long acc=0;
     for(int r=0;r<reps;r++){ auto v=index_sample_weighted(rng,w,204); acc+=v[0]; }
     auto t1=std::chrono::steady_clock::now();
-    printf("full sampler %.2f us (acc %llu)\n", std::chrono::duration<double>(t1-t0).count()/reps*1e6, acc);
+    const double full_us = std::chrono::duration<double>(t1-t0).count()/reps*1e6;
+    printf("full sampler %.2f us (acc %llu)\n", full_us, acc);
+    {   // the sections of the real function (time-stamp-counter ticks, scaled to the measured total)
+        const char *name[6] = {"draws + exponents", "brackets", "histogram + threshold", "filter", "log2 keys of the survivors", "top 204 in order"};
+        unsigned long long sum = 0;
+        for (int i = 0; i < 6; i++) sum += sampler_prof()[i];
+        for (int i = 0; i < 6; i++) printf("  %-28s %5.2f us\n", name[i], full_us * (double)sampler_prof()[i] / (double)sum);
+    }
     {   // the sampler's own sections (a copy of index_sample_weighted's pre-filter path with timers)
         const uint32_t amount = 204, length = 1100;
         std::vector<WeightedKey> keyed;
