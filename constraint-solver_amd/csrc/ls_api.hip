@@ -427,8 +427,51 @@ __attribute__((target("avx2"))) static void widen_i32_avx2(const int32_t *src, i
     for (; j < n; j++) dst[j] = src[j];
 }
 
+// nq_cs_after_move and widen_i32 in one pass (sixteen columns per step): the scores are read, corrected, stored and widened once
+__attribute__((target("avx512f"))) static void nq_cs_after_move_widen_avx512(const int32_t *rows, int32_t *cs, int64_t *out, int n, int mc, int mv, int mq)
+{
+    const __m512i vmc = _mm512_set1_epi32(mc), vmv = _mm512_set1_epi32(mv), vmq = _mm512_set1_epi32(mq), one = _mm512_set1_epi32(1);
+    __m512i idx = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15), cnt = _mm512_setzero_si512();
+    const __m512i sixteen = _mm512_set1_epi32(16), zero = _mm512_setzero_si512();
+    int j = 0;
+    for (; j + 16 <= n; j += 16) {
+        const __m512i q = _mm512_loadu_si512(rows + j);
+        const __m512i dc = _mm512_abs_epi32(_mm512_sub_epi32(idx, vmc));
+        const __m512i dn = _mm512_abs_epi32(_mm512_sub_epi32(q, vmv)), dq = _mm512_abs_epi32(_mm512_sub_epi32(q, vmq));
+        const __mmask16 hn = _mm512_cmpeq_epi32_mask(dn, zero) | _mm512_cmpeq_epi32_mask(dn, dc); // attacked from the new square
+        const __mmask16 hq = _mm512_cmpeq_epi32_mask(dq, zero) | _mm512_cmpeq_epi32_mask(dq, dc); // ... from the old one
+        __m512i c = _mm512_loadu_si512(cs + j);
+        c = _mm512_mask_add_epi32(c, hn, c, one);
+        c = _mm512_mask_sub_epi32(c, hq, c, one);
+        _mm512_storeu_si512(cs + j, c);
+        _mm512_storeu_si512(out + j, _mm512_cvtepi32_epi64(_mm512_castsi512_si256(c)));
+        _mm512_storeu_si512(out + j + 8, _mm512_cvtepi32_epi64(_mm512_extracti64x4_epi64(c, 1)));
+        cnt = _mm512_mask_add_epi32(cnt, hn, cnt, one);
+        idx = _mm512_add_epi32(idx, sixteen);
+    }
+    int total = _mm512_reduce_add_epi32(cnt);
+    for (; j < n; j++) {
+        const int q = rows[j], dc = j > mc ? j - mc : mc - j;
+        const int dn = q > mv ? q - mv : mv - q, dq = q > mq ? q - mq : mq - q;
+        const int hn = (dn == 0) | (dn == dc), hq = (dq == 0) | (dq == dc);
+        cs[j] += hn - hq;
+        out[j] = cs[j];
+        total += hn;
+    }
+    cs[mc] = total; // column mc itself, as in nq_cs_after_move
+    out[mc] = total;
+}
+
 } // extern "C"
 namespace lsamd {
+void widen_i32(const int32_t *src, int64_t *dst, int n);
+void nq_cs_after_move_widen(const int32_t *rows, int32_t *cs, int64_t *out, int n, int mc, int mv, int mq)
+{
+    static const bool wide = __builtin_cpu_supports("avx512f") && getenv("LS_HOST_NO_AVX512") == nullptr;
+    if (wide) { nq_cs_after_move_widen_avx512(rows, cs, out, n, mc, mv, mq); return; }
+    nq_cs_after_move(rows, cs, n, mc, mv, mq);
+    widen_i32(cs, out, n);
+}
 void widen_i32(const int32_t *src, int64_t *dst, int n)
 {
     static const bool avx2 = __builtin_cpu_supports("avx2");
@@ -585,8 +628,8 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
                 for (int j = 0; j < n; j++) cs[j] = k16[j];
                 rs.cs_valid[(size_t)r] = r < 64;
             } else {
-                if (moved) nq_cs_after_move(sh, cs, n, mc, mv, sh[mc]);
-                widen_i32(cs, next_col_scores + (size_t)r * n, n);
+                if (moved) nq_cs_after_move_widen(sh, cs, next_col_scores + (size_t)r * n, n, mc, mv, sh[mc]);
+                else widen_i32(cs, next_col_scores + (size_t)r * n, n);
             }
         }
         if (moved) sh[mc] = mv; // the device applied it

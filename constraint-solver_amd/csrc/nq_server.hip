@@ -439,6 +439,7 @@ static long long sync_board(NqServer *s, int slot, const int32_t *rows)
 
 void nq_cs_after_move(const int32_t *rows, int32_t *cs, int n, int mc, int mv, int mq); // ls_api.hip
 void widen_i32(const int32_t *src, int64_t *dst, int n);                                // ls_api.hip
+void nq_cs_after_move_widen(const int32_t *rows, int32_t *cs, int64_t *out, int n, int mc, int mv, int mq); // ls_api.hip
 
 // One LS iteration of one restart on slot `slot` (what ls_nqueens_eval_batch[_next] computes for n_restarts == 1).
 // rows / cols are validated by the caller; window is already clamped.
@@ -505,8 +506,8 @@ int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int6
             for (int j = 0; j < n; j++) { sl.cs[(size_t)j] = k16[j]; next_col_scores[j] = k16[j]; }
             sl.cs_valid = true;
         } else {
-            if (moved) nq_cs_after_move(sh, sl.cs.data(), n, res->best_col, res->best_value, sh[res->best_col]);
-            widen_i32(sl.cs.data(), next_col_scores, n);
+            if (moved) nq_cs_after_move_widen(sh, sl.cs.data(), next_col_scores, n, res->best_col, res->best_value, sh[res->best_col]);
+            else widen_i32(sl.cs.data(), next_col_scores, n);
         }
     }
     if (moved) sh[res->best_col] = res->best_value; // the workgroup applied it to its LDS board
