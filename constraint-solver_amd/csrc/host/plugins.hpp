@@ -322,23 +322,21 @@ struct NQueensProblem {
     {
         int64_t want_total = 0;
         const std::vector<int64_t> &cs = col_scores(start, &want_total, trusted);
-        std::vector<uint32_t> &conflict_cols = conflict_cols_buf;
-        std::vector<double> &weights = weights_buf;
-        conflict_cols.resize(cs.size());
-        weights.resize(cs.size());
+        std::vector<uint32_t> &conflict_cols = conflict_cols_buf; // n entries; the first n_conflict count (never shrunk: growing a
+        std::vector<double> &weights = weights_buf;               // vector back to n would zero-fill ~36 KB per LS iteration)
+        if (conflict_cols.size() < cs.size()) conflict_cols.resize(cs.size());
+        if (weights.size() < cs.size()) weights.resize(cs.size());
         int64_t sum = 0;
         const size_t n_conflict = nonzero_columns(cs.data(), cs.size(), conflict_cols.data(), weights.data(), &sum);
         if (sum != want_total) // fail loudly on impossible column scores (they sum to the board's score) instead of walking on from them
             throw std::runtime_error("column scores of the current board sum to " + std::to_string(sum) + ", its score is " + std::to_string(want_total));
-        conflict_cols.resize(n_conflict);
-        weights.resize(n_conflict);
-        if (conflict_cols.empty()) return {};
+        if (n_conflict == 0) return {};
         size_t amount = start.size() / 20;
         if (amount < 1) amount = 1;
-        if (amount > conflict_cols.size()) amount = conflict_cols.size();
+        if (amount > n_conflict) amount = n_conflict;
         const auto TA = std::chrono::steady_clock::now();
-        const_cast<NQueensProblem *>(this)->n_conf += conflict_cols.size();
-        const std::vector<uint32_t> picked = index_sample_weighted(rng, weights, (uint32_t)amount);
+        const_cast<NQueensProblem *>(this)->n_conf += n_conflict;
+        const std::vector<uint32_t> picked = index_sample_weighted(rng, weights.data(), (uint32_t)n_conflict, (uint32_t)amount);
         const_cast<NQueensProblem *>(this)->t_samp += std::chrono::duration<double>(std::chrono::steady_clock::now() - TA).count();
         const uint64_t num_cols = gen_range_u64_incl(rng, 1, picked.size());
         const std::vector<uint32_t> order = index_sample(rng, (uint32_t)picked.size(), (uint32_t)num_cols);

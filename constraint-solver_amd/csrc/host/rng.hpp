@@ -745,10 +745,15 @@ inline unsigned long long *sampler_prof() { static thread_local unsigned long lo
 #define LS_SP(i) do { } while (0)
 #endif
 
+template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, const double *weights, uint32_t length, uint32_t amount);
 template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, const std::vector<double> &weights, uint32_t amount)
 {
+    return index_sample_weighted(rng, weights.data(), (uint32_t)weights.size(), amount);
+}
+// (pointer + length: the proposer keeps its weights in a buffer of n entries of which the first `length` count)
+template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, const double *weights, uint32_t length, uint32_t amount)
+{
     LS_SP_BEGIN;
-    const uint32_t length = (uint32_t)weights.size();
     if (amount == 0) return {};
     if (amount > length) throw std::runtime_error("`amount` of samples must be less than or equal to `length`");
     static thread_local std::vector<WeightedKey> keyed;
@@ -774,7 +779,7 @@ template <class R> inline std::vector<uint32_t> index_sample_weighted(R &rng, co
     if constexpr (std::is_same<R, ChaCha20Rng>::value) {
         if (weighted_have_avx512()) { // the draws in one run of vector conversions, the exponents by vector division (the same IEEE quotients)
             bool all_ge1 = true;
-            if (!weighted_exponents_avx512(weights.data(), length, ys.data(), &all_ge1)) throw std::runtime_error("invalid weight");
+            if (!weighted_exponents_avx512(weights, length, ys.data(), &all_ge1)) throw std::runtime_error("invalid weight");
             rng.fill_f64(us.data(), length);
             prefilter = prefilter && all_ge1;
             bulk = true;
