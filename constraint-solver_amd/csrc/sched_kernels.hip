@@ -2312,6 +2312,7 @@ void sched_server_pause(ls_ctx *ctx)
             const unsigned tag = h->next_tag(0);
             volatile unsigned *dst = h->req(0);
             for (int d = 0; d < 16; d++) dst[d] = (tag << 16) | (d == 0 ? SRV_F_QUIT : 0u);
+            h->flush_lines();
         }
         (void)hipStreamSynchronize(h->stream);
     }
@@ -2516,6 +2517,7 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
             const unsigned tag = s->grid.next_tag(0);
             volatile unsigned *dst = s->grid.req(0);
             for (int d = 0; d < 16; d++) dst[d] = (tag << 16) | (d == 0 ? SRV_F_QUIT : 0u);
+            s->grid.flush_lines();
         }
         LS_HIP(ctx, hipStreamSynchronize(s->grid.stream));
         s->grid_fin = 0;
@@ -2583,7 +2585,9 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
         alignas(64) unsigned msg[64];
         for (int d = 0; d < 64; d++) msg[d] = (tag << 16) | pay[d];
         volatile unsigned *dst = s->grid.req(0);
+        s->grid.flush_lines();
         for (int l = 3; l >= 0; l--) srv_store_line(dst + 16 * l, msg + 16 * l);
+        s->grid.flush_lines();
         s->grid_requests++;
     }
     static const bool trace = getenv("LS_AMD_TRACE") != nullptr;

@@ -167,7 +167,18 @@ struct SrvHost {
     std::vector<unsigned> tags;   // last tag posted per slot
     std::function<hipError_t(const SrvLink &)> launch; // set by the owner: starts the resident kernel on `stream`
 
-    unsigned *req(int s) const { return reinterpret_cast<unsigned *>(pinned) + (size_t)s * 16; }
+    // Request lines: pinned host memory (the device polls them over PCIe), or -- LS_SRV_MAILBOX=device on a large-BAR platform --
+    // fine-grained DEVICE memory the host writes through the PCIe BAR (write-combined: one 64-byte store per line, then sfence):
+    // the workgroup's poll is then a local read and a request crosses PCIe once instead of being fetched (tools/server_probe.hip:
+    // mailbox round trip 2.9 -> 2.3 us).
+    unsigned *req_dev = nullptr;
+    unsigned *req(int s) const { return (req_dev ? req_dev : reinterpret_cast<unsigned *>(pinned)) + (size_t)s * 16; }
+    void flush_lines() const
+    {
+#if defined(__x86_64__)
+        if (req_dev) _mm_sfence();
+#endif
+    }
     unsigned *resp(int s) const { return reinterpret_cast<unsigned *>(pinned + o_resp) + (size_t)s * 16; }
     unsigned long long *exit_gen() const { return reinterpret_cast<unsigned long long *>(pinned + o_exit); }
     char *extra() const { return pinned + o_extra; }
@@ -200,6 +211,17 @@ struct SrvHost {
         e = hipHostMalloc(reinterpret_cast<void **>(&pinned), off, hipHostMallocCoherent);
         if (e != hipSuccess) { pinned = nullptr; release(); return set_err(ctx, LS_ERR_NOMEM, "%s: pinned allocation failed: %s", what, hipGetErrorString(e)); }
         memset(pinned, 0, off);
+        if (const char *v = getenv("LS_SRV_MAILBOX")) {
+            int large_bar = 0;
+            if (strcmp(v, "device") == 0 && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar) {
+                if (hipExtMallocWithFlags(reinterpret_cast<void **>(&req_dev), (size_t)slots * 64, hipDeviceMallocFinegrained) != hipSuccess) {
+                    (void)hipGetLastError();
+                    req_dev = nullptr;
+                } else {
+                    hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, stream, reinterpret_cast<int *>(req_dev), 0, (long long)slots * 16);
+                }
+            }
+        }
         e = hipMalloc(reinterpret_cast<void **>(&ctl), 256);
         if (e != hipSuccess) { ctl = nullptr; release(); return set_err(ctx, LS_ERR_NOMEM, "%s: device allocation failed: %s", what, hipGetErrorString(e)); }
         hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<long long *>(ctl), 0ll, 32ll);
@@ -215,7 +237,8 @@ struct SrvHost {
         if (stream) (void)hipStreamDestroy(stream);
         if (pinned) (void)hipHostFree(pinned);
         if (ctl) (void)hipFree(ctl);
-        stream = nullptr; pinned = nullptr; ctl = nullptr;
+        if (req_dev) (void)hipFree(req_dev);
+        stream = nullptr; pinned = nullptr; ctl = nullptr; req_dev = nullptr;
     }
     bool drained() const { return __atomic_load_n(exit_gen(), __ATOMIC_ACQUIRE) == launch_gen.load(std::memory_order_acquire); }
 
@@ -252,7 +275,9 @@ struct SrvHost {
         alignas(64) unsigned line[16];
         for (int d = 0; d < 16; d++) line[d] = (tag << 16) | (pay[d] & 0xffffu);
         __atomic_thread_fence(__ATOMIC_RELEASE); // the bulk data is written before the line that announces it
+        flush_lines();                           // (a write-combined line is not ordered behind ordinary stores by itself)
         srv_store_line(req(slot), line);
+        flush_lines();
         requests.fetch_add(1, std::memory_order_relaxed);
     }
     // Poll the slot's answer line for the tag of the request just posted (the same hooks as the completion-word wait of a
@@ -316,6 +341,7 @@ struct SrvHost {
                 volatile unsigned *dst = req(i);
                 for (int d = 0; d < 16; d++) dst[d] = (tag << 16) | (d == 0 ? SRV_F_QUIT : 0u);
             }
+            flush_lines();
         }
         (void)hipStreamSynchronize(stream);
         release();
