@@ -599,3 +599,13 @@ def test_two_scheduling_grids_that_cannot_both_be_resident():
         assert after["server_waits_on_drained_launch"] - before["server_waits_on_drained_launch"] >= 2
         assert after["server_requests"] - before["server_requests"] <= 2
         assert a.counters()["completion_word_fallbacks"] == 0 and after["completion_word_fallbacks"] == 0
+
+
+def test_servers_with_the_mailbox_in_device_memory(monkeypatch):
+    # LS_SRV_MAILBOX=device: the request lines live in fine-grained device memory and the host writes them through the PCIe BAR
+    # (write-combined 64-byte stores + fences); falls back to pinned host memory where the platform has no large BAR.  The
+    # N-queens server, the scheduling workgroup and the scheduling grid, each against the oracle and its launched route.
+    monkeypatch.setenv("LS_SRV_MAILBOX", "device")
+    test_server_equals_launch_per_call_route(monkeypatch)
+    test_sched_grid_server_long_lists(monkeypatch)
+    test_sched_server_follows_any_call_sequence(monkeypatch, ((2022, 5, 9), (2022, 6, 8)), 7)
