@@ -567,6 +567,8 @@ def test_two_scheduling_grids_that_cannot_both_be_resident():
                    (e["n_scored"], e["best_index"], e["best_hard"], e["best_soft"]), (tag, w)
 
     with ls_amd.Context(0) as a, ls_amd.Context(0) as b:
+        if a.device_info()["n_cus"] >= 2 * ((len(moves) + 511) // 512):
+            pytest.skip("both grids fit this device")
         for c in (a, b):
             c.sched_instance_upload(D, S, inst.start_weekday, E, bits)
             c.sched_moves_upload(moves)
