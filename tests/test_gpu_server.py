@@ -539,6 +539,35 @@ def test_sched_exhaustive_grid(monkeypatch):
     assert results["1"] == results["0"] == results["1 day-by-day"]
 
 
+@pytest.mark.parametrize("E,chunks_per_workgroup", [(5000, 2), (16000, 4)])
+def test_sched_exhaustive_grid_chunks_per_workgroup(E, chunks_per_workgroup):
+    # the exhaustive grid with two and with four consecutive chunks per workgroup (E = 9000 in the test above gives three):
+    # windows beyond everything, inside a workgroup's second / last chunk (first request: the finisher is workgroup 0 and has
+    # to re-score another workgroup's chunks; repeated: the cut workgroup is the finisher and uses the keys it holds), 1
+    import ls_amd
+    rng = np.random.default_rng(E)
+    hol = {int(e): [int(rng.integers(0, 31))] for e in rng.choice(E, size=E // 4, replace=False)}
+    inst = orc.Sched((2022, 5, 9), (2022, 6, 8), hol)
+    D, S = inst.n_scored_days, inst.n_scored_days + 1
+    bits = np.zeros(E, dtype=np.uint64)
+    for e, ds in hol.items():
+        for d in ds:
+            bits[e] |= np.uint64(1) << np.uint64(int(d))
+    per = S * E
+    assert (((per + 511) // 512) + 255) // 256 == chunks_per_workgroup
+    with ls_amd.Context(0) as c:
+        c.sched_instance_upload(D, S, inst.start_weekday, E, bits)
+        state = rng.integers(0, E, size=S)
+        moves = orc.Sched.exhaustive_moves(state, range(E))
+        span = 512 * chunks_per_workgroup
+        for w in (10 ** 9, 7 * span + 512 + 77, 7 * span + 512 + 77, 100 * span + span - 3, 100 * span + span - 3, per // 2, 1):
+            r = c.sched_eval_exhaustive(state[None, :], w)[0]
+            exp = inst.neighbourhood(state, moves, w)
+            assert (r["n_scored"], r["best_index"]) == (exp["n_scored"], exp["best_index"]), (E, w)
+            assert (r["best_hard"], r["best_soft"]) == (exp["best_hard"], exp["best_soft"])
+        assert c.counters()["server_requests"] >= 7
+
+
 def test_two_scheduling_grids_that_cannot_both_be_resident():
     # The grid's workgroups wait for each other, one per CU: two contexts with 70 000-move lists (137 workgroups each) do not
     # fit a 256-CU device together.  Taking turns, each finds the CUs free after the other's idle time-out (a relaunch per turn);
