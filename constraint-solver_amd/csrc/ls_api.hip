@@ -87,11 +87,12 @@ static int bind(ls_ctx *ctx)
 // The server a one-restart LS step of this context goes to: the attached slot of a shared server (ls_multi_solver), or the
 // context's own one-slot server, started on demand (and restarted when the board size changes).  *out stays null when the
 // step has to take the launch-per-call route (a shared server built for another board size).
-int nq_ctx_server(ls_ctx *ctx, int n, NqServer **out)
+int nq_ctx_server(ls_ctx *ctx, int n, NqServer **out, int slots)
 {
     *out = nullptr;
-    if (ctx->server && nq_server_n(ctx->server) == n) { *out = ctx->server; return LS_OK; }
+    if (ctx->server && nq_server_n(ctx->server) == n && nq_server_slots(ctx->server) >= slots) { *out = ctx->server; return LS_OK; }
     if (ctx->server && !ctx->server_owned) return LS_OK;
+    if (ctx->server && nq_server_n(ctx->server) == n && nq_server_slots(ctx->server) > slots) slots = nq_server_slots(ctx->server); // never shrinks
     if (ctx->server) { // another n: the context's own server is replaced; its counters stay in the context's totals
         unsigned long long c4[4];
         nq_server_counters(ctx->server, c4);
@@ -100,7 +101,7 @@ int nq_ctx_server(ls_ctx *ctx, int n, NqServer **out)
         ctx->server = nullptr;
     }
     NqServer *s = nullptr;
-    const int rc = nq_server_create(ctx, n, 1, &s);
+    const int rc = nq_server_create(ctx, n, slots, &s);
     if (rc != LS_OK) return rc;
     ctx->server = s; ctx->server_slot = 0; ctx->server_owned = true;
     *out = s;
@@ -674,6 +675,37 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
         if (srv)
             return nq_server_step(ctx, srv, ctx->server_slot, rows, cur_scores[0], cols, n_cols[0], nq_clamp_window(window, max_cols, n), results,
                                   next_col_scores);
+    }
+    if (!scores_out && n_restarts > 1 && n_restarts <= 64 && ctx->nq_step_mode >= 4 && (!ctx->server || ctx->server_owned) &&
+        nq_step_eligible(ctx, n, max_cols, nq_clamp_window(window, max_cols, n))) {
+        // A batch of restarts (the reference-shaped "8 restarts per launch" of config 4, ls_multi_solver's lockstep mode): one slot of
+        // the context's own server per restart, all requests in flight before the first answer is awaited -- still no launch.
+        NqServer *srv = ctx->server && nq_server_n(ctx->server) == n && nq_server_slots(ctx->server) >= n_restarts ? ctx->server : nullptr;
+        if (!srv) {
+            LS_BIND(ctx);
+            rc = nq_ctx_server(ctx, n, &srv, n_restarts);
+            if (rc != LS_OK) return rc;
+        }
+        if (srv) {
+            const long long win = nq_clamp_window(window, max_cols, n);
+            for (int r = 0; r < n_restarts; r++) {
+                rc = nq_server_post(ctx, srv, r, rows + (size_t)r * n, cols + (size_t)r * max_cols, n_cols[r], win, next_col_scores != nullptr);
+                if (rc != LS_OK) { // rows out of range: the requests already posted are answered and dropped, the error stands
+                    for (int q = 0; q < r; q++) {
+                        ls_nq_result dropped;
+                        (void)nq_server_finish(ctx, srv, q, cur_scores[q], cols + (size_t)q * max_cols, &dropped, nullptr);
+                    }
+                    return rc;
+                }
+            }
+            int first_rc = LS_OK;
+            for (int r = 0; r < n_restarts; r++) {
+                rc = nq_server_finish(ctx, srv, r, cur_scores[r], cols + (size_t)r * max_cols, results + r,
+                                      next_col_scores ? next_col_scores + (size_t)r * n : nullptr);
+                if (rc != LS_OK && first_rc == LS_OK) first_rc = rc;
+            }
+            return first_rc;
+        }
     }
     LS_BIND(ctx);
     if (!all_in_range(rows, (long long)n_restarts * n, n))

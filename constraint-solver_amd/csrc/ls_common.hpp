@@ -235,7 +235,10 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
 bool sched_xgrid_eligible(const ls_ctx *ctx);
 int sched_server_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out);
 // ls_api.hip
-int nq_ctx_server(ls_ctx *ctx, int n, NqServer **out);
+int nq_ctx_server(ls_ctx *ctx, int n, NqServer **out, int slots = 1);
+int nq_server_post(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, const int32_t *cols, int32_t n_cols, long long window,
+                   bool has_next_col_scores);
+int nq_server_finish(ls_ctx *ctx, NqServer *s, int slot, int64_t cur_score, const int32_t *cols, ls_nq_result *res, int64_t *next_col_scores);
 int nq_ctx_prepare_server(ls_ctx *ctx, int n);
 
 #define LS_HIP(ctx, call)                                                                   \

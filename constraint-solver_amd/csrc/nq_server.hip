@@ -319,6 +319,7 @@ struct NqServer {
         unsigned long long calls = 0, dev_ticks[6] = {0, 0, 0, 0, 0, 0}; // stamps builds: phase ends of the workgroup's service, shader cycles / 4
         unsigned board_id = 0;
         bool valid = false, cs_valid = false;
+        bool want_cs = false; // the request in flight asked the workgroup for the column scores (post -> finish)
         std::vector<int32_t> cs;
     };
     std::vector<Slot> slots;
@@ -443,8 +444,10 @@ void nq_cs_after_move_widen(const int32_t *rows, int32_t *cs, int64_t *out, int 
 
 // One LS iteration of one restart on slot `slot` (what ls_nqueens_eval_batch[_next] computes for n_restarts == 1).
 // rows / cols are validated by the caller; window is already clamped.
-int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int64_t cur_score, const int32_t *cols, int32_t n_cols,
-                   long long window, ls_nq_result *res, int64_t *next_col_scores)
+// One LS step of a slot in two halves, so that a batched call can have the requests of all its restarts in flight at once:
+// nq_server_post writes the request, nq_server_finish waits for the answer and decodes it.  nq_server_step = both.
+int nq_server_post(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, const int32_t *cols, int32_t n_cols, long long window,
+                   bool has_next_col_scores)
 {
     if (slot < 0 || slot >= s->n_slots) return set_err(ctx, LS_ERR_INVALID, "LS-step server: slot %d outside [0, %d)", slot, s->n_slots);
     const int n = s->n;
@@ -456,8 +459,9 @@ int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int6
         if (bad >= 0) return set_err(ctx, LS_ERR_INVALID, "rows[%lld] = %d outside [0, %d)", bad, rows[bad], n);
     }
     ctx->steps_done++;
-    if (!next_col_scores) sl.cs_valid = false; // nobody keeps the scores across this call
-    const bool want_cs = next_col_scores != nullptr && !(sl.cs_valid && ctx->nq_host_cs);
+    if (!has_next_col_scores) sl.cs_valid = false; // nobody keeps the scores across this call
+    const bool want_cs = has_next_col_scores && !(sl.cs_valid && ctx->nq_host_cs);
+    sl.want_cs = want_cs;
     // the window arithmetic of the step (nq_k_limit, nq_step_kernel) is done here: 64-bit divisions are slow on the device
     const long long full = window / (n - 1);
     const int n_whole = (int)(full < n_cols ? full : n_cols);
@@ -483,6 +487,18 @@ int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int6
     int rc = s->h.ensure_running(ctx);
     if (rc != LS_OK) return rc;
     s->h.post(slot, pay);
+    if (trace) sl.t_pre += std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count();
+    return LS_OK;
+}
+
+int nq_server_finish(ls_ctx *ctx, NqServer *s, int slot, int64_t cur_score, const int32_t *cols, ls_nq_result *res, int64_t *next_col_scores)
+{
+    const int n = s->n;
+    NqServer::Slot &sl = s->slots[(size_t)slot];
+    static const bool trace = getenv("LS_AMD_TRACE") != nullptr;
+    const bool want_cs = sl.want_cs;
+    const auto T0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    int rc;
     const auto T1 = trace ? std::chrono::steady_clock::now() : T0;
     unsigned r[8];
     rc = s->h.wait(ctx, slot, r);
@@ -514,12 +530,20 @@ int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int6
     if (trace) {
         const auto T3 = std::chrono::steady_clock::now();
         auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-        sl.t_pre += sec(T0, T1); sl.t_wait += sec(T1, T2); sl.t_post += sec(T2, T3);
+        sl.t_wait += sec(T1, T2); sl.t_post += sec(T2, T3);
         sl.calls++;
         const volatile unsigned *rl = s->h.resp(slot);
         for (int d = 0; d < 6; d++) sl.dev_ticks[d] += (rl[7 + d] >> 16) == s->h.tags[(size_t)slot] ? rl[7 + d] & 0xffffu : 0u;
     }
     return LS_OK;
+}
+
+int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int64_t cur_score, const int32_t *cols, int32_t n_cols,
+                   long long window, ls_nq_result *res, int64_t *next_col_scores)
+{
+    const int rc = nq_server_post(ctx, s, slot, rows, cols, n_cols, window, next_col_scores != nullptr);
+    if (rc != LS_OK) return rc;
+    return nq_server_finish(ctx, s, slot, cur_score, cols, res, next_col_scores);
 }
 
 // get_col_scores + score of one board (examples/nqueens/src/lib.rs:74-87, 126-140) on the slot; the board stays with the

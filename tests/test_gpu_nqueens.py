@@ -334,10 +334,11 @@ def _expect_step(rows, cols, n_cols, window):
     return out
 
 
-@pytest.mark.parametrize("mode", ["3", "2", "1", "0"])
+@pytest.mark.parametrize("mode", ["4", "3", "2", "1", "0"])
 def test_fused_step_kernel_matches_oracle(monkeypatch, mode):
     # the solver's per-iteration launch: one block per restart does tables + argmin + move + column scores.
-    # LS_NQ_STEP: 3 = zero-copy + resident boards + 16-bit column scores + polled completion word (default),
+    # LS_NQ_STEP: 4 = no launch: one slot of the context's resident server per restart, all requests in flight at once (default),
+    # 3 = zero-copy + resident boards + 16-bit column scores + polled completion word,
     # 2 = zero-copy on pinned host memory + stream sync, 1 = through staging copies, 0 = multi-launch path
     import ls_amd
     monkeypatch.setenv("LS_NQ_STEP", mode)
