@@ -662,10 +662,12 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True):
         for _ in range(200):     # also lets the clocks settle after the heavy launches above
             step()
         reps = 1000
+        requests_before = ctx.counters()["server_requests"]
         t0 = time.perf_counter()
         for _ in range(reps):
             step()
         s = (time.perf_counter() - t0) / reps
+        on_server = ctx.counters()["server_requests"] - requests_before >= reps * RR
         c = kc.get(f"nq_step_kernel_r{RR}") or {}
         raw_us = None
         if RR == 1:
@@ -698,10 +700,11 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True):
             "us_per_call_bare_c_entry": raw_us,
             "note": "us_per_call includes ctypes/numpy marshalling of the Python wrapper (about 8 us); us_per_call_bare_c_entry calls the C entry "
                     "with arguments marshalled once (still a Python loop: about 1 us of interpreter per call)",
-            "route": "resident LS-step server (no launch per call)" if RR == 1 and ctx.counters()["server_requests"] else "one fused LS-step launch per call",
+            "route": ("resident LS-step server (no launch per call" + ("" if RR == 1 else f": one slot per restart, {RR} requests in flight") + ")") if on_server
+                     else "one fused LS-step launch per call",
             # a latency-bound launch: one 1024-thread block per restart; its issue bounds on the CUs it can occupy are a small
             # fraction of the kernel time, which is PCIe-free set-up, LDS round trips and the completion word
-            ("launched_kernel_of_the_launch_per_call_route_LS_NQ_STEP_3" if RR == 1 and ctx.counters()["server_requests"] else "kernel"):
+            ("launched_kernel_of_the_launch_per_call_route_LS_NQ_STEP_3" if on_server else "kernel"):
                 {k: c.get(k) for k in ("duration_us", "valu_issue_bound_us", "lds_array_bound_us", "cus_usable", "roofline", "source")} if c else None}
     if e2e:
         out["config4_end_to_end_64_restarts_one_gpu"] = config4_end_to_end(ctx, n)
