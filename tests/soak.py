@@ -171,16 +171,24 @@ def server_walk(ctx):
     stats["server_steps"] = stats.get("server_steps", 0) + 12
 
 
+os.environ["LS_NQ_STEP"] = "3"          # a second context on the launch-per-call routes (the knob is read when a context is created)
+ctx3 = ls_amd.Context(0)
+os.environ.pop("LS_NQ_STEP")
 with ls_amd.Context(0) as ctx:
     last = time.time()
+    turn = 0
     while time.time() < t_end:
-        nq_case(ctx)
+        nq_case(ctx if turn % 2 == 0 else ctx3)   # batched LS steps: resident server slots | fused launches
         sched_case(ctx)
         server_walk(ctx)
+        turn += 1
         if time.time() - last > 30:
             print("progress", stats, flush=True)
             last = time.time()
     cnt = ctx.counters()
+    cnt3 = ctx3.counters()
+    ctx3.close()
+    assert cnt3["server_requests"] == 0 and cnt3["completion_word_fallbacks"] == 0, cnt3
 # the slow branches of the latency-critical path must not have been taken silently
 assert cnt["completion_word_fallbacks"] == 0, cnt
 print("SOAK OK", stats, "seed", seed, "counters", cnt)
