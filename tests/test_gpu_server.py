@@ -178,6 +178,44 @@ def test_server_route_argument_errors_leave_the_slot_usable():
         assert c.counters()["server_boards_uploaded"] == 1       # the rejected board never reached the shadow
 
 
+def test_batched_step_on_server_slots_and_its_error_path():
+    # A batched call takes one server slot per restart (all requests in flight at once).  Walks of four restarts continuing
+    # from their winners, one restart perturbed in between; then a batch whose THIRD board is out of range: the call fails, the
+    # two requests already posted are answered and dropped, and the slots serve the next (valid) batch correctly.
+    import ls_amd
+    rng = np.random.default_rng(23)
+    n, R, mc, window = 1024, 4, 9, 5 * 1024
+    with ls_amd.Context(0) as c:
+        rows = np.stack([_board(rng, n, "uniform") for _ in range(R)])
+
+        def batch(rows):
+            cols = np.stack([rng.permutation(n)[:mc] for _ in range(R)])
+            cur = [int(orc.nq_col_scores_table(rows[r]).sum()) for r in range(R)]
+            out, nxt = c.nqueens_eval_batch_next(rows, cur, cols, [mc] * R, window)
+            boards = []
+            for r in range(R):
+                exp, board, cs = _expect(rows[r], cols[r], window)
+                assert (out[r]["n_scored"], out[r]["best_index"]) == (exp["n_scored"], exp["best_index"]), r
+                assert np.array_equal(nxt[r], cs), r
+                boards.append(board)
+            return np.stack(boards)
+
+        for it in range(12):
+            rows = batch(rows)
+            if it == 5:
+                rows[2] = _board(rng, n, "perm")
+        before = c.counters()["server_requests"]
+        assert before >= 12 * R                                  # the server is what ran
+        bad = rows.copy()
+        bad[2, 100] = -1
+        with pytest.raises(ls_amd.LsError) as ei:
+            c.nqueens_eval_batch_next(bad, [0] * R, np.tile(np.arange(mc), (R, 1)), [mc] * R, window)
+        assert ei.value.code == ls_amd._lib.LS_ERR_INVALID and "rows[100]" in str(ei.value)
+        for it in range(4):                                      # (restarts 0 and 1 moved on the device: their boards are re-read)
+            rows = batch(rows)
+        assert c.counters()["completion_word_fallbacks"] == 0
+
+
 def test_servers_of_two_contexts_on_two_threads():
     import threading
     import ls_amd
