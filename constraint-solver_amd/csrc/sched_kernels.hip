@@ -1720,6 +1720,7 @@ struct SchedGridArgs {
     unsigned long long ready_target; // g->ready once every workgroup of THIS launch has started (the host adds the grid size per launch)
     unsigned *rec;           // [n_chunks][8] every workgroup's record of the current request (tagged dwords)
     int emp_entries;         // entries of the workgroup's employee -> scored-days table in dynamic LDS (0: none, the scorers compare day by day)
+    int poll_delay;          // the finisher sleeps this many x 64 cycles before its first look at the records; < 0: adapts (starts at 6)
     int cpw;                 // 512-candidate chunks per workgroup (consecutive ones): 1 for a resident stream, up to four for the exhaustive proposer
 };
 
@@ -1766,6 +1767,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         }
     }
     unsigned last_seq = 0;
+    int pd = a.poll_delay < 0 ? 6 : a.poll_delay, calm = 0; // the finisher's wait before its first look at the records (x 64 cycles), requests without a second pass
     bool abort_launch = false; // workgroup 0: the workgroups of this launch are not all resident -- nothing is served, everybody leaves
     SrvPoll poll{0, 0, 0};
 #ifdef LS_NQ_STAMPS
@@ -1898,7 +1900,15 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
             // every workgroup's record of THIS request (nch <= 64 NW: one record per thread)
             unsigned rv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             bool given_up = false;
+            // A pass over the records is an L2-bypassing read of ~1.2 us; one that starts a moment too early misses the last records
+            // and a second full pass follows, so the answer wait depends on WHEN the first pass starts: measured on config 5 with fixed
+            // waits of 0 / 512 / 1024 cycles before it: 11.0 / 9.85 / 10.7 us on one build, 10.4 / 10.3 us on the next (a few
+            // instructions moved the edge).  The finisher keeps its wait just above the point where second passes appear:
+            // +2 x 64 cycles after a request that needed one, -1 after 64 requests that did not.
+            for (int w = 0; w < pd; w++) __builtin_amdgcn_s_sleep(1);
+            int passes = 0;
             for (;;) {
+                passes++;
                 bool ok = true;
                 if (tid < nch) {
 #pragma unroll
@@ -1913,6 +1923,10 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                 __syncthreads(); // ... and read by everybody before thread 0 writes it again
             }
             if (given_up) continue; // no answer: the host's wait finds the launch drained
+            if (a.poll_delay < 0) { // block-uniform
+                if (passes > 1) { pd = pd + 2 < 32 ? pd + 2 : 32; calm = 0; }
+                else if (++calm >= 64) { pd = pd > 0 ? pd - 1 : 0; calm = 0; }
+            }
             SCG_STAMP(6);
             if (window > 0) {
                 const int b = tid;
@@ -2543,6 +2557,7 @@ int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long l
             a.moves = gen ? nullptr : ctx->sc_resident_moves.as<ls_sched_move>();
             a.n_resident = gen ? (long long)ctx->sched.n_days_stored * ctx->sched.n_employees : ctx->sc_resident_n;
             a.cpw = cpw;
+            a.poll_delay = getenv("LS_SCHED_GRID_POLL_DELAY") ? atoi(getenv("LS_SCHED_GRID_POLL_DELAY")) : -1; // measurement knob; default: adaptive
             a.g = s->g;
             s->ready_total += (unsigned long long)n;
             a.ready_target = s->ready_total;
