@@ -287,6 +287,7 @@ def run_rank(args, rank, world, device, sync, launcher):
                     "table_64_restarts_frac": (ex.get("table_full_neighbourhood_64_restarts", {}).get("roofline") or {}).get("frac"),
                     "ls_step_round_trip_us_one_restart": st1.get("us_per_call_bare_c_entry") or st1.get("us_per_call"),
                     "ls_step_round_trip_us_one_restart_through_the_python_wrapper": st1.get("us_per_call"),
+                    "ls_step_round_trip_us_8_restarts_per_call": ex.get("fused_ls_step_host_round_trip_8_restarts", {}).get("us_per_call_bare_c_entry"),
                     "config4_end_to_end_s": e2e.get("seconds"), "config4_end_to_end_neighbours_per_s": e2e.get("neighbours_per_s"),
                     "config4_end_to_end_equals_single_solver_runs": (e2e.get("timed_run_vs_single_solver_runs_on_the_launch_per_call_route") or {}).get("equal")}
                 out["roofline"]["int_formulation"] = ex.get("scan_int_formulation_packed_u16")
@@ -670,36 +671,37 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True):
         on_server = ctx.counters()["server_requests"] - requests_before >= reps * RR
         c = kc.get(f"nq_step_kernel_r{RR}") or {}
         raw_us = None
-        if RR == 1:
+        if True:
             # the same loop on the bare C entry (arguments marshalled once): what a C / Rust caller pays per call
             import ctypes as C
             import ls_amd as _la
-            rows1, cur1 = np.ascontiguousarray(b_h[:1], np.int32), np.ascontiguousarray(c_h[:1], np.int64)
-            cols1, nc1 = np.ascontiguousarray(cols_h[:1], np.int32), np.ascontiguousarray(ncols_h[:1], np.int32)
-            res1, nxt1 = (_la.NqResult * 1)(), np.empty((1, n), dtype=np.int64)
+            rows1, cur1 = np.ascontiguousarray(b_h[:RR], np.int32), np.ascontiguousarray(c_h[:RR], np.int64)
+            cols1, nc1 = np.ascontiguousarray(cols_h[:RR], np.int32), np.ascontiguousarray(ncols_h[:RR], np.int32)
+            res1, nxt1 = (_la.NqResult * RR)(), np.empty((RR, n), dtype=np.int64)
             vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-            cargs = (ctx._h, 1, n, vp(rows1), vp(cur1), vp(cols1), vp(nc1), int(cols1.shape[1]), 5 * n, C.cast(res1, C.c_void_p), vp(nxt1))
+            cargs = (ctx._h, RR, n, vp(rows1), vp(cur1), vp(cols1), vp(nc1), int(cols1.shape[1]), 5 * n, C.cast(res1, C.c_void_p), vp(nxt1))
             fn = ctx._l.ls_nqueens_eval_batch_next
 
             def raw_step():
                 if fn(*cargs) != 0:
                     raise RuntimeError(ctx._l.ls_last_error(ctx._h).decode())
-                r = res1[0]
-                if r.best_index >= 0:
-                    rows1[0, r.best_col] = r.best_value
-                    cur1[0] = r.best_score
+                for rr in range(RR):
+                    r = res1[rr]
+                    if r.best_index >= 0:
+                        rows1[rr, r.best_col] = r.best_value
+                        cur1[rr] = r.best_score
 
             for _ in range(200):
                 raw_step()
             t0 = time.perf_counter()
-            for _ in range(5000):
+            for _ in range(5000 // RR):
                 raw_step()
-            raw_us = (time.perf_counter() - t0) / 5000 * 1e6
+            raw_us = (time.perf_counter() - t0) / (5000 // RR) * 1e6
         out[f"fused_ls_step_host_round_trip_{RR}_restarts"] = {
             "us_per_call": s * 1e6, "candidates_per_call": RR * min(5 * n, mc * (n - 1)),
             "us_per_call_bare_c_entry": raw_us,
             "note": "us_per_call includes ctypes/numpy marshalling of the Python wrapper (about 8 us); us_per_call_bare_c_entry calls the C entry "
-                    "with arguments marshalled once (still a Python loop: about 1 us of interpreter per call)",
+                    "with arguments marshalled once (still a Python loop: about 1 us of interpreter per call and restart)",
             "route": ("resident LS-step server (no launch per call" + ("" if RR == 1 else f": one slot per restart, {RR} requests in flight") + ")") if on_server
                      else "one fused LS-step launch per call",
             # a latency-bound launch: one 1024-thread block per restart; its issue bounds on the CUs it can occupy are a small
