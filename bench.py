@@ -256,6 +256,10 @@ def run_rank(args, rank, world, device, sync, launcher):
         all_recs = [r for g in gathered for r in g["recs"]]
         best = sharding.best_of(all_recs)
 
+        # the scheduling line (config 5 shape, one restart per rank): every rank takes part, also at N > 1
+        sched_line = None
+        if not args.no_sched:
+            sched_line = sched_rank_line(args, ctx, torch, dev, stream, rank, world, sync)
         out = None
         if world > 1:
             print(f"[bench rank {rank}] device {device}, host cores this rank may use: {host_core_share()} "
@@ -264,36 +268,84 @@ def run_rank(args, rank, world, device, sync, launcher):
             value = neighbours_per_step * world * args.steps / elapsed
             avg_launch_s = float(np.mean(launch_ms)) / 1e3
             out = build_report(args, world, R, n, info, value, elapsed, avg_launch_s, neighbours_per_step, window, best, launcher)
+            roof = out["roofline"]
             out["verified"] = verify_results(n, all_recs)           # every restart's record vs the oracle (after the timed region)
             if not out["verified"]["ok"]:
                 print(json.dumps(out), flush=True)
                 raise SystemExit("bench.py: the timed launch's results differ from the oracle")
+            if sched_line is not None:
+                out["sched"] = sched_line
+                roof["sched_gpu_per_s"] = sched_line["value"]
+                roof["sched_gpu_us_per_step"] = sched_line["us_per_step"]
+                roof["sched_verified"] = bool(sched_line["verified"]["ok"])
+                if not sched_line["verified"]["ok"]:
+                    print(json.dumps(out), flush=True)
+                    raise SystemExit("bench.py: the timed scheduling launch's results differ from the oracle")
             if not args.no_cpu_baseline and world == 1:
                 cb, ns, cb_best = cpu_baseline(n, boards[0], args.cpu_seconds)
                 out["cpu_baseline"] = cb
                 out["cpu_baseline"]["gpu_over_cpu"] = value / cb["value"]
             if not args.no_extra and world == 1:
                 with torch.cuda.stream(stream):
-                    out["extra"] = extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=not args.no_e2e)
+                    out["extra"] = extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=not args.no_e2e,
+                                                      sched_cpu_seconds=0.0 if args.no_cpu_baseline else 0.4)
                 ex = out["extra"]
                 # what LS_NQ_ALGO_AUTO (the library default) gives a caller, next to the headline scan kernel: kept inside
                 # `roofline` so that it survives consumers that drop `extra`
                 tb, e2e = ex.get("table_full_neighbourhood", {}), ex.get("config4_end_to_end_64_restarts_one_gpu", {})
+                tb64 = ex.get("table_full_neighbourhood_64_restarts", {})
                 st1 = ex.get("fused_ls_step_host_round_trip_1_restarts", {})  # (bare C entry where measured)
-                out["roofline"]["default_path"] = {
+                eq = (e2e.get("timed_run_vs_single_solver_runs_on_the_launch_per_call_route") or {}).get("equal")
+                roof["default_path"] = {
                     "table_neighbours_per_s": tb.get("neighbours_per_s"), "table_frac": (tb.get("roofline") or {}).get("frac"),
                     "table_bound": (tb.get("roofline") or {}).get("bound"),
-                    "table_64_restarts_neighbours_per_s": ex.get("table_full_neighbourhood_64_restarts", {}).get("neighbours_per_s"),
-                    "table_64_restarts_frac": (ex.get("table_full_neighbourhood_64_restarts", {}).get("roofline") or {}).get("frac"),
+                    "table_64_restarts_neighbours_per_s": tb64.get("neighbours_per_s"),
+                    "table_64_restarts_frac": (tb64.get("roofline") or {}).get("frac"),
                     "ls_step_round_trip_us_one_restart": st1.get("us_per_call_bare_c_entry") or st1.get("us_per_call"),
                     "ls_step_round_trip_us_one_restart_through_the_python_wrapper": st1.get("us_per_call"),
                     "ls_step_round_trip_us_8_restarts_per_call": ex.get("fused_ls_step_host_round_trip_8_restarts", {}).get("us_per_call_bare_c_entry"),
                     "config4_end_to_end_s": e2e.get("seconds"), "config4_end_to_end_neighbours_per_s": e2e.get("neighbours_per_s"),
-                    "config4_end_to_end_equals_single_solver_runs": (e2e.get("timed_run_vs_single_solver_runs_on_the_launch_per_call_route") or {}).get("equal")}
-                out["roofline"]["int_formulation"] = ex.get("scan_int_formulation_packed_u16")
-                if e2e.get("error"):
+                    "config4_end_to_end_equals_single_solver_runs": eq}
+                roof["int_formulation"] = ex.get("scan_int_formulation_packed_u16")
+                # the same facts as FLAT scalars: consumers of the line keep scalar keys of `roofline` only
+                hs = roof.get("hbm_effective_secondary") or {}
+                flat = {
+                    "table_frac": (tb.get("roofline") or {}).get("frac"), "table_per_s": tb.get("neighbours_per_s"),
+                    "table_r64_frac": (tb64.get("roofline") or {}).get("frac"), "table_r64_per_s": tb64.get("neighbours_per_s"),
+                    "int_formulation_per_s": (ex.get("scan_int_formulation_packed_u16") or {}).get("neighbours_per_s"),
+                    "hbm_measured_bytes": hs.get("measured_hbm_bytes_per_launch"), "hbm_effective_over_peak": hs.get("effective_over_hbm_peak"),
+                    "ls_step_us": st1.get("us_per_call_bare_c_entry") or st1.get("us_per_call"),
+                    "c4_e2e_s": e2e.get("seconds"), "c4_e2e_per_s": e2e.get("neighbours_per_s"), "c4_e2e_equal": eq,
+                    "c2_us_per_ls_iteration": (ex.get("config2_end_to_end_nq1024_seed42") or {}).get("us_per_ls_iteration"),
+                    "c3_us_per_ls_iteration": (ex.get("config3_end_to_end_sched_example_seed42") or {}).get("us_per_ls_iteration"),
+                    "c5_us_per_ls_iteration": (ex.get("config5_end_to_end_sched10k_window65536_seed42") or {}).get("us_per_ls_iteration"),
+                    "sched_legs_verified": (ex.get("sched_verified") or {}).get("ok"),
+                }
+                legs = (ex.get("sched_cpu_baseline") or {}).get("legs") or {}
+                c5 = legs.get("sched10k_random_stream_window_65536") or {}
+                flat.update({"sched_cpu_per_s": c5.get("one_core_per_s"), "sched_cpu_all_cores_per_s": c5.get("all_cores_per_s"),
+                             "sched_cpu_cores": c5.get("cores"),
+                             "sched_example_cpu_per_s": (legs.get("sched_example_window100") or {}).get("one_core_per_s"),
+                             "sched_exhaustive_cpu_per_s": (legs.get("sched10k_exhaustive_320k") or {}).get("one_core_per_s"),
+                             "sched_exhaustive_gpu_per_s": (ex.get("sched10k_exhaustive_320k") or {}).get("neighbours_per_s"),
+                             "sched_example_x64_gpu_per_s": (ex.get("sched_example_window100_x64_restarts") or {}).get("neighbours_per_s")})
+                ms = ex.get("config3_multi_restart_end_to_end") or {}
+                flat.update({"c3_x64_e2e_per_s": ms.get("neighbours_per_s"), "c3_x64_e2e_equal": ms.get("equal_single_solver_runs")})
+                m5 = ex.get("config5_multi_restart_end_to_end") or {}
+                flat.update({"c5_x8_e2e_s": m5.get("seconds"), "c5_x8_over_single": m5.get("wall_over_single_restart"),
+                             "c5_x8_e2e_equal": m5.get("equal_single_solver_runs")})
+                roof.update({k: v for k, v in flat.items() if v is not None})
+                if "cpu_baseline" in out and c5.get("one_core_per_s"):
+                    out["cpu_baseline"]["sched_value"] = c5["one_core_per_s"]
+                    out["cpu_baseline"]["sched_all_cores_value"] = c5.get("all_cores_per_s")
+                    out["cpu_baseline"]["sched_sample"] = (f"first {c5.get('one_core_sample')} candidates of the window-65536 move list at 10 000 employees "
+                                                           f"(full get_scored_solution each), {c5.get('one_core_seconds', 0):.2f} s on one core; "
+                                                           f"{c5.get('cores')} cores: {c5.get('all_cores_sample')} candidates in {c5.get('all_cores_seconds', 0):.2f} s")
+                failed = [k for k in ("config4_end_to_end_64_restarts_one_gpu", "config3_multi_restart_end_to_end", "config5_multi_restart_end_to_end")
+                          if (ex.get(k) or {}).get("error")]
+                if failed or not (ex.get("sched_verified") or {"ok": True})["ok"]:
                     print(json.dumps(out), flush=True)
-                    raise SystemExit("bench.py: " + str(e2e["error"]))
+                    raise SystemExit("bench.py: " + (str(ex[failed[0]]["error"]) if failed else "a timed scheduling launch differs from the oracle"))
             print(json.dumps(out), flush=True)
         sync.barrier()
         ctx.set_stream(None)
@@ -458,6 +510,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-sched", action="store_true", help="skip the scheduling line (config 5 shape, one restart per rank)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs of `extra` (config 2-5 solver runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse ranks on one GPU)")
     ap.add_argument("--all-on-device", type=int, default=None,
@@ -532,7 +585,7 @@ def main():
         dist.destroy_process_group()
 
 
-def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True):
+def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True, sched_cpu_seconds=0.4):
     """Secondary lines (not `value`): the other kernel family on the same workload and the
     reference-shaped small launch (<= 204 proposed columns, window 5n), SURVEY 8(d) config 4."""
     out = {}
@@ -712,7 +765,7 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True):
         out["config4_end_to_end_64_restarts_one_gpu"] = config4_end_to_end(ctx, n)
         out.update(single_restart_end_to_end(ctx))
     ctx.set_algo("scan")
-    out.update(sched_measurements(ctx, torch, dev, timed, issue_roofline))
+    out.update(sched_measurements(ctx, torch, dev, timed, issue_roofline, cpu_seconds=max(sched_cpu_seconds, 0.05)))
     # the HBM figure the rooflines divide by is the vendor's 8 TB/s; this is what a plain device-to-device
     # copy of 2 GiB reaches on this box (torch's copy kernel; bytes read + bytes written per second)
     try:
@@ -840,52 +893,225 @@ def single_restart_end_to_end(ctx):
     return out
 
 
-def sched_measurements(ctx, torch, dev, timed, issue_roofline):
-    """Scheduling path, kernel throughput with moves and states resident in HBM."""
+# ------------------------------------------------------------------------------------------------ scheduling workloads
+SCHED_D, SCHED_S = 31, 32          # examples/employee-scheduling/src/main.rs:11-12: 31 scored days, 32 stored (lib.rs:407-411)
+
+
+def sched_random_moves(rng, n, D, E):
+    """A list shaped like ScheduleRandomMoveProposer's stream (lib.rs:444-490): ChangeDay : SwapDays = 1 : 4, a swap's two
+    days distinct.  (Synthetic: the real stream comes from the host driver's generator; the kernels do not care.)"""
+    mv = np.zeros((n, 3), dtype=np.int32)
+    change = rng.integers(0, 5, size=n) == 0
+    a = rng.integers(0, D, size=n)
+    mv[:, 0] = np.where(change, 0, 1)
+    mv[:, 1] = a
+    mv[:, 2] = np.where(change, rng.integers(0, E, size=n), (a + 1 + rng.integers(0, D - 1, size=n)) % D)
+    return mv
+
+
+def sched_holidays_10k(E=10_000, D=SCHED_D, seed=2022):
+    """every employee gets h ~ U{0..3} distinct holidays, uniform over the scored days."""
+    rng = np.random.default_rng(seed)
+    h = rng.integers(0, 4, size=E)
+    days = np.argsort(rng.random((E, D)), axis=1)[:, :3]      # three distinct days per employee, the first h[e] are used
+    bits = np.zeros(E, dtype=np.uint64)
+    for k in range(3):
+        bits |= np.where(h > k, np.uint64(1) << days[:, k].astype(np.uint64), np.uint64(0))
+    return bits
+
+
+def sched_oracle_instance(bits=None):
+    """The oracle's view of an instance: the example's dates (2022-05-09 .. 2022-06-08) + holidays from the bit masks."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    orc.build()
+    hol = {}
+    if bits is not None:
+        for e in np.nonzero(bits)[0]:
+            hol[int(e)] = [d for d in range(SCHED_D) if (int(bits[e]) >> d) & 1]
+    return orc.Sched((2022, 5, 9), (2022, 6, 8), hol)
+
+
+def _sched_apply(state, m):
+    c = [int(x) for x in state]
+    if m[0] == 0:
+        c[m[1]] = int(m[2])
+    else:
+        c[m[1]], c[m[2]] = int(state[m[2]]), int(state[m[1]])
+    return tuple(c)
+
+
+def sched_oracle_record(inst, state, moves, window, threads=1):
+    """local_search.rs:315-325 by the oracle's literal pipeline (clone + tabu test + full get_scored_solution per candidate,
+    minimum by (hard, soft, vector), first of equals) -> (n_scored, best_index, hard, soft).  The list prefix take(window)
+    reaches is cut into `threads` slices scored in parallel (ctypes releases the GIL); the slices' minima are combined in
+    the same order.  Checker only: never the thing measured."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    st = np.asarray(state, dtype=np.int64)
+    mv = np.ascontiguousarray(np.asarray(moves, dtype=np.int64).reshape(-1, 3))
+    if len(mv) == 0 or window <= 0:
+        return (0, -1, 0, 0)
+    real = np.where(mv[:, 0] == 0, st[mv[:, 1]] != mv[:, 2], st[mv[:, 1]] != st[np.minimum(mv[:, 2], len(st) - 1)])
+    cum = np.cumsum(real)
+    n_scored = int(min(cum[-1], window))
+    if n_scored == 0:
+        return (0, -1, 0, 0)
+    k_end = int(np.searchsorted(cum, n_scored)) + 1
+    bounds = np.linspace(0, k_end, max(1, threads) + 1).astype(int)
+
+    def one(t):
+        lo, hi = bounds[t], bounds[t + 1]
+        if hi <= lo:
+            return None
+        r = inst.neighbourhood(st, mv[lo:hi], 1 << 62, want_scores=False)
+        if r["best_index"] < 0:
+            return None
+        k = lo + r["best_index"]
+        return (r["best_hard"], r["best_soft"], _sched_apply(st, mv[k]), k)
+
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        parts = [p for p in ex.map(one, range(len(bounds) - 1)) if p is not None]
+    h, so, _, k = min(parts)
+    return (n_scored, int(k), int(h), int(so))
+
+
+def sched_cpu_rate(inst, state, moves, window, seconds, threads):
+    """Candidates / second of the oracle's literal scheduling pipeline (the reference's work per candidate,
+    examples/employee-scheduling/src/lib.rs:265-374) on a bounded sample of one workload: the first candidates of the SAME
+    move list the GPU leg times, on one core, and -- one disjoint slice of the list per thread -- on `threads` cores."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    st = np.asarray(state, dtype=np.int64)
+    mv = np.ascontiguousarray(np.asarray(moves, dtype=np.int64).reshape(-1, 3))
+    t0 = time.perf_counter()
+    r = inst.neighbourhood(st, mv[:256], 1 << 62, want_scores=False)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    rate0 = max(r["n_scored"], 1) / dt
+    sample = int(max(64, min(min(window, len(mv)), rate0 * seconds)))
+    t0 = time.perf_counter()
+    r = inst.neighbourhood(st, mv[:sample + sample // 8], sample, want_scores=False)
+    dt1 = time.perf_counter() - t0
+    one = r["n_scored"] / max(dt1, 1e-9)
+    per = max(64, min(len(mv) // max(1, threads), sample))
+
+    def leg(t):
+        return inst.neighbourhood(st, mv[t * per:(t + 1) * per], 1 << 62, want_scores=False)["n_scored"]
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        tot = sum(ex.map(leg, range(threads)))
+    dtn = time.perf_counter() - t0
+    return {"one_core_per_s": one, "one_core_sample": int(r["n_scored"]), "one_core_seconds": dt1,
+            "all_cores_per_s": tot / max(dtn, 1e-9), "cores": threads, "all_cores_sample": int(tot), "all_cores_seconds": dtn}
+
+
+def sched_rank_line(args, ctx, torch, dev, stream, rank, world, sync):
+    """The scheduling line every run carries, also at --gpus N > 1 (10 000 employees x 31 days, ONE
+    restart per GPU, the random proposer's stream with window 65 536): kernel throughput with state and move list resident
+    in HBM, barrier + synchronise on both sides, MAX over ranks; each rank's timed result record is then re-checked against
+    the oracle's literal pipeline.  Called by ALL ranks (it has barriers)."""
+    E, n_moves, window, steps, warm = 10_000, 70_000, 65_536, 50, 5
+    bits = sched_holidays_10k(E)
+    rid = rank                                     # global restart id: one restart per rank
+    rng = np.random.default_rng(7000 + rid)
+    state_np = rng.integers(0, E, size=(1, SCHED_S)).astype(np.int32)
+    moves_np = sched_random_moves(rng, n_moves, SCHED_D, E)
+    ctx.sched_instance_upload(SCHED_D, SCHED_S, 0, E, bits)
+    with torch.cuda.stream(stream):
+        states = torch.from_numpy(state_np).to(dev)
+        mv = torch.from_numpy(moves_np[None]).to(dev)
+        nm = torch.full((1,), n_moves, dtype=torch.int64, device=dev)
+        res = torch.zeros((1, 4), dtype=torch.int64, device=dev)
+
+        def step():
+            ctx.sched_eval_batch_dev(1, states.data_ptr(), mv.data_ptr(), nm.data_ptr(), n_moves, window, res.data_ptr())
+
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize(dev)
+        sync.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        sync.barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        rec = tuple(int(x) for x in res.cpu().numpy()[0])
+    t0 = time.perf_counter()
+    exp = sched_oracle_record(sched_oracle_instance(bits), state_np[0], moves_np, window, threads=host_core_share())
+    t_check = time.perf_counter() - t0
+    gathered = sync.all_gather(rank, dict(elapsed=elapsed, n_scored=rec[0], ok=(rec == exp), rid=rid, got=rec, want=exp))
+    if rank != 0:
+        return None
+    elapsed = max(g["elapsed"] for g in gathered)
+    total = sum(g["n_scored"] for g in gathered)
+    bad = [g["rid"] for g in gathered if not g["ok"]]
+    return {"metric": "scheduling neighbour evals/sec (10 000 employees x 31 days, one restart per GPU, random stream, window 65 536)",
+            "value": total * steps / elapsed, "unit": "neighbour evals/s", "n_gpus": world, "steps": steps, "warmup": warm,
+            "us_per_step": elapsed / steps * 1e6, "scaling": "weak", "restarts": world, "candidates_per_step_per_gpu": gathered[0]["n_scored"],
+            "effective_GBps_at_144B": total * steps * 144 / elapsed / 1e9,
+            "verified": {"ok": not bad, "restarts_checked": len(gathered), "mismatching_restarts": bad, "seconds": t_check,
+                         "against": "oracle/sched_oracle.c literal pipeline, (n_scored, best_index, hard, soft) per restart",
+                         "first_mismatch": None if not bad else next(dict(got=g["got"], want=g["want"]) for g in gathered if not g["ok"])}}
+
+
+def sched_measurements(ctx, torch, dev, timed, issue_roofline, cpu_seconds=0.4):
+    """Scheduling path: kernel throughput with moves and states resident in HBM; every timed
+    launch's result records re-checked against the oracle AFTER the timed region; the oracle's literal pipeline timed on the
+    same move lists beside it (one core, all host cores: a reported baseline, not a target)."""
     out = {}
     rng = np.random.default_rng(2022)
-
-    def random_moves(n, D, E):
-        mv = np.zeros((n, 3), dtype=np.int32)
-        for i in range(n):
-            if rng.integers(0, 5) == 0:
-                mv[i] = (0, rng.integers(0, D), rng.integers(0, E))
-            else:
-                a, b = rng.choice(D, size=2, replace=False)
-                mv[i] = (1, a, b)
-        return mv
+    cores = host_core_share()
+    verified, cpu = {}, {}
 
     # config 3 shape: example instance (7 employees, 31/32 days), window 100, 64 restarts per launch
-    D, S, E, R, W = 31, 32, 7, 64, 100
+    D, S, E, R, W = SCHED_D, SCHED_S, 7, 64, 100
     ctx.sched_instance_upload(D, S, 0, E)
-    states = torch.from_numpy(rng.integers(0, E, size=(R, S)).astype(np.int32)).to(dev)
-    mv = torch.from_numpy(np.stack([random_moves(160, D, E) for _ in range(R)])).to(dev)
+    inst7 = sched_oracle_instance(None)
+    st7 = rng.integers(0, E, size=(R, S)).astype(np.int32)
+    mv7 = np.stack([sched_random_moves(rng, 160, D, E) for _ in range(R)])
+    states = torch.from_numpy(st7).to(dev)
+    mv = torch.from_numpy(mv7).to(dev)
     nm = torch.full((R,), 160, dtype=torch.int64, device=dev)
     res = torch.zeros((R, 4), dtype=torch.int64, device=dev)
     s = timed(lambda: ctx.sched_eval_batch_dev(R, states.data_ptr(), mv.data_ptr(), nm.data_ptr(), 160, W, res.data_ptr()), 200)
+    torch.cuda.synchronize()
+    got = res.cpu().numpy()
+    bad = [r for r in range(R) if tuple(int(x) for x in got[r]) != sched_oracle_record(inst7, st7[r], mv7[r], W)]
+    verified["sched_example_window100_x64_restarts"] = {"ok": not bad, "records_checked": R, "mismatching": bad}
+    cpu["sched_example_window100"] = sched_cpu_rate(inst7, st7[0], np.concatenate(list(mv7)), 10 ** 9, cpu_seconds, cores)
     out["sched_example_window100_x64_restarts"] = {"neighbours_per_s": R * W / s, "us_per_launch": s * 1e6,
-                                                   "candidates_per_launch": R * W}
+                                                   "candidates_per_launch": R * W,
+                                                   "cpu_one_core_per_s": cpu["sched_example_window100"]["one_core_per_s"]}
     # config 5 shape: 10 000 employees, holidays U{0..3} per employee, one restart per GPU
     E = 10_000
-    bits = np.zeros(E, dtype=np.uint64)
-    for e in range(E):
-        for d in rng.choice(D, size=int(rng.integers(0, 4)), replace=False):
-            bits[e] |= np.uint64(1) << np.uint64(d)
+    bits = sched_holidays_10k(E)
+    inst10k = sched_oracle_instance(bits)
     ctx.sched_instance_upload(D, S, 0, E, bits)
     state_np = rng.integers(0, E, size=(1, S)).astype(np.int32)
     states = torch.from_numpy(state_np).to(dev)
     ex = ctx.sched_exhaustive_moves(state_np)[0]       # exhaustive ScheduleMoveProposer order (lib.rs:493-559), built on the device
     res = torch.zeros((1, 4), dtype=torch.int64, device=dev)
     for name, moves, window in (("sched10k_exhaustive_320k", ex, 10 ** 9),
-                                ("sched10k_random_stream_window_65536", random_moves(70_000, D, E), 65_536)):
+                                ("sched10k_random_stream_window_65536", sched_random_moves(rng, 70_000, D, E), 65_536)):
         mv = torch.from_numpy(moves[None]).to(dev)
         nm = torch.full((1,), len(moves), dtype=torch.int64, device=dev)
         s = timed(lambda: ctx.sched_eval_batch_dev(1, states.data_ptr(), mv.data_ptr(), nm.data_ptr(), len(moves), window,
                                                    res.data_ptr()), 50)
         torch.cuda.synchronize()
-        n_scored = int(res.cpu().numpy()[0, 0])
+        rec = tuple(int(x) for x in res.cpu().numpy()[0])
+        t0 = time.perf_counter()
+        exp = sched_oracle_record(inst10k, state_np[0], moves, window, threads=cores)
+        verified[name] = {"ok": rec == exp, "records_checked": 1, "oracle_seconds": time.perf_counter() - t0,
+                          **({} if rec == exp else {"got": rec, "want": exp})}
+        cpu[name] = sched_cpu_rate(inst10k, state_np[0], moves, window, cpu_seconds, cores)
+        n_scored = rec[0]
         out[name] = {"neighbours_per_s": n_scored / s, "us_per_launch": s * 1e6, "candidates_per_launch": n_scored,
                      "effective_GBps_at_144B": n_scored * 144 / s / 1e9,
+                     "cpu_one_core_per_s": cpu[name]["one_core_per_s"], "cpu_all_cores_per_s": cpu[name]["all_cores_per_s"],
                      "roofline_eval_kernel_bound_over_whole_chain_time": issue_roofline("sched_eval_all_kernel_exhaustive_list" if "exhaustive" in name
                                                                  else "sched_eval_all_kernel_random65536", s)}
     # the same exhaustive neighbourhood through the host entry that generates the move list on the device:
@@ -899,11 +1125,19 @@ def sched_measurements(ctx, torch, dev, timed, issue_roofline):
         r0 = ctx.sched_eval_exhaustive(state_np, 10 ** 9)[0]
     s = (time.perf_counter() - t0) / reps
     on_grid = ctx.counters()["server_requests"] - before >= reps
+    want = sched_oracle_record(inst10k, state_np[0], ex, 10 ** 9, threads=cores)
+    got_rt = (r0["n_scored"], r0["best_index"], r0["best_hard"], r0["best_soft"])
+    verified["sched10k_exhaustive_320k_host_round_trip"] = {"ok": got_rt == want, "records_checked": 1}
     out["sched10k_exhaustive_320k_host_round_trip_generated_on_device"] = {
         "neighbours_per_s": r0["n_scored"] / s, "us_per_call": s * 1e6, "candidates_per_call": r0["n_scored"],
         "route": "resident grid (no launch per call; candidates generated in the kernel, one workgroup per three 512-candidate chunks)" if on_grid
                  else "two launches per call (sched_eval_all_kernel + sched_finish_kernel)",
         "note": "includes about 4 us of ctypes / numpy marshalling in the Python wrapper (tools/exhaustive_grid_trace.py times the bare C entry)"}
+    out["sched_verified"] = {"ok": all(v["ok"] for v in verified.values()), "legs": verified,
+                             "against": "oracle/sched_oracle.c: literal clone + tabu test + get_scored_solution per candidate, after the timed regions"}
+    out["sched_cpu_baseline"] = {"kind": "port", "unit": "neighbour evals/s", "legs": cpu,
+                                 "note": "the oracle's literal scheduling pipeline (examples/employee-scheduling/src/lib.rs:265-374 per candidate) on "
+                                         "bounded samples of the same move lists; the reference is single-threaded Rust, unbuildable here"}
     return out
 
 

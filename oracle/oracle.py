@@ -179,19 +179,18 @@ class Sched:
             raise RuntimeError(f"oracle sched score rc={rc}")
         return (h.value, s.value, t) if terms else (h.value, s.value)
 
-    def neighbourhood(self, e, moves, window):
-        """moves: array-like [n_moves, 3] of (type, a, b)."""
+    def neighbourhood(self, e, moves, window, want_scores=True):
+        """moves: array-like [n_moves, 3] of (type, a, b) (an int64 array is passed to C as it is)."""
         a = _a64(e)
         m = _a64(moves).reshape(-1, 3)
-        mv = (SchedMove * len(m))()
-        for i, (t, x, y) in enumerate(m):
-            mv[i].type, mv[i].a, mv[i].b = int(t), int(x), int(y)
-        hard = np.empty(len(m), dtype=np.int64)
-        soft = np.empty(len(m), dtype=np.int64)
+        mv = C.cast(m.ctypes.data, C.POINTER(SchedMove))  # SchedMove = three int64: the array IS the move list
+        hard = np.empty(len(m), dtype=np.int64) if want_scores else None
+        soft = np.empty(len(m), dtype=np.int64) if want_scores else None
         ns, bi, bh, bs = _i64(0), _i64(0), _i64(0), _i64(0)
         rc = lib().orc_sched_neighbourhood(
             C.byref(self.inst), _ptr(a), len(a), mv, len(m), int(window),
-            _ptr(hard), _ptr(soft), C.byref(ns), C.byref(bi), C.byref(bh), C.byref(bs))
+            _ptr(hard) if want_scores else None, _ptr(soft) if want_scores else None,
+            C.byref(ns), C.byref(bi), C.byref(bh), C.byref(bs))
         if rc != 0:
             raise RuntimeError(f"oracle sched neighbourhood rc={rc}")
         return dict(n_scored=ns.value, best_index=bi.value, best_hard=bh.value,
