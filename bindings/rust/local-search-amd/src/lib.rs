@@ -237,6 +237,52 @@ impl GpuContext {
     }
 }
 
+/// Many independent scheduling restarts on one GPU (ls_multi_solver_create_sched): every restart is the unchanged get_ils
+/// driver (examples/employee-scheduling/src/lib.rs:57-117) under its own seed (convention of examples/nqueens/src/main.rs:167);
+/// the restarts are the slots of ONE resident launch.  `best(r)` = ((hard, soft), employee indices of the stored days).
+pub struct MultiSchedSolver {
+    raw: *mut sys::ls_multi_solver,
+    n_stored: usize,
+}
+
+impl MultiSchedSolver {
+    pub fn new(ctx: &mut GpuContext, n_days_scored: usize, start_weekday: u32, holiday_bits: &[u64], seeds: &[&str],
+               params: &sys::ls_solver_params) -> Result<Self, LsError> {
+        let owned: Vec<std::ffi::CString> = seeds.iter().map(|s| std::ffi::CString::new(*s).expect("seed without NUL")).collect();
+        let ptrs: Vec<*const std::os::raw::c_char> = owned.iter().map(|s| s.as_ptr()).collect();
+        let mut raw = std::ptr::null_mut();
+        let rc = unsafe {
+            sys::ls_multi_solver_create_sched(ctx.raw, n_days_scored as i32, start_weekday as i32, holiday_bits.len() as i32,
+                                              holiday_bits.as_ptr(), ptrs.len() as i32, ptrs.as_ptr(), params, &mut raw)
+        };
+        ctx.check(rc)?;
+        Ok(MultiSchedSolver { raw, n_stored: n_days_scored + 1 })
+    }
+
+    pub fn run(&mut self, max_rounds_per_restart: u64, max_seconds: f64) -> Result<(), LsError> {
+        let rc = unsafe { sys::ls_multi_solver_run(self.raw, max_rounds_per_restart, max_seconds) };
+        if rc == 0 { Ok(()) } else { Err(LsError { code: rc, message: String::from("ls_multi_solver_run failed") }) }
+    }
+
+    pub fn best(&self, restart: usize) -> Option<((i64, i64), Vec<i64>)> {
+        let (mut score, mut sol, mut len, mut have) = ([0i64; 2], vec![0i64; self.n_stored], 0i32, 0);
+        let rc = unsafe {
+            sys::ls_multi_solver_get_best(self.raw, restart as i32, score.as_mut_ptr(), sol.as_mut_ptr(), self.n_stored as i32, &mut len, &mut have)
+        };
+        if rc != 0 || have == 0 { return None; }
+        sol.truncate(len as usize);
+        Some(((score[0], score[1]), sol))
+    }
+}
+
+impl Drop for MultiSchedSolver {
+    fn drop(&mut self) {
+        unsafe {
+            sys::ls_multi_solver_free(self.raw);
+        }
+    }
+}
+
 impl Drop for GpuContext {
     fn drop(&mut self) {
         unsafe {

@@ -102,6 +102,9 @@ extern "C" {
     pub fn ls_multi_solver_create_nqueens(ctx: *mut ls_ctx, board_size: u64, n_restarts: i32,
                                           seeds: *const *const c_char, params: *const ls_solver_params,
                                           out: *mut *mut ls_multi_solver) -> c_int;
+    pub fn ls_multi_solver_create_sched(ctx: *mut ls_ctx, n_days_scored: i32, start_weekday: i32, n_employees: i32,
+                                        holiday_bits: *const u64, n_restarts: i32, seeds: *const *const c_char,
+                                        params: *const ls_solver_params, out: *mut *mut ls_multi_solver) -> c_int;
     pub fn ls_multi_solver_configure(m: *mut ls_multi_solver, n_slots: i32, mode: i32) -> c_int;
     pub fn ls_multi_solver_run(m: *mut ls_multi_solver, max_rounds_per_restart: u64, max_seconds: c_double) -> c_int;
     pub fn ls_multi_solver_get_best(m: *const ls_multi_solver, restart: i32, score: *mut i64, solution: *mut i64,

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libls_amd.so")
-SOURCES = ["ls_api.hip", "nq_kernels.hip", "nq_server.hip", "sched_kernels.hip", "ls_solver.hip"]
+SOURCES = ["ls_api.hip", "nq_kernels.hip", "nq_server.hip", "sched_wave.hip", "sched_delta.hip", "sched_server.hip", "sched_grid.hip", "ls_solver.hip"]
 ARCH = "gfx950"
 
 

@@ -35,6 +35,14 @@
 #include <thread>
 #include <vector>
 
+// spin-wait hint: `pause` on x86-64, nothing elsewhere (the ucontext fallback below is what a non-x86 host builds)
+static inline void fiber_cpu_relax()
+{
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
+
 #if !defined(__x86_64__)
 #include <ucontext.h>
 #endif
@@ -151,7 +159,7 @@ private:
         std::atomic_flag lock = ATOMIC_FLAG_INIT;
         std::vector<Fiber *> mine;   // this worker's fibres that are not finished (running or suspended); guarded by `lock`
         std::atomic<int> n_mine{0};  // mine.size(), readable without the lock (thieves look for the fullest worker)
-        void acquire() { while (lock.test_and_set(std::memory_order_acquire)) { __builtin_ia32_pause(); } }
+        void acquire() { while (lock.test_and_set(std::memory_order_acquire)) { fiber_cpu_relax(); } }
         void release() { lock.clear(std::memory_order_release); }
         Fiber *current = nullptr;    // the fibre this worker is running
         uint64_t forced = 0;         // fibres resumed without their answer
@@ -302,7 +310,7 @@ private:
                     if (w.n_mine.load(std::memory_order_relaxed) == 0) { // nothing to take: the others run one fibre each
                         // back off: spin, then yield, then sleep -- at the tail of a run most workers are here while the longest
                         // restarts finish on the others, and a spinning hyper-thread takes issue slots from its busy sibling
-                        if (++idle <= 64) { for (int k = 0; k < 32; k++) __builtin_ia32_pause(); }
+                        if (++idle <= 64) { for (int k = 0; k < 32; k++) fiber_cpu_relax(); }
                         else if (idle <= 64 + 16) sched_yield();
                         else {
                             struct timespec ts = {0, 20000}; // 20 us
@@ -310,7 +318,7 @@ private:
                         }
                     } else idle = 0;
                 } else {
-                    __builtin_ia32_pause(); // all of this worker's fibres wait for the GPU
+                    fiber_cpu_relax(); // all of this worker's fibres wait for the GPU
                 }
                 continue;
             }

@@ -1,6 +1,6 @@
 // ls_api.hip — the extern "C" boundary declared in include/ls_amd.h: context
 // life-cycle, argument validation, host<->device staging.  Kernels live in
-// nq_kernels.hip / sched_kernels.hip.  No CPU fallback exists anywhere in this
+// nq_kernels.hip / nq_server.hip / sched_*.hip.  No CPU fallback exists anywhere in this
 // library: without a HIP device ls_ctx_create fails.
 #include <immintrin.h>
 #include <sched.h>
@@ -44,7 +44,7 @@ bool nq_step_eligible(const ls_ctx *ctx, int n, int max_cols, long long window);
 int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long long *cur, const int *cols,
                 const int *n_cols, int max_cols, long long window, ls_nq_result *results, int *next_rows,
                 long long *next_col_scores, long long *next_totals, const NqStepExtra *extra, const NqStepInline *inl = nullptr);
-// sched_kernels.hip
+// sched_wave.hip / sched_delta.hip
 int sched_score_dev(ls_ctx *ctx, int n_states, const int *states_d, long long *hard_d, long long *soft_d,
                     long long *terms_d);
 int sched_eval_batch_dev(ls_ctx *ctx, int n_restarts, const int *states_d, const ls_sched_move *moves_d,
@@ -63,7 +63,7 @@ static void for_each_buf(ls_ctx *ctx, void (*f)(DevBuf &))
     DevBuf *bufs[] = {&ctx->nq_rows, &ctx->nq_cur, &ctx->nq_cols, &ctx->nq_ncols, &ctx->nq_results,
                       &ctx->nq_scores, &ctx->nq_keys, &ctx->nq_tabs, &ctx->nq_colscores, &ctx->nq_totals, &ctx->nq_next_rows,
                       &ctx->sc_states, &ctx->sc_moves, &ctx->sc_nmoves, &ctx->sc_results, &ctx->sc_hard,
-                      &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sc_cand_keys, &ctx->sc_ticket, &ctx->sched.holiday_bits, &ctx->sched.lane_tab,
+                      &ctx->sc_soft, &ctx->sc_keys, &ctx->sc_terms, &ctx->sc_cand_keys, &ctx->sched.holiday_bits, &ctx->sched.lane_tab,
                       &ctx->sc_resident_moves};
     for (DevBuf *b : bufs) f(*b);
 }
@@ -102,6 +102,7 @@ int nq_ctx_server(ls_ctx *ctx, int n, NqServer **out, int slots)
     }
     NqServer *s = nullptr;
     const int rc = nq_server_create(ctx, n, slots, &s);
+    if (rc == LS_ERR_UNSUPPORTED) return LS_OK; // more slots than the device holds resident: the caller launches per call
     if (rc != LS_OK) return rc;
     ctx->server = s; ctx->server_slot = 0; ctx->server_owned = true;
     *out = s;
@@ -116,6 +117,93 @@ int nq_ctx_prepare_server(ls_ctx *ctx, int n)
     if (hipSetDevice(ctx->device) != hipSuccess) return LS_OK;
     NqServer *s = nullptr;
     return nq_ctx_server(ctx, n, &s);
+}
+
+// ------------------------------------------------------------------------------------------- scheduling: resident routes
+static bool sched_resident_ok(const ls_ctx *ctx)
+{
+    return ctx->sched_server_on && ctx->sched_delta && ctx->sched.valid && ctx->sched.n_employees <= 32768;
+}
+
+static void sched_retire_counters(ls_ctx *ctx, const unsigned long long c3[3])
+{
+    for (int i = 0; i < 3; i++) ctx->sched_retired[i] += c3[i];
+}
+
+// this context's own resident launches leave and are released (their arguments -- the instance -- are about to change, or the
+// context goes away); an attached slot of a shared launch is only detached
+void sched_ctx_drop_servers(ls_ctx *ctx, bool detach_shared)
+{
+    (void)hipSetDevice(ctx->device);
+    if (ctx->sched_step && ctx->sched_step_owned) {
+        unsigned long long c3[3];
+        sched_step_counters(ctx->sched_step, c3);
+        sched_retire_counters(ctx, c3);
+        sched_step_destroy(ctx->sched_step);
+        ctx->sched_step = nullptr;
+    } else if (detach_shared) ctx->sched_step = nullptr;
+    if (ctx->sched_grid && ctx->sched_grid_owned) {
+        unsigned long long c3[3];
+        sched_grid_counters(ctx->sched_grid, c3);
+        sched_retire_counters(ctx, c3);
+        sched_grid_destroy(ctx->sched_grid);
+        ctx->sched_grid = nullptr;
+    } else if (detach_shared) ctx->sched_grid = nullptr;
+}
+
+// the step server a call of this context goes to: the attached slot of a shared launch, or its own one-slot server (on demand)
+static int sched_ctx_step(ls_ctx *ctx, SchedStepServer **out)
+{
+    if (!ctx->sched_step) {
+        SchedStepServer *s = nullptr;
+        const int rc = sched_step_create(ctx, 1, &s);
+        if (rc != LS_OK) return rc;
+        ctx->sched_step = s; ctx->sched_step_slot = 0; ctx->sched_step_owned = true;
+    }
+    *out = ctx->sched_step;
+    return LS_OK;
+}
+
+// the grid a call of this context goes to, or null (the launched pipeline serves it): the attached sub-grid of a shared launch
+// when it is of the right kind and size, or the context's own one-sub-grid launch, replaced when the kind or the list length changes
+static int sched_ctx_grid(ls_ctx *ctx, bool gen, long long n_list, SchedGrid **out)
+{
+    *out = nullptr;
+    if (ctx->sched_grid_unavailable || !sched_resident_ok(ctx)) return LS_OK;
+    if (ctx->sched_grid) {
+        SchedGrid *g = ctx->sched_grid;
+        const bool fits = sched_grid_is_gen(g) == gen && (gen || n_list <= sched_grid_capacity(g));
+        if (fits) { *out = g; return LS_OK; }
+        if (!ctx->sched_grid_owned) return LS_OK;
+        unsigned long long c3[3];
+        sched_grid_counters(g, c3);
+        sched_retire_counters(ctx, c3);
+        sched_grid_destroy(g);
+        ctx->sched_grid = nullptr;
+    }
+    if (!sched_grid_fits(ctx, 1, gen, n_list)) return LS_OK;
+    SchedGrid *g = nullptr;
+    const int rc = sched_grid_create(ctx, 1, gen, n_list, &g);
+    if (rc != LS_OK) return rc;
+    ctx->sched_grid = g; ctx->sched_grid_sub = 0; ctx->sched_grid_owned = true;
+    *out = g;
+    return LS_OK;
+}
+
+// the device copy of the resident list, for the launched pipelines (made when one first needs the current list)
+static int sched_resident_dev(ls_ctx *ctx)
+{
+    if (ctx->sc_resident_dev_gen == ctx->sc_resident_gen) return LS_OK;
+    LS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = ctx->sc_resident_host.size() * sizeof(ls_sched_move);
+    int rc = sync_and_collect(ctx); // the stream may still read the previous list
+    if (rc != LS_OK) return rc;
+    LS_RESERVE(ctx, ctx->sc_resident_moves, bytes ? bytes : 1);
+    if (bytes) LS_HIP(ctx, hipMemcpyAsync(ctx->sc_resident_moves.p, ctx->sc_resident_host.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = sync_and_collect(ctx);
+    if (rc != LS_OK) return rc;
+    ctx->sc_resident_dev_gen = ctx->sc_resident_gen;
+    return LS_OK;
 }
 
 } // namespace lsamd
@@ -174,16 +262,8 @@ int ls_ctx_create(int device_id, ls_ctx **out)
     }
     ctx->stream = ctx->own_stream;
     if (const char *v = getenv("LS_NQ_SCAN_VARIANT")) ctx->nq_scan_variant = atoi(v);
-    if (const char *v = getenv("LS_NQ_STEP")) ctx->nq_step_mode = atoi(v);
-    if (const char *v = getenv("LS_NQ_TABLE_VARIANT")) ctx->nq_table_variant = atoi(v);
-    if (const char *v = getenv("LS_YIELD")) ctx->yield_while_waiting = atoi(v) != 0;
-    if (const char *v = getenv("LS_SCHED_ZEROCOPY")) ctx->sched_zero_copy = atoi(v) != 0;
-    if (const char *v = getenv("LS_SCHED_FUSED")) ctx->sched_fused = atoi(v) != 0;
-    ctx->sched_force_64 = getenv("LS_SCHED_FORCE_64") != nullptr;
+    if (const char *v = getenv("LS_NQ_STEP")) ctx->nq_step_mode = atoi(v) >= 4 ? 4 : 3; // 4 (default): resident server; 3: one fused launch per call
     if (const char *v = getenv("LS_SCHED_DELTA")) ctx->sched_delta = atoi(v) != 0;
-    if (const char *v = getenv("LS_NQ_HOST_CS")) ctx->nq_host_cs = atoi(v) != 0;
-    if (const char *v = getenv("LS_NQ_RESIDENT_TABS")) ctx->nq_resident_tabs = atoi(v) != 0;
-    if (const char *v = getenv("LS_SCHED_ONE_LAUNCH")) ctx->sched_one_launch = atoi(v) != 0;
     if (const char *v = getenv("LS_SCHED_SERVER")) ctx->sched_server_on = atoi(v) != 0;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->wave_size = prop.warpSize;
@@ -206,7 +286,7 @@ int ls_ctx_destroy(ls_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->server && ctx->server_owned) nq_server_destroy(ctx->server); // the resident launches leave before anything is freed
     ctx->server = nullptr;
-    sched_server_destroy(ctx);
+    sched_ctx_drop_servers(ctx, true);
     (void)hipStreamSynchronize(ctx->stream);
     for_each_buf(ctx, [](DevBuf &b) { b.release(); });
     ctx->stage_in.release();
@@ -280,9 +360,11 @@ int ls_ctx_get_counters(const ls_ctx *ctx, uint64_t out[LS_N_COUNTERS])
         for (int i = 0; i < 4; i++) out[i] = c4[i];
     }
     {
+        // the resident scheduling launches of this context count into the same three
         unsigned long long c3[3];
-        sched_server_counters(ctx, c3); // the resident scheduling step counts into the same three
-        for (int i = 0; i < 3; i++) out[i] += c3[i];
+        for (int i = 0; i < 3; i++) out[i] += ctx->sched_retired[i];
+        if (ctx->sched_step && ctx->sched_step_owned) { sched_step_counters(ctx->sched_step, c3); for (int i = 0; i < 3; i++) out[i] += c3[i]; }
+        if (ctx->sched_grid && ctx->sched_grid_owned) { sched_grid_counters(ctx->sched_grid, c3); for (int i = 0; i < 3; i++) out[i] += c3[i]; }
     }
     out[4] = ctx->n_done_fallbacks;
     out[5] = ctx->n_resident_uploads;
@@ -499,7 +581,6 @@ static int wait_done_word(ls_ctx *ctx, const unsigned long long *flag, unsigned 
 #endif
         // A launch takes >= 10 us: after a short spin give the core to another runnable thread (ls_multi_solver runs
         // more slots than cores: one slot's host proposer then runs while the other slot's launch is in flight)
-        if (ctx->yield_while_waiting && spins >= 64) sched_yield();
         if ((spins & 0xfff) == 0xfff) {
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (dt > 0.002) { // far beyond any LS step: let the runtime tell whether the launch failed
@@ -547,7 +628,7 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
     }
     if (rs.n != n || (int)rs.valid.size() < R) { // geometry changed: nothing on the device can be reused
         // the step kernel's table layout (nq_step_dev picks the paired layout for even n >= 128): 6n + 4 or 5n + 1 u16
-        const bool pairs = (n & 1) == 0 && n >= 128 && ctx->nq_table_variant >= 10;
+        const bool pairs = (n & 1) == 0 && n >= 128;
         const int tab_words = pairs ? ((((6 * n + 4) >> 1) + 3) & ~3) : ((((5 * n + 1) >> 1) + 3) & ~3);
         rs.n = 0; // nothing is committed before both reservations have succeeded (a failure leaves "no resident geometry")
         rs.valid.clear();
@@ -572,7 +653,7 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
     }
     Staging &si = ctx->stage_in, &so = ctx->stage_out;
     // A board that is not the one left by the previous call is uploaded; its column scores then come from the kernel.
-    // Otherwise the host keeps them itself: cs(winner board) follows from cs(board) and the move in O(n) (ctx->nq_host_cs).
+    // Otherwise the host keeps them itself: cs(winner board) follows from cs(board) and the move in O(n).
     unsigned long long fresh = 0, want_cs = 0;
     for (int r = 0; r < R; r++) {
         const int32_t *src = rows + (size_t)r * n;
@@ -586,7 +667,7 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
             if (r < 64) fresh |= 1ull << r;
         }
         if (!cs_b) rs.cs_valid[(size_t)r] = 0; // nobody keeps the scores across this call
-        if (cs_b && r < 64 && !(rs.cs_valid[(size_t)r] && ctx->nq_host_cs)) want_cs |= 1ull << r;
+        if (cs_b && r < 64 && !rs.cs_valid[(size_t)r]) want_cs |= 1ull << r;
     }
     memcpy(si.h<char>(o_cur), cur_scores, cur_b);
     if (cols_b) memcpy(si.h<char>(o_cols), cols, cols_b);
@@ -594,7 +675,7 @@ static int nq_host_step_resident(ls_ctx *ctx, int32_t R, int32_t n, const int32_
     NqStepExtra x;
     x.fresh_mask = fresh;
     x.resident_rows = rs.dev_rows.as<int>();
-    x.resident_tabs = ctx->nq_resident_tabs ? rs.dev_tabs.as<unsigned>() : nullptr;
+    x.resident_tabs = rs.dev_tabs.as<unsigned>();
     x.tab_words = rs.tab_words;
     x.next_cs16 = cs_b ? so.h<unsigned short>(o_cs) : nullptr;
     x.want_cs_mask = want_cs;
@@ -725,7 +806,7 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
         if (e != hipSuccess) return set_err(ctx, LS_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
     }
     const long long win = nq_clamp_window(window, max_cols, n);
-    if (!sc_b && ctx->nq_step_mode >= 3 && n_restarts <= 64 && nq_step_eligible(ctx, n, max_cols, win)) // packs its own (smaller) blocks
+    if (!sc_b && n_restarts <= 64 && nq_step_eligible(ctx, n, max_cols, win)) // packs its own (smaller) blocks
         return nq_host_step_resident(ctx, n_restarts, n, rows, cur_scores, cols, n_cols, max_cols, win, results, next_col_scores);
     if (cs_b) LS_RESERVE(ctx, ctx->nq_next_rows, rows_b);
     if (sc_b) LS_RESERVE(ctx, ctx->nq_scores, sc_b);
@@ -734,23 +815,6 @@ static int nq_host_call(ls_ctx *ctx, int32_t n_restarts, int32_t n, const int32_
     memcpy(si.h<char>(o_rows), rows, rows_b);
     if (cols_b) memcpy(si.h<char>(o_cols), cols, cols_b);
     memcpy(si.h<char>(o_nc), n_cols, nc_b);
-    if (!sc_b && ctx->nq_step_mode > 0 && nq_step_eligible(ctx, n, max_cols, win)) {
-        // One LS step per restart in one launch.  Mode 2: the kernel reads the pinned staging block and writes
-        // the pinned result block directly (each byte crosses PCIe once, no copy dispatches in the chain).
-        const bool zc = ctx->nq_step_mode >= 2;
-        if (!zc) LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
-        char *ib = static_cast<char *>(zc ? si.host : si.dev), *ob = static_cast<char *>(zc ? so.host : so.dev);
-        rc = nq_step_dev(ctx, n_restarts, n, reinterpret_cast<int *>(ib + o_rows), reinterpret_cast<long long *>(ib + o_cur),
-                         reinterpret_cast<int *>(ib + o_cols), reinterpret_cast<int *>(ib + o_nc), max_cols, win,
-                         reinterpret_cast<ls_nq_result *>(ob + o_res), nullptr,
-                         cs_b ? reinterpret_cast<long long *>(ob + o_cs) : nullptr, nullptr, nullptr);
-        if (rc != LS_OK) return rc;
-        if (!zc) LS_HIP(ctx, hipMemcpyAsync(so.host, so.dev, out_b, hipMemcpyDeviceToHost, ctx->stream));
-        LS_SYNC(ctx);
-        memcpy(results, so.h<char>(o_res), res_b);
-        if (cs_b) memcpy(next_col_scores, so.h<char>(o_cs), cs_b);
-        return LS_OK;
-    }
     LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
     rc = nq_eval_batch_dev(ctx, n_restarts, n, si.d<int>(o_rows), si.d<long long>(o_cur), si.d<int>(o_cols), si.d<int>(o_nc),
                            max_cols, win, so.d<ls_nq_result>(o_res),
@@ -786,7 +850,7 @@ int ls_nqueens_eval_batch_next_dev(ls_ctx *ctx, int32_t n_restarts, int32_t n, c
     LS_REQUIRE(ctx, rows_d && cur_scores_d && n_cols_d && results_d && (cols_d || max_cols == 0) && next_rows_d &&
                         next_col_scores_d, "null device pointer");
     const long long win = nq_clamp_window(window, max_cols, n);
-    if (ctx->nq_step_mode > 0 && nq_step_eligible(ctx, n, max_cols, win))
+    if (nq_step_eligible(ctx, n, max_cols, win))
         return nq_step_dev(ctx, n_restarts, n, rows_d, reinterpret_cast<const long long *>(cur_scores_d), cols_d, n_cols_d,
                            max_cols, win, results_d, next_rows_d, reinterpret_cast<long long *>(next_col_scores_d),
                            reinterpret_cast<long long *>(next_scores_d), nullptr);
@@ -929,7 +993,7 @@ int ls_sched_instance_upload(ls_ctx *ctx, int32_t n_days_scored, int32_t n_days_
                    "employee %d has a holiday outside the scored range (the reference panics here: "
                    "examples/employee-scheduling/src/lib.rs:275)", e);
     // the stream (and the resident scheduling step, whose launch arguments are this instance) may still be reading the previous one
-    sched_server_pause(ctx);
+    sched_ctx_drop_servers(ctx, false);
     LS_SYNC(ctx);
     LS_RESERVE(ctx, ctx->sched.holiday_bits, (size_t)n_employees * 8);
     LS_HIP(ctx, hipMemcpyAsync(ctx->sched.holiday_bits.p, holiday_bits, (size_t)n_employees * 8,
@@ -962,7 +1026,18 @@ int ls_sched_score(ls_ctx *ctx, int32_t n_states, const int32_t *states, int64_t
     if (!ctx) return LS_ERR_INVALID;
     if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
     LS_REQUIRE(ctx, n_states >= 1 && states && hard && soft, "bad arguments");
-    if (n_states == 1 && !terms && sched_server_can_score(ctx)) return sched_server_score(ctx, states, hard, soft); // no launch
+    if (n_states == 1 && !terms && sched_resident_ok(ctx)) { // no launch: the slot's workgroup, or the master of the attached sub-grid
+        if (ctx->sched_grid && !ctx->sched_step && !ctx->sched_grid_unavailable) {
+            const int rc_g = sched_grid_score(ctx, ctx->sched_grid, ctx->sched_grid_sub, states, hard, soft);
+            if (rc_g != SRV_RC_GIVE_UP) return rc_g;
+            ctx->sched_grid_unavailable = true;
+        } else {
+            SchedStepServer *sv = nullptr;
+            const int rc_s = sched_ctx_step(ctx, &sv);
+            if (rc_s == LS_OK) return sched_step_score(ctx, sv, ctx->sched_step_slot, states, hard, soft);
+            if (rc_s != LS_ERR_UNSUPPORTED) return rc_s;
+        }
+    }
     LS_BIND(ctx);
     const int S = ctx->sched.n_days_stored;
     int rc = sched_check_state(ctx, states, (long long)n_states * S);
@@ -1043,7 +1118,7 @@ int ls_sched_eval_batch(ls_ctx *ctx, int32_t n_restarts, const int32_t *states, 
         memcpy(si.h<char>(o_nm), n_moves, nm_b);
         memcpy(si.h<char>(o_st), states, st_b);
         if (mv_b) memcpy(si.h<char>(o_mv), moves, mv_b);
-        const bool zc = ctx->sched_zero_copy && ctx->sched_fused && max_moves <= 512;
+        const bool zc = max_moves <= 512;
         if (!zc) LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
         char *ib = static_cast<char *>(zc ? si.host : si.dev), *ob = static_cast<char *>(zc ? so.host : so.dev);
         rc = sched_eval_batch_dev(ctx, n_restarts, reinterpret_cast<int *>(ib + o_st), reinterpret_cast<ls_sched_move *>(ib + o_mv),
@@ -1098,20 +1173,16 @@ static int sched_check_moves(ls_ctx *ctx, const ls_sched_move *moves, long long 
 
 int ls_sched_moves_upload(ls_ctx *ctx, const ls_sched_move *moves, int64_t n_moves)
 {
-    LS_BIND(ctx);
+    if (!ctx) return LS_ERR_INVALID;
     if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
     LS_REQUIRE(ctx, n_moves >= 0 && (moves || n_moves == 0), "bad arguments");
     int rc = sched_check_moves(ctx, moves, n_moves, 0);
     if (rc != LS_OK) return rc;
-    sched_server_pause(ctx); // the resident scheduling step holds the previous list: it leaves and is started again with the new one
-    LS_SYNC(ctx); // the stream may still read the previous list
-    LS_RESERVE(ctx, ctx->sc_resident_moves, (size_t)n_moves * sizeof(ls_sched_move));
-    if (n_moves)
-        LS_HIP(ctx, hipMemcpyAsync(ctx->sc_resident_moves.p, moves, (size_t)n_moves * sizeof(ls_sched_move),
-                                   hipMemcpyHostToDevice, ctx->stream));
-    LS_SYNC(ctx);
-    ctx->sc_resident_n = n_moves;
+    // The list stays on the host: a resident workgroup reads its moves from the slot's pinned block once per list, a launched
+    // pipeline gets a device copy when it first needs one (sched_resident_dev).  No runtime call, no launch paused.
     ctx->sc_resident_host.assign(moves, moves + n_moves);
+    ctx->sc_resident_n = n_moves;
+    ctx->sc_resident_gen++;
     return LS_OK;
 }
 
@@ -1123,41 +1194,47 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
     LS_REQUIRE(ctx, n_moves >= 0 && n_moves <= ctx->sc_resident_n, "n_moves = %lld exceeds the resident list (%lld)",
                (long long)n_moves, ctx->sc_resident_n);
     const int S = ctx->sched.n_days_stored;
-    // no launch and, in the steady state, no runtime call: the resident workgroup (<= 512 moves) or the resident grid
-    if (sched_server_eligible(ctx, n_moves)) return sched_server_eval(ctx, state, n_moves, window, out);
-    if (sched_grid_eligible(ctx, n_moves)) {
-        const int rc_g = sched_grid_eval(ctx, state, n_moves, window, out);
-        if (rc_g != SRV_RC_GIVE_UP) return rc_g; // else: the grid cannot be resident now -- the launched pipeline below
+    // no launch and, in the steady state, no runtime call: the slot's resident workgroup (<= 512 moves) or its resident sub-grid
+    if (sched_resident_ok(ctx) && ctx->sc_resident_n > 0) {
+        if (n_moves <= 512) {
+            SchedStepServer *sv = nullptr;
+            const int rc_s = sched_ctx_step(ctx, &sv);
+            if (rc_s == LS_OK) return sched_step_eval(ctx, sv, ctx->sched_step_slot, state, n_moves, window, out);
+            if (rc_s != LS_ERR_UNSUPPORTED) return rc_s;
+        } else {
+            SchedGrid *g = nullptr;
+            const int rc0 = sched_ctx_grid(ctx, false, ctx->sc_resident_n, &g);
+            if (rc0 != LS_OK) return rc0;
+            if (g) {
+                const int rc_g = sched_grid_eval(ctx, g, ctx->sched_grid_sub, state, n_moves, window, out);
+                if (rc_g != SRV_RC_GIVE_UP) return rc_g;
+                ctx->sched_grid_unavailable = true; // the grid cannot be resident now (another launch holds the CUs): the launched pipeline, from now on
+            }
+        }
     }
     LS_BIND(ctx);
     int rc = sched_check_state(ctx, state, S);
     if (rc != LS_OK) return rc;
-    const size_t o_nm = 0, o_st = 256, in_b = align256(o_st + (size_t)S * 4), out_b = 256;
+    rc = sched_resident_dev(ctx);
+    if (rc != LS_OK) return rc;
     {
-        hipError_t e = ctx->stage_in.reserve(in_b);
-        if (e == hipSuccess) e = ctx->stage_out.reserve(out_b);
+        hipError_t e = ctx->stage_out.reserve(256);
         if (e != hipSuccess) return set_err(ctx, LS_ERR_NOMEM, "staging allocation failed: %s", hipGetErrorString(e));
     }
-    Staging &si = ctx->stage_in, &so = ctx->stage_out;
-    *si.h<long long>(o_nm) = n_moves;
-    memcpy(si.h<char>(o_st), state, (size_t)S * 4);
-    // The per-iteration inputs are 136 bytes and the output 32.  LS_SCHED_ZEROCOPY (default on): the state and n_moves
-    // travel in the kernel arguments -- no copy and no PCIe read by the kernels; off: one staging copy.
-    const bool zc = ctx->sched_zero_copy;
-    if (!zc) LS_HIP(ctx, hipMemcpyAsync(si.dev, si.host, in_b, hipMemcpyHostToDevice, ctx->stream));
-    // The result record always goes straight to pinned host memory and its writer publishes a completion word, which
-    // the caller polls instead of synchronising the stream.
+    // The per-iteration inputs are 136 bytes and the output 32: the state and n_moves travel in the kernel arguments (no copy,
+    // no PCIe read by the kernels), the result record goes straight to pinned host memory and its writer publishes a
+    // completion word, which the caller polls instead of synchronising the stream.
     NqResident &rs = ctx->nq_res; // the context's completion word is shared with the N-queens LS step (one call at a time per context)
     {
         const int rc0 = ensure_done_word(ctx);
         if (rc0 != LS_OK) return rc0;
     }
-    rc = sched_eval_batch_dev(ctx, 1, si.d<int>(o_st), ctx->sc_resident_moves.as<ls_sched_move>(), si.d<long long>(o_nm), n_moves, window,
-                              so.h<ls_sched_result>(0), nullptr, nullptr, rs.flag, ++rs.seq, zc ? state : nullptr, n_moves);
+    rc = sched_eval_batch_dev(ctx, 1, nullptr, ctx->sc_resident_moves.as<ls_sched_move>(), nullptr, n_moves, window,
+                              ctx->stage_out.h<ls_sched_result>(0), nullptr, nullptr, rs.flag, ++rs.seq, state, n_moves);
     if (rc != LS_OK) return rc;
     rc = wait_done_word(ctx, rs.flag, rs.seq);
     if (rc != LS_OK) return rc;
-    *out = *so.h<ls_sched_result>(0);
+    *out = *ctx->stage_out.h<ls_sched_result>(0);
     return LS_OK;
 }
 
@@ -1198,14 +1275,20 @@ int ls_sched_eval_exhaustive(ls_ctx *ctx, int32_t n_restarts, const int32_t *sta
     if (rc != LS_OK) return rc;
     const long long per = (long long)S * ctx->sched.n_employees;
     // one state: the resident grid generates and scores the S x E candidates without a launch (sched_grid_server_kernel<GEN>)
-    if (n_restarts == 1 && sched_xgrid_eligible(ctx)) {
-        const int rc_g = sched_grid_eval(ctx, states, per, window, results, true);
-        if (rc_g != SRV_RC_GIVE_UP) return rc_g; // else: the grid cannot be resident now -- the launched pipeline below
+    if (n_restarts == 1 && sched_resident_ok(ctx)) {
+        SchedGrid *g = nullptr;
+        const int rc0 = sched_ctx_grid(ctx, true, per, &g);
+        if (rc0 != LS_OK) return rc0;
+        if (g) {
+            const int rc_g = sched_grid_eval(ctx, g, ctx->sched_grid_sub, states, per, window, results);
+            if (rc_g != SRV_RC_GIVE_UP) return rc_g;
+            ctx->sched_grid_unavailable = true; // the grid cannot be resident now -- the launched pipeline below, from now on
+        }
     }
     const size_t st_b = (size_t)n_restarts * S * 4, mv_b = (size_t)n_restarts * per * sizeof(ls_sched_move),
                  nm_b = (size_t)n_restarts * 8, res_b = (size_t)n_restarts * sizeof(ls_sched_result);
     bool handled = false;
-    if (n_restarts == 1 && ctx->sched_delta && ctx->sched_zero_copy) {
+    if (n_restarts == 1 && ctx->sched_delta) {
         // one restart (config 5's per-GPU shape): the state travels in the kernel arguments, the result record goes
         // straight to pinned host memory and its writer publishes the completion word the caller polls
         hipError_t e = ctx->stage_out.reserve(256);

@@ -135,7 +135,8 @@ struct NqResident {
 
 // The resident LS-step server (nq_server.hip): one never-ending launch per device whose workgroups are the slots.
 struct NqServer;
-struct SchedServer; // sched_kernels.hip: the resident scheduling LS step (one workgroup per context)
+struct SchedStepServer; // sched_server.hip: the resident scheduling LS step, one workgroup per slot
+struct SchedGrid;       // sched_grid.hip: the resident scheduling grid, one sub-grid per restart
 constexpr int SRV_RC_GIVE_UP = 1; // internal (never crosses the ABI): a resident launch could not serve the request, the caller takes the launched route
 
 struct SchedInstance {
@@ -152,9 +153,8 @@ struct ls_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int nq_algo = LS_NQ_ALGO_AUTO;
-    int nq_step_mode = 4; // fused LS-step kernel (LS_NQ_STEP): 0 off, 1 through device staging copies, 2 zero-copy on pinned host memory +
-                          // stream sync, 3 = 2 + boards resident on the device, 16-bit column scores on the wire, polled completion word,
-                          // 4 (default) = one-restart host calls go to the resident LS-step server (nq_server.hip): no launch per call
+    int nq_step_mode = 4; // LS_NQ_STEP: 4 (default) = host calls of up to 64 restarts go to the resident LS-step server (nq_server.hip): no launch per
+                          // call; 3 = one fused LS-step launch per call (boards resident on the device, polled completion word): the launched fallback
     lsamd::NqServer *server = nullptr; // the server this context's one-restart LS steps go to (own: started on demand; or a slot of a shared one)
     int server_slot = 0;
     bool server_owned = false;
@@ -176,18 +176,7 @@ struct ls_ctx {
     int n_wait_words = 0;
     unsigned wait_tag = 0;
     unsigned long long steps_done = 0; // one-restart LS steps of this context (ls_multi_solver: the running restart's scheduling priority)
-    bool yield_while_waiting = false; // completion-word poll: sched_yield() after a short spin (set by ls_multi_solver when slots > cores; LS_YIELD)
-    bool sched_zero_copy = true; // ls_sched_eval_resident: kernels work on the pinned staging blocks directly (LS_SCHED_ZEROCOPY)
-    bool sched_fused = true;     // small scheduling launches: locate + eval + reduce in one kernel (LS_SCHED_FUSED)
-    bool nq_resident_tabs = true; // LS_NQ_RESIDENT_TABS: the resident LS step keeps the count tables on the device and patches them (0: rebuilt every call)
-    bool nq_host_cs = true;      // LS_NQ_HOST_CS: the resident LS step keeps the column scores on the host (0: the kernel writes them every call)
     bool sched_delta = true;     // LS_SCHED_DELTA: lane-per-candidate delta scorer (0: the wavefront-per-candidate kernels)
-    bool sched_one_launch = false; // LS_SCHED_ONE_LAUNCH=1: the last block of the delta pipeline's scoring launch does the finish step itself
-                                   // (measured slower than the second launch: every block pays a barrier + agent-scope release)
-    bool sched_force_64 = false; // LS_SCHED_FORCE_64: use the full-wavefront scheduling kernel even for <= 32 days
-    int nq_table_variant = 24; // TABLE family (LS_NQ_TABLE_VARIANT): 0 per-range kernel; 1/2/4 column teams of 256 lanes per block;
-                               // 11/12/14 the same with two candidates per lane and LDS look-up (even n >= 512); 21/22/24 (default)
-                               // two candidates per lane and look-up, one wavefront per column
     int nq_scan_variant = 0; // register-scan formulation: 0 auto (fp32), 1 packed u16 (LS_NQ_SCAN_VARIANT)
     int n_cus = 0;
     int wave_size = 0;
@@ -198,11 +187,24 @@ struct ls_ctx {
     // persistent workspaces (grow-only)
     lsamd::DevBuf nq_rows, nq_cur, nq_cols, nq_ncols, nq_results, nq_scores, nq_keys, nq_tabs,
         nq_colscores, nq_totals, nq_next_rows;
-    lsamd::DevBuf sc_states, sc_moves, sc_nmoves, sc_results, sc_hard, sc_soft, sc_keys, sc_terms, sc_cand_keys, sc_ticket;
+    lsamd::DevBuf sc_states, sc_moves, sc_nmoves, sc_results, sc_hard, sc_soft, sc_keys, sc_terms, sc_cand_keys;
     lsamd::SchedInstance sched;
-    lsamd::DevBuf sc_resident_moves; // ls_sched_moves_upload
-    std::vector<ls_sched_move> sc_resident_host; // host copy of the resident list (the server route applies winners to its shadow state)
-    lsamd::SchedServer *sched_server = nullptr;  // resident scheduling LS step (started on demand by ls_sched_eval_resident)
+    // ls_sched_moves_upload: the resident list lives on the host (the resident servers read it from pinned memory, once, and the
+    // winner is applied to the shadow state from it); the device copy is made when a launched pipeline first needs it
+    std::vector<ls_sched_move> sc_resident_host;
+    unsigned long long sc_resident_gen = 0;      // bumped by every upload: what a server slot holds is compared with it
+    lsamd::DevBuf sc_resident_moves;
+    unsigned long long sc_resident_dev_gen = 0;  // generation of the device copy
+    // the resident routes of this context's scheduling calls: a server of its own (started on demand), or one slot / sub-grid
+    // of a launch shared with other contexts (ls_multi_solver_create_sched)
+    lsamd::SchedStepServer *sched_step = nullptr;
+    int sched_step_slot = 0;
+    bool sched_step_owned = false;
+    lsamd::SchedGrid *sched_grid = nullptr;
+    int sched_grid_sub = 0;
+    bool sched_grid_owned = false;
+    bool sched_grid_unavailable = false;         // its workgroups could not all be resident (another launch holds the CUs): not tried again
+    unsigned long long sched_retired[3] = {0, 0, 0}; // counters of this context's earlier servers
     bool sched_server_on = true;                 // LS_SCHED_SERVER=0: one launch per call
     lsamd::Staging stage_in, stage_out;
     lsamd::NqResident nq_res;
@@ -215,6 +217,7 @@ int set_err(const ls_ctx *ctx, int code, const char *fmt, ...);
 
 // nq_server.hip
 bool nq_server_supports(const ls_ctx *ctx, int n);
+int nq_server_max_slots(ls_ctx *ctx, int n); // resident workgroups of the server the device holds at once (less headroom)
 int nq_server_create(ls_ctx *ctx, int n, int n_slots, NqServer **out);
 void nq_server_destroy(NqServer *s);
 int nq_server_n(const NqServer *s);
@@ -223,17 +226,26 @@ void nq_server_counters(const NqServer *s, unsigned long long out[4]); // reques
 int nq_server_step(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int64_t cur_score, const int32_t *cols, int32_t n_cols,
                    long long window, ls_nq_result *res, int64_t *next_col_scores);
 int nq_server_col_scores(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, int64_t *col_scores, int64_t *total);
-// sched_kernels.hip
-bool sched_server_eligible(const ls_ctx *ctx, long long n_moves);
-void sched_server_pause(ls_ctx *ctx);
-void sched_server_destroy(ls_ctx *ctx);
-void sched_server_counters(const ls_ctx *ctx, unsigned long long out[3]); // requests, launches, waits that found the launch drained
-bool sched_server_can_score(const ls_ctx *ctx);
-int sched_server_score(ls_ctx *ctx, const int32_t *state, int64_t *hard, int64_t *soft);
-bool sched_grid_eligible(const ls_ctx *ctx, long long n_moves);
-int sched_grid_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out, bool gen = false);
-bool sched_xgrid_eligible(const ls_ctx *ctx);
-int sched_server_eval(ls_ctx *ctx, const int32_t *state, long long n_moves, long long window, ls_sched_result *out);
+// sched_server.hip: the resident scheduling LS step
+int sched_step_max_slots(ls_ctx *ctx);
+int sched_step_create(ls_ctx *ctx, int n_slots, SchedStepServer **out);
+void sched_step_destroy(SchedStepServer *s);
+int sched_step_slots(const SchedStepServer *s);
+void sched_step_pause(SchedStepServer *s);
+void sched_step_counters(const SchedStepServer *s, unsigned long long out[3]); // requests, launches, waits that found the launch drained
+int sched_step_score(ls_ctx *ctx, SchedStepServer *s, int slot, const int32_t *state, int64_t *hard, int64_t *soft);
+int sched_step_eval(ls_ctx *ctx, SchedStepServer *s, int slot, const int32_t *state, long long n_moves, long long window, ls_sched_result *out);
+// sched_grid.hip: the resident scheduling grid
+bool sched_grid_fits(const ls_ctx *ctx, int n_sub, bool gen, long long n_moves);
+int sched_grid_create(ls_ctx *ctx, int n_sub, bool gen, long long capacity, SchedGrid **out);
+void sched_grid_destroy(SchedGrid *s);
+int sched_grid_subs(const SchedGrid *s);
+bool sched_grid_is_gen(const SchedGrid *s);
+long long sched_grid_capacity(const SchedGrid *s);
+void sched_grid_pause(SchedGrid *s);
+void sched_grid_counters(const SchedGrid *s, unsigned long long out[3]);
+int sched_grid_score(ls_ctx *ctx, SchedGrid *s, int sub, const int32_t *state, int64_t *hard, int64_t *soft);
+int sched_grid_eval(ls_ctx *ctx, SchedGrid *s, int sub, const int32_t *state, long long n_moves, long long window, ls_sched_result *out);
 // ls_api.hip
 int nq_ctx_server(ls_ctx *ctx, int n, NqServer **out, int slots = 1);
 int nq_server_post(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, const int32_t *cols, int32_t n_cols, long long window,

@@ -33,8 +33,13 @@ struct ls_solver {
 
 struct ls_multi_solver {
     ls_ctx *ctx = nullptr;
+    int kind = 0; // 0 N-queens, 1 scheduling
     ls_solver_params params{};
     size_t board_size = 0;
+    // scheduling: the instance every restart works on (examples/employee-scheduling/src/lib.rs:57-117)
+    int32_t sc_days_scored = 0, sc_start_weekday = 0, sc_employees = 0;
+    std::vector<uint64_t> sc_holidays;
+    std::vector<ScoredSolution<SchedProblem>> sc_best;
     std::vector<std::string> seeds;
     std::vector<ScoredSolution<NQueensProblem>> best;
     std::vector<int> have;
@@ -296,6 +301,36 @@ int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_r
     });
 }
 
+int ls_multi_solver_create_sched(ls_ctx *ctx, int32_t n_days_scored, int32_t start_weekday, int32_t n_employees,
+                                 const uint64_t *holiday_bits, int32_t n_restarts, const char *const *seeds,
+                                 const ls_solver_params *params, ls_multi_solver **out)
+{
+    if (!ctx || !out || !seeds || n_restarts < 1) return LS_ERR_INVALID;
+    *out = nullptr;
+    int rc = check_params(ctx, params);
+    if (rc != LS_OK) return rc;
+    rc = ls_sched_instance_upload(ctx, n_days_scored, n_days_scored + 1, start_weekday, n_employees, holiday_bits); // validates; the run's shared launches carry it
+    if (rc != LS_OK) return rc;
+    return guarded(ctx, [&]() {
+        std::unique_ptr<ls_multi_solver> m(new ls_multi_solver());
+        m->ctx = ctx;
+        m->kind = 1;
+        m->params = *params;
+        m->sc_days_scored = n_days_scored; m->sc_start_weekday = start_weekday; m->sc_employees = n_employees;
+        m->sc_holidays.assign(holiday_bits, holiday_bits + n_employees);
+        for (int32_t r = 0; r < n_restarts; r++) {
+            if (!seeds[r]) throw std::runtime_error("seed is NULL");
+            m->seeds.emplace_back(seeds[r]);
+        }
+        m->sc_best.resize((size_t)n_restarts);
+        m->have.assign((size_t)n_restarts, 0);
+        const unsigned hw = usable_cores();
+        m->n_slots = (int)(4 * hw > 256 ? 256 : (4 * hw < 1 ? 1 : 4 * hw));
+        *out = m.release();
+        return LS_OK;
+    });
+}
+
 int ls_multi_solver_configure(ls_multi_solver *m, int32_t n_slots, int32_t mode)
 {
     if (!m) return LS_ERR_INVALID;
@@ -311,9 +346,12 @@ int ls_multi_solver_configure(ls_multi_solver *m, int32_t n_slots, int32_t mode)
     return LS_OK;
 }
 
+static int multi_run_sched(ls_multi_solver *m, uint64_t max_rounds_per_restart, double max_seconds);
+
 int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, double max_seconds)
 {
     if (!m) return LS_ERR_INVALID;
+    if (m->kind == 1) return guarded(m->ctx, [&]() { return multi_run_sched(m, max_rounds_per_restart, max_seconds); });
     return guarded(m->ctx, [&]() {
         const int R = (int)m->seeds.size();
         const int T = m->n_slots < R ? m->n_slots : R; // slots = host threads; a finished restart's slot takes the next seed
@@ -333,7 +371,8 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
             }
         } shared;
         shared.owned.assign((size_t)T, nullptr);
-        if (!lockstep && m->ctx->nq_step_mode >= 4 && lsamd::nq_server_supports(m->ctx, (int)m->board_size) && T <= 240)
+        if (!lockstep && m->ctx->nq_step_mode >= 4 && lsamd::nq_server_supports(m->ctx, (int)m->board_size) &&
+            T <= lsamd::nq_server_max_slots(m->ctx, (int)m->board_size)) // (more slots than the device holds resident: a launch per call)
             check_rc(m->ctx, lsamd::nq_server_create(m->ctx, (int)m->board_size, T, &shared.s), "LS-step server");
         std::vector<uint64_t> fallbacks((size_t)T, 0), reuploads((size_t)T, 0);
         NqBatcher batcher(m->ctx, (int32_t)m->board_size, T);
@@ -454,6 +493,10 @@ int ls_multi_solver_get_best(const ls_multi_solver *m, int32_t restart, int64_t 
     if (!m || !score || restart < 0 || (size_t)restart >= m->seeds.size()) return LS_ERR_INVALID;
     if (have) *have = m->have[(size_t)restart];
     if (!m->have[(size_t)restart]) { if (len) *len = 0; return LS_OK; }
+    if (m->kind == 1) {
+        score[0] = m->sc_best[(size_t)restart].score.first; score[1] = m->sc_best[(size_t)restart].score.second;
+        return copy_solution(m->sc_best[(size_t)restart].solution, solution, cap, len);
+    }
     score[0] = m->best[(size_t)restart].score; score[1] = 0;
     return copy_solution(m->best[(size_t)restart].solution, solution, cap, len);
 }
@@ -562,3 +605,131 @@ int ls_host_rng_script(const uint8_t seed32[32], const int64_t *ops, int64_t n_o
 }
 
 } // extern "C"
+
+// Many scheduling restarts on one GPU: restart = the unchanged driver of examples/employee-scheduling/src/lib.rs:57-117
+// on a host thread or fibre, seeds by the convention of examples/nqueens/src/main.rs:167; the slots' GPU requests go to ONE resident
+// launch shared by all of them -- slot t is workgroup t of the LS-step server (sched_server.hip: lists of at most 512 moves, the
+// reference example's window 100), or sub-grid t of the grid (sched_grid.hip: longer lists, config 5's window 65 536) -- so no
+// slot ever waits for another and nothing is launched per LS iteration.  When neither fits (too many slots for the device, a
+// window between the two) every slot's context takes its own routes.
+static int multi_run_sched(ls_multi_solver *m, uint64_t max_rounds_per_restart, double max_seconds)
+{
+    const int R = (int)m->seeds.size();
+    int T = m->n_slots < R ? m->n_slots : R;
+    const ls_solver_params &p = m->params;
+    ls_ctx *base = m->ctx;
+    struct Shared {
+        lsamd::SchedStepServer *step = nullptr;
+        lsamd::SchedGrid *grid = nullptr;
+        std::vector<ls_ctx *> owned; // per-slot contexts: destroyed after the shared launches have left (hipHostFree waits for resident kernels)
+        ~Shared()
+        {
+            if (step) lsamd::sched_step_destroy(step);
+            if (grid) lsamd::sched_grid_destroy(grid);
+            for (ls_ctx *c : owned) if (c) (void)ls_ctx_destroy(c);
+        }
+    } shared;
+    const long long want = (long long)p.window_size + (long long)p.window_size / 4 + 16; // the list prefix an LS iteration asks for (SchedProblem::best_of_neighbourhood)
+    const bool resident = base->sched_server_on && base->sched_delta && m->sc_employees <= 32768 && p.all_solution_iteration_expiry >= 1;
+    if (resident && want <= 512) {
+        const int cap = lsamd::sched_step_max_slots(base);
+        if (T > cap) T = cap;
+        check_rc(base, lsamd::sched_step_create(base, T, &shared.step), "scheduling LS-step server");
+    } else if (resident) {
+        while (T > 1 && !lsamd::sched_grid_fits(base, T, false, want)) T--; // as many sub-grids as the device holds side by side
+        if (lsamd::sched_grid_fits(base, T, false, want)) check_rc(base, lsamd::sched_grid_create(base, T, false, want, &shared.grid), "scheduling grid");
+    }
+    shared.owned.assign((size_t)T, nullptr);
+    std::vector<std::string> errors((size_t)T);
+    std::vector<uint64_t> ls_it((size_t)R, 0), scored((size_t)R, 0), rounds((size_t)R, 0), launches((size_t)T, 0);
+    std::atomic<int> next_restart{0};
+    std::atomic<bool> stop{false};
+    const auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&](int t, bool as_fibre) {
+        try {
+            ls_ctx *ctx = base;
+            if (t > 0) { // one context per slot (the drivers are independent); slot 0 uses the caller's
+                ls_ctx *own = nullptr;
+                check_rc(nullptr, ls_ctx_create(base->device, &own), "ls_ctx_create");
+                shared.owned[(size_t)t] = own;
+                own->sched_delta = base->sched_delta; own->sched_server_on = base->sched_server_on;
+                check_rc(own, ls_sched_instance_upload(own, m->sc_days_scored, m->sc_days_scored + 1, m->sc_start_weekday, m->sc_employees,
+                                                       m->sc_holidays.data()), "ls_sched_instance_upload");
+                ctx = own;
+            }
+            struct Attach { // this slot's workgroup / sub-grid of the shared launch (slot 0: the caller's context lends itself for the run)
+                ls_ctx *c; lsamd::SchedStepServer *s0; int slot0; bool owned0; lsamd::SchedGrid *g0; int sub0; bool gowned0; bool un0;
+                ~Attach() { c->sched_step = s0; c->sched_step_slot = slot0; c->sched_step_owned = owned0; c->sched_grid = g0; c->sched_grid_sub = sub0; c->sched_grid_owned = gowned0; c->sched_grid_unavailable = un0; }
+            } attach{ctx, ctx->sched_step, ctx->sched_step_slot, ctx->sched_step_owned, ctx->sched_grid, ctx->sched_grid_sub, ctx->sched_grid_owned, ctx->sched_grid_unavailable};
+            if (shared.step) { ctx->sched_step = shared.step; ctx->sched_step_slot = t; ctx->sched_step_owned = false; }
+            if (shared.grid) { ctx->sched_step = nullptr; ctx->sched_step_owned = false; ctx->sched_grid = shared.grid; ctx->sched_grid_sub = t; ctx->sched_grid_owned = false; ctx->sched_grid_unavailable = false; }
+            struct Restore {
+                ls_ctx *c; void (*h)(void *); void *a;
+                ~Restore() { c->wait_hook = h; c->wait_hook_arg = a; }
+            } restore{ctx, ctx->wait_hook, ctx->wait_hook_arg};
+            if (as_fibre) { ctx->wait_hook = &fibre_wait_hook; ctx->wait_hook_arg = ctx; }
+            for (;;) {
+                const int r = next_restart.fetch_add(1);
+                if (r >= R || stop.load()) break;
+                ctx->steps_done = 0; // the new restart's scheduling priority starts over
+                SchedProblem problem(ctx, m->sc_days_scored, m->sc_days_scored + 1, m->sc_employees);
+                const ChaCha20Rng solver_rng = ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]); // lib.rs:58-62
+                const ChaCha20Rng ils_rng = ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]);    // lib.rs:94
+                LocalSearch<SchedProblem> ls(&problem, p.local_search_max_iterations, (size_t)p.window_size, (size_t)p.best_solutions_capacity,
+                                             (size_t)p.all_solutions_capacity, p.all_solution_iteration_expiry, solver_rng);
+                History<SchedProblem> history((size_t)p.best_solutions_capacity, (size_t)p.all_solutions_capacity, p.all_solution_iteration_expiry);
+                IteratedLocalSearch<SchedProblem> ils(&problem, std::move(ls), std::move(history), p.iterated_local_search_max_iterations,
+                                                      p.max_allow_no_improvement_for, ils_rng);
+                while (!ils.is_finished() && rounds[(size_t)r] < max_rounds_per_restart) {
+                    ils.execute_round();
+                    rounds[(size_t)r]++;
+                    ScoredSolution<SchedProblem> b;
+                    if (ils.get_best_solution(b) && SchedProblem::is_best(b.score)) break; // later rounds are no-ops
+                    if (max_seconds > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > max_seconds) {
+                        stop.store(true); // no further seeds are started
+                        break;
+                    }
+                }
+                ScoredSolution<SchedProblem> b;
+                if (ils.get_best_solution(b)) { m->sc_best[(size_t)r] = b; m->have[(size_t)r] = 1; }
+                ls_it[(size_t)r] = ils.ls_iterations();
+                scored[(size_t)r] = problem.neighbours_scored;
+                launches[(size_t)t] += problem.gpu_evals;
+            }
+        } catch (const std::exception &e) {
+            errors[(size_t)t] = e.what();
+        } catch (...) { // nothing may escape a std::thread (std::terminate)
+            errors[(size_t)t] = "unknown exception in a restart";
+        }
+    };
+    const int hwc = (int)usable_cores();
+    const int n_threads = (hwc >= 1 && T > hwc) ? hwc : T;
+    m->fibre_steals = 0;
+    if (n_threads == T) {
+        std::vector<std::thread> threads;
+        for (int th = 0; th < n_threads; th++) threads.emplace_back([&, th]() { worker(th, false); });
+        for (auto &t : threads) t.join();
+    } else {
+        FiberPool pool(n_threads);
+        for (int t = 0; t < T; t++) pool.add([&, t]() { worker(t, true); }, t);
+        pool.run();
+        m->fibre_steals = pool.steals();
+    }
+    for (const std::string &e : errors)
+        if (!e.empty()) throw std::runtime_error(e);
+    m->restart_ls_iterations = ls_it; m->restart_scored = scored; m->restart_rounds = rounds;
+    m->ls_iterations = m->neighbours_scored = m->rounds = m->gpu_launches = 0;
+    for (int r = 0; r < R; r++) {
+        m->ls_iterations += ls_it[(size_t)r];
+        m->neighbours_scored += scored[(size_t)r];
+        m->rounds += rounds[(size_t)r];
+    }
+    for (int t = 0; t < T; t++) m->gpu_launches += launches[(size_t)t];
+    for (uint64_t &c : m->counters) c = 0;
+    unsigned long long c3[3] = {0, 0, 0};
+    if (shared.step) lsamd::sched_step_counters(shared.step, c3);
+    if (shared.grid) lsamd::sched_grid_counters(shared.grid, c3);
+    for (int i = 0; i < 3; i++) m->counters[i] = c3[i];
+    m->counters[6] = m->fibre_steals;
+    return LS_OK;
+}

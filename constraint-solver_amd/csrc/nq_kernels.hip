@@ -1639,7 +1639,6 @@ static int launch_table_teams_t(ls_ctx *ctx, const NqArgs &a, long long window)
     const long long by_waves = 32 / (NT / 64);
     per_cu = per_cu > by_waves ? by_waves : per_cu;
     per_cu = per_cu < 1 ? 1 : per_cu;
-    if (ctx->nq_table_variant >= 30) per_cu = 1; // measurement knob: one block per CU (fewer, longer-lived workgroups)
     long long bpr = ((long long)ctx->n_cus * per_cu) / a.n_restarts;
     if (bpr < 1) bpr = 1;
     // work units: whole slots x parts; a unit should keep a team busy for >= 4 steps (of TL values, or TL pairs)
@@ -1666,33 +1665,12 @@ static int launch_table_teams_t(ls_ctx *ctx, const NqArgs &a, long long window)
     return LS_OK;
 }
 
-// LS_NQ_TABLE_VARIANT (measurement knob): 0 = per-range kernel; 1, 2, 4 = column teams of 256 lanes, one candidate per lane and
-// look-up; 11, 12, 14 = the same with two candidates per lane and look-up (even n >= 512); 21, 22, 24 = two candidates per
-// lane and look-up, a team is ONE wavefront (1, 2, 4 x 256 threads per block).
+// even 512 <= n: two candidates per lane and look-up, one wavefront per column (nq_table_pairs_kernel); else one candidate per
+// lane, 256-lane teams (nq_table_teams_kernel)
 static int launch_table_teams(ls_ctx *ctx, const NqArgs &a, long long window)
 {
-    const int v = ctx->nq_table_variant;
-    const bool pairs = v >= 10 && (a.n & 1) == 0 && a.n >= 512;
-    const int q = v % 10;
-    if (pairs && v >= 20) {
-        switch (q) {
-        case 1: return launch_table_teams_t<256, 64, true>(ctx, a, window);
-        case 2: return launch_table_teams_t<512, 64, true>(ctx, a, window);
-        default: return launch_table_teams_t<1024, 64, true>(ctx, a, window);
-        }
-    }
-    if (pairs) {
-        switch (q) {
-        case 1: return launch_table_teams_t<256, 256, true>(ctx, a, window);
-        case 2: return launch_table_teams_t<512, 256, true>(ctx, a, window);
-        default: return launch_table_teams_t<1024, 256, true>(ctx, a, window);
-        }
-    }
-    switch (q) {
-    case 1: return launch_table_teams_t<256, 256, false>(ctx, a, window);
-    case 2: return launch_table_teams_t<512, 256, false>(ctx, a, window);
-    default: return launch_table_teams_t<1024, 256, false>(ctx, a, window);
-    }
+    if ((a.n & 1) == 0 && a.n >= 512) return launch_table_teams_t<1024, 64, true>(ctx, a, window);
+    return launch_table_teams_t<1024, 256, false>(ctx, a, window);
 }
 
 int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, const long long *cur_d,
@@ -1746,7 +1724,7 @@ int nq_eval_batch_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows_d, con
         }
     }
     if (max_cols > 0) {
-        if (ctx->nq_algo != LS_NQ_ALGO_SCAN && n >= 256 && n <= NQ_TABLE_LDS_MAX_N && ctx->nq_table_variant != 0) {
+        if (ctx->nq_algo != LS_NQ_ALGO_SCAN && n >= 256 && n <= NQ_TABLE_LDS_MAX_N) {
             int rc = launch_table_teams(ctx, a, window);
             if (rc != LS_OK) return rc;
         } else if (ctx->nq_algo != LS_NQ_ALGO_SCAN && n <= NQ_TABLE_LDS_MAX_N) {
@@ -1890,7 +1868,7 @@ int nq_step_dev(ls_ctx *ctx, int n_restarts, int n, const int *rows, const long 
     a.rows = rows; a.cur_scores = cur; a.cols = cols; a.n_cols = n_cols;
     a.n = n; a.n_restarts = n_restarts; a.max_cols = max_cols; a.window = window;
     a.best_keys = nullptr; a.scores_out = nullptr; a.tabs = nullptr; a.tab_stride = 0;
-    const bool pairs = (n & 1) == 0 && n >= 128 && ctx->nq_table_variant >= 10;
+    const bool pairs = (n & 1) == 0 && n >= 128;
     static std::atomic<bool> attr_done_dev[64];
     if (!attr_done_dev[ctx->device & 63].load(std::memory_order_acquire)) {
         const int max_lds = (((6 * NQ_STEP_MAX_N + 4) / 2 + 4) + NQ_STEP_MAX_N + 4 * NQ_STEP_MAX_SLOTS) * 4;

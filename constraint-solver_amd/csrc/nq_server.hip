@@ -346,38 +346,65 @@ static const void *server_fn(bool pairs)
     return pairs ? reinterpret_cast<const void *>(&nq_server_kernel<true>) : reinterpret_cast<const void *>(&nq_server_kernel<false>);
 }
 
+static size_t server_lds(int n, bool pairs)
+{
+    const size_t tab_words = pairs ? ((((size_t)(6 * n + 4) >> 1) + 3) & ~(size_t)3) : ((((size_t)(5 * n + 1) / 2) + 3) & ~(size_t)3);
+    return (tab_words + (((size_t)n + 3) & ~(size_t)3) + 4 * (size_t)NQ_STEP_MAX_SLOTS) * 4;
+}
+
+static int server_set_lds_attr(ls_ctx *ctx)
+{
+    static std::atomic<bool> attr_done_dev[64];
+    if (attr_done_dev[ctx->device & 63].load(std::memory_order_acquire)) return LS_OK;
+    const int max_lds = (((6 * NQ_STEP_MAX_N + 4) / 2 + 4) + NQ_STEP_MAX_N + 4 * NQ_STEP_MAX_SLOTS) * 4;
+    hipError_t e;
+    if ((e = hipFuncSetAttribute(server_fn(false), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess ||
+        (e = hipFuncSetAttribute(server_fn(true), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess)
+        return set_err(ctx, LS_ERR_HIP, "LS-step server: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    attr_done_dev[ctx->device & 63].store(true, std::memory_order_release);
+    return LS_OK;
+}
+
+// How many slots one resident launch can hold on this device for boards of size n: every workgroup (1024 threads, the
+// board's tables in LDS) must be resident for as long as the launch lives -- a workgroup that is never scheduled never
+// answers, and the served slots keep the launch from idling out -- so the count is bounded by what the CUs hold at once,
+// less some headroom for whatever else must run (another context's server, the scheduling grid, copy kernels).
+int nq_server_max_slots(ls_ctx *ctx, int n)
+{
+    if (server_set_lds_attr(ctx) != LS_OK) return 0;
+    const bool pairs = (n & 1) == 0 && n >= 128;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, server_fn(pairs), 1024, server_lds(n, pairs)) != hipSuccess) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    const long long cap = (long long)(per_cu < 1 ? 1 : per_cu) * ctx->n_cus - (ctx->n_cus >= 64 ? 16 : 0);
+    return (int)(cap < 1 ? 1 : (cap > 1024 ? 1024 : cap));
+}
+
 int nq_server_create(ls_ctx *ctx, int n, int n_slots, NqServer **out)
 {
     *out = nullptr;
-    if (n < 2 || n > NQ_STEP_MAX_N || n_slots < 1 || n_slots > 240)
+    if (n < 2 || n > NQ_STEP_MAX_N || n_slots < 1)
         return set_err(ctx, LS_ERR_UNSUPPORTED, "LS-step server: n = %d, %d slots outside what one resident launch holds", n, n_slots);
+    {
+        const int cap = nq_server_max_slots(ctx, n);
+        if (n_slots > cap)
+            return set_err(ctx, LS_ERR_UNSUPPORTED, "LS-step server: %d slots at n = %d, the device holds at most %d resident workgroups of it", n_slots, n, cap);
+    }
     NqServer *s = new (std::nothrow) NqServer();
     if (!s) return set_err(ctx, LS_ERR_NOMEM, "out of host memory");
     s->n = n;
     s->n_pad = (n + 63) & ~63;
     s->n_slots = n_slots;
-    s->pairs = (n & 1) == 0 && n >= 128 && ctx->nq_table_variant >= 10;
-    const size_t tab_words = s->pairs ? ((((size_t)(6 * n + 4) >> 1) + 3) & ~(size_t)3) : ((((size_t)(5 * n + 1) / 2) + 3) & ~(size_t)3);
-    s->lds = (tab_words + (((size_t)n + 3) & ~(size_t)3) + 4 * (size_t)NQ_STEP_MAX_SLOTS) * 4;
+    s->pairs = (n & 1) == 0 && n >= 128;
+    s->lds = server_lds(n, s->pairs);
     size_t off = 0;
     s->o_cols = off; off += (size_t)n_slots * NQ_STEP_MAX_SLOTS * 4;
     s->o_shadow = off; off += (size_t)n_slots * s->n_pad * 4;
     s->o_cs = off; off += (size_t)n_slots * s->n_pad * 2;
     int rc = s->h.init(ctx, "LS-step server", n_slots, off);
     if (rc != LS_OK) { delete s; return rc; }
-    static std::atomic<bool> attr_done_dev[64];
-    if (!attr_done_dev[ctx->device & 63].load(std::memory_order_acquire)) {
-        const int max_lds = (((6 * NQ_STEP_MAX_N + 4) / 2 + 4) + NQ_STEP_MAX_N + 4 * NQ_STEP_MAX_SLOTS) * 4;
-        hipError_t e;
-        if ((e = hipFuncSetAttribute(server_fn(false), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess ||
-            (e = hipFuncSetAttribute(server_fn(true), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) {
-            rc = set_err(ctx, LS_ERR_HIP, "LS-step server: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            s->h.release();
-            delete s;
-            return rc;
-        }
-        attr_done_dev[ctx->device & 63].store(true, std::memory_order_release);
-    }
     s->slots.resize((size_t)n_slots);
     for (auto &sl : s->slots) sl.cs.resize((size_t)n);
     s->h.launch = [s](const SrvLink &L) {
@@ -460,7 +487,7 @@ int nq_server_post(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, cons
     }
     ctx->steps_done++;
     if (!has_next_col_scores) sl.cs_valid = false; // nobody keeps the scores across this call
-    const bool want_cs = has_next_col_scores && !(sl.cs_valid && ctx->nq_host_cs);
+    const bool want_cs = has_next_col_scores && !sl.cs_valid;
     sl.want_cs = want_cs;
     // the window arithmetic of the step (nq_k_limit, nq_step_kernel) is done here: 64-bit divisions are slow on the device
     const long long full = window / (n - 1);
@@ -526,6 +553,7 @@ int nq_server_finish(ls_ctx *ctx, NqServer *s, int slot, int64_t cur_score, cons
             else widen_i32(sl.cs.data(), next_col_scores, n);
         }
     }
+    else if (moved) sl.cs_valid = false; // nobody asked for the scores of the board this call leaves behind: the cached ones are the previous board's
     if (moved) sh[res->best_col] = res->best_value; // the workgroup applied it to its LDS board
     if (trace) {
         const auto T3 = std::chrono::steady_clock::now();

@@ -152,7 +152,8 @@ inline void srv_store_line(volatile unsigned *dst, const unsigned *line)
 }
 
 struct SrvHost {
-    int device = 0, n_slots = 0;
+    int device = 0, n_slots = 0;  // n_slots: mailbox lines (a reader owns `lines_per_msg` consecutive ones)
+    int lines_per_msg = 1;
     const char *what = "server";
     hipStream_t stream = nullptr;
     char *pinned = nullptr;       // request lines | answer lines | exit word | the owner's per-server block
@@ -167,18 +168,7 @@ struct SrvHost {
     std::vector<unsigned> tags;   // last tag posted per slot
     std::function<hipError_t(const SrvLink &)> launch; // set by the owner: starts the resident kernel on `stream`
 
-    // Request lines: pinned host memory (the device polls them over PCIe), or -- LS_SRV_MAILBOX=device on a large-BAR platform --
-    // fine-grained DEVICE memory the host writes through the PCIe BAR (write-combined: one 64-byte store per line, then sfence):
-    // the workgroup's poll is then a local read and a request crosses PCIe once instead of being fetched (tools/server_probe.hip:
-    // mailbox round trip 2.9 -> 2.3 us).
-    unsigned *req_dev = nullptr;
-    unsigned *req(int s) const { return (req_dev ? req_dev : reinterpret_cast<unsigned *>(pinned)) + (size_t)s * 16; }
-    void flush_lines() const
-    {
-#if defined(__x86_64__)
-        if (req_dev) _mm_sfence();
-#endif
-    }
+    unsigned *req(int s) const { return reinterpret_cast<unsigned *>(pinned) + (size_t)s * 16; } // request lines: pinned host memory, polled over PCIe
     unsigned *resp(int s) const { return reinterpret_cast<unsigned *>(pinned + o_resp) + (size_t)s * 16; }
     unsigned long long *exit_gen() const { return reinterpret_cast<unsigned long long *>(pinned + o_exit); }
     char *extra() const { return pinned + o_extra; }
@@ -195,7 +185,7 @@ struct SrvHost {
         {   // CU-masked streams are never pooled; fallback: the high-priority pool
             std::vector<uint32_t> mask(((size_t)ctx->n_cus + 31) / 32, 0xffffffffu);
             if (ctx->n_cus % 32) mask.back() = (1u << (ctx->n_cus % 32)) - 1u;
-            e = getenv("LS_NQ_SERVER_PRIO_STREAM") ? hipErrorNotSupported : hipExtStreamCreateWithCUMask(&stream, (uint32_t)mask.size(), mask.data());
+            e = hipExtStreamCreateWithCUMask(&stream, (uint32_t)mask.size(), mask.data());
             if (e != hipSuccess) {
                 (void)hipGetLastError();
                 int lo = 0, hi = 0;
@@ -211,17 +201,6 @@ struct SrvHost {
         e = hipHostMalloc(reinterpret_cast<void **>(&pinned), off, hipHostMallocCoherent);
         if (e != hipSuccess) { pinned = nullptr; release(); return set_err(ctx, LS_ERR_NOMEM, "%s: pinned allocation failed: %s", what, hipGetErrorString(e)); }
         memset(pinned, 0, off);
-        if (const char *v = getenv("LS_SRV_MAILBOX")) {
-            int large_bar = 0;
-            if (strcmp(v, "device") == 0 && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar) {
-                if (hipExtMallocWithFlags(reinterpret_cast<void **>(&req_dev), (size_t)slots * 64, hipDeviceMallocFinegrained) != hipSuccess) {
-                    (void)hipGetLastError();
-                    req_dev = nullptr;
-                } else {
-                    hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, stream, reinterpret_cast<int *>(req_dev), 0, (long long)slots * 16);
-                }
-            }
-        }
         e = hipMalloc(reinterpret_cast<void **>(&ctl), 256);
         if (e != hipSuccess) { ctl = nullptr; release(); return set_err(ctx, LS_ERR_NOMEM, "%s: device allocation failed: %s", what, hipGetErrorString(e)); }
         hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<long long *>(ctl), 0ll, 32ll);
@@ -237,8 +216,7 @@ struct SrvHost {
         if (stream) (void)hipStreamDestroy(stream);
         if (pinned) (void)hipHostFree(pinned);
         if (ctl) (void)hipFree(ctl);
-        if (req_dev) (void)hipFree(req_dev);
-        stream = nullptr; pinned = nullptr; ctl = nullptr; req_dev = nullptr;
+        stream = nullptr; pinned = nullptr; ctl = nullptr;
     }
     bool drained() const { return __atomic_load_n(exit_gen(), __ATOMIC_ACQUIRE) == launch_gen.load(std::memory_order_acquire); }
 
@@ -275,10 +253,38 @@ struct SrvHost {
         alignas(64) unsigned line[16];
         for (int d = 0; d < 16; d++) line[d] = (tag << 16) | (pay[d] & 0xffffu);
         __atomic_thread_fence(__ATOMIC_RELEASE); // the bulk data is written before the line that announces it
-        flush_lines();                           // (a write-combined line is not ordered behind ordinary stores by itself)
         srv_store_line(req(slot), line);
-        flush_lines();
         requests.fetch_add(1, std::memory_order_relaxed);
+    }
+    // A message of n_lines consecutive lines starting at line `slot` (the scheduling grid: header + state), every dword under
+    // ONE new tag; the reader accepts a snapshot only when all tags agree, so the order of the line stores does not matter.
+    void post_lines(int slot, const unsigned *pay, int n_lines)
+    {
+        const unsigned tag = next_tag(slot);
+        alignas(64) unsigned msg[64];
+        for (int d = 0; d < 16 * n_lines; d++) msg[d] = (tag << 16) | (pay[d] & 0xffffu);
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        for (int l = n_lines - 1; l >= 0; l--) srv_store_line(req(slot + l), msg + 16 * l);
+        requests.fetch_add(1, std::memory_order_relaxed);
+    }
+    // QUIT to every reader (one per `lines_per_msg` lines), as a WHOLE message of that reader's size under one new tag
+    void post_quit_all()
+    {
+        unsigned pay[64] = {0};
+        pay[0] = SRV_F_QUIT;
+        for (int i = 0; i + lines_per_msg <= n_slots; i += lines_per_msg) {
+            if (lines_per_msg == 1) post(i, pay);
+            else post_lines(i, pay, lines_per_msg);
+        }
+        requests.fetch_sub((unsigned long long)(n_slots / lines_per_msg), std::memory_order_relaxed); // not requests of a caller
+    }
+    // the launch leaves now (its arguments are about to change, or memory is about to be released) and comes back on demand
+    void pause()
+    {
+        if (!stream) return;
+        (void)hipSetDevice(device);
+        if (pinned && !drained()) post_quit_all();
+        (void)hipStreamSynchronize(stream);
     }
     // Poll the slot's answer line for the tag of the request just posted (the same hooks as the completion-word wait of a
     // launched step: the caller's idle work, another restart's fibre, sched_yield).
@@ -309,7 +315,6 @@ struct SrvHost {
 #if defined(__x86_64__)
             else __builtin_ia32_pause();
 #endif
-            if (ctx->yield_while_waiting && spins >= 64) sched_yield();
             if ((spins & 15u) == 15u || ctx->wait_hook) { // behind a hook every return here may have been a long absence
                 // has the launch drained under the request (idle time-out, age limit)?  Then it is launched again and finds the request.
                 if (drained()) {
@@ -334,16 +339,7 @@ struct SrvHost {
     void shutdown()
     {
         if (!stream) return;
-        (void)hipSetDevice(device);
-        if (pinned && !drained()) {
-            for (int i = 0; i < n_slots; i++) {
-                const unsigned tag = next_tag(i);
-                volatile unsigned *dst = req(i);
-                for (int d = 0; d < 16; d++) dst[d] = (tag << 16) | (d == 0 ? SRV_F_QUIT : 0u);
-            }
-            flush_lines();
-        }
-        (void)hipStreamSynchronize(stream);
+        pause();
         release();
     }
 };

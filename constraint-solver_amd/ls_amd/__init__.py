@@ -342,21 +342,35 @@ class Solver:
 
 
 class MultiSolver:
-    """ls_multi_solver: R independent N-queens restarts on one GPU in lockstep (one batched launch
-    per step); each restart's result equals running it alone."""
+    """ls_multi_solver: many independent restarts on one GPU, each restart's result equal to running it alone.
+    MultiSolver(ctx, board_size, seeds, params) = N-queens; MultiSolver.scheduling(...) = the scheduling plug-in."""
 
     MODES = {"lockstep": 0, "free": 1}
 
-    def __init__(self, ctx: Context, board_size: int, seeds, params: dict, n_slots: int | None = None, mode: str | None = None):
+    def __init__(self, ctx: Context, board_size: int, seeds, params: dict, n_slots: int | None = None, mode: str | None = None,
+                 _sched=None):
         self._ctx, self._l, self.n, self.seeds = ctx, ctx._l, int(board_size), [str(s) for s in seeds]
+        self.kind = "nqueens" if _sched is None else "sched"
         arr = (C.c_char_p * len(self.seeds))(*[s.encode() for s in self.seeds])
         h = C.c_void_p()
         p = _params(params)
-        ctx._check(self._l.ls_multi_solver_create_nqueens(ctx._h, self.n, len(self.seeds), C.cast(arr, C.c_void_p),
-                                                          C.byref(p), C.byref(h)))
+        if _sched is None:
+            ctx._check(self._l.ls_multi_solver_create_nqueens(ctx._h, self.n, len(self.seeds), C.cast(arr, C.c_void_p),
+                                                              C.byref(p), C.byref(h)))
+        else:
+            n_days_scored, start_weekday, n_employees, hb = _sched
+            ctx._check(self._l.ls_multi_solver_create_sched(ctx._h, int(n_days_scored), int(start_weekday), int(n_employees), _vp(hb),
+                                                            len(self.seeds), C.cast(arr, C.c_void_p), C.byref(p), C.byref(h)))
         self._h = h
         if n_slots is not None or mode is not None:
             ctx._check(self._l.ls_multi_solver_configure(h, int(n_slots or 0), self.MODES[mode or "free"]))
+
+    @classmethod
+    def scheduling(cls, ctx: Context, n_days_scored: int, start_weekday: int, n_employees: int, seeds, params: dict,
+                   holiday_bits=None, n_slots: int | None = None) -> "MultiSolver":
+        """ls_multi_solver_create_sched: the restarts are the slots of ONE resident launch (step server or sub-grids)."""
+        hb = np.zeros(n_employees, dtype=np.uint64) if holiday_bits is None else _c(holiday_bits, np.uint64)
+        return cls(ctx, int(n_days_scored) + 1, seeds, params, n_slots=n_slots, _sched=(n_days_scored, start_weekday, n_employees, hb))
 
     def run(self, max_rounds_per_restart=2 ** 62, max_seconds=0.0):
         self._ctx._check(self._l.ls_multi_solver_run(self._h, int(max_rounds_per_restart), float(max_seconds)))
@@ -367,7 +381,10 @@ class MultiSolver:
         n, have = C.c_int32(), C.c_int()
         self._ctx._check(self._l.ls_multi_solver_get_best(self._h, int(restart), _vp(sc), _vp(sol), self.n, C.byref(n),
                                                           C.byref(have)))
-        return (int(sc[0]), tuple(int(x) for x in sol[:n.value])) if have.value else None
+        if not have.value:
+            return None
+        score = int(sc[0]) if self.kind == "nqueens" else (int(sc[0]), int(sc[1]))
+        return score, tuple(int(x) for x in sol[:n.value])
 
     def stats(self):
         a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()

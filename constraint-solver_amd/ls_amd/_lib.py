@@ -100,6 +100,7 @@ SIGNATURES = {
     "ls_solver_get_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ls_solver_free": (C.c_int, [_vp]),
     "ls_multi_solver_create_nqueens": (C.c_int, [_vp, C.c_uint64, _i32, _vp, _vp, C.POINTER(_vp)]),
+    "ls_multi_solver_create_sched": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, C.POINTER(_vp)]),
     "ls_multi_solver_configure": (C.c_int, [_vp, _i32, _i32]),
     "ls_multi_solver_run": (C.c_int, [_vp, C.c_uint64, C.c_double]),
     "ls_multi_solver_get_best": (C.c_int, [_vp, _i32, _vp, _vp, _i32, C.POINTER(_i32), C.POINTER(C.c_int)]),

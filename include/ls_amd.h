@@ -356,6 +356,17 @@ int ls_solver_free(ls_solver *s);
 typedef struct ls_multi_solver ls_multi_solver;
 int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_restarts, const char *const *seeds,
                                    const ls_solver_params *params, ls_multi_solver **out);
+/* The same for the scheduling plug-in: n_restarts complete, unchanged get_ils drivers (examples/employee-scheduling/src/lib.rs:57-117;
+ * instance as for ls_solver_create_sched, seeds by the convention of examples/nqueens/src/main.rs:167) on one GPU.  The slots'
+ * GPU requests go to ONE resident launch shared by all of them: slot t is workgroup t of the scheduling LS-step server (move
+ * lists of at most 512 entries: the reference example's window 100, examples/employee-scheduling/src/main.rs:26) or sub-grid t
+ * of the resident grid (longer lists: a window of 65 536 over 10 000 employees) -- no kernel launch per LS iteration, no slot
+ * waits for another.  Free-running only (LS_MULTI_LOCKSTEP is refused by ls_multi_solver_configure's caller contract: the
+ * mode argument is ignored for scheduling).  ls_multi_solver_get_best returns score[0] = hard, score[1] = soft and the employee
+ * indices of the n_days_scored + 1 stored days; every restart's result equals its ls_solver_create_sched run. */
+int ls_multi_solver_create_sched(ls_ctx *ctx, int32_t n_days_scored, int32_t start_weekday, int32_t n_employees,
+                                 const uint64_t *holiday_bits, int32_t n_restarts, const char *const *seeds,
+                                 const ls_solver_params *params, ls_multi_solver **out);
 /* n_slots in [1, 256], or 0 for the mode's default (default: four per core the process may use; free-running slots beyond the cores share host
  * threads as cooperative fibres: a slot whose launch is in flight lends its thread to a slot with host work to do;
  * lockstep slots are one host thread each), mode as above; call before ls_multi_solver_run. */

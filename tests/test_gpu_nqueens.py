@@ -334,7 +334,7 @@ def _expect_step(rows, cols, n_cols, window):
     return out
 
 
-@pytest.mark.parametrize("mode", ["4", "3", "2", "1", "0"])
+@pytest.mark.parametrize("mode", ["4", "3"])
 def test_fused_step_kernel_matches_oracle(monkeypatch, mode):
     # the solver's per-iteration launch: one block per restart does tables + argmin + move + column scores.
     # LS_NQ_STEP: 4 = no launch: one slot of the context's resident server per restart, all requests in flight at once (default),
@@ -345,7 +345,7 @@ def test_fused_step_kernel_matches_oracle(monkeypatch, mode):
     rng = np.random.default_rng(100 + int(mode))
     with ls_amd.Context(0) as c:                      # default algo: auto
         for n, R, mc, window in ((2, 3, 2, 10), (3, 2, 3, 4), (8, 4, 1, 40), (64, 5, 3, 64), (300, 6, 9, 1500),
-                                 (1024, 8, 51, 5120), (4096, 8, 204, 20480), (4096, 2, 3, 10 ** 9), (8192, 2, 12, 40960),
+                                 (1024, 8, 51, 5120), (64, 70, 3, 64), (4096, 8, 204, 20480), (4096, 2, 3, 10 ** 9), (8192, 2, 12, 40960),
                                  (8192, 1, 9, 65535), (500, 3, 4, 1)):
             kind = "uniform" if n % 2 == 0 else "perm"
             rows = np.stack([_board(rng, n, kind) for _ in range(R)])
@@ -367,8 +367,7 @@ def test_fused_step_kernel_matches_oracle(monkeypatch, mode):
                 assert np.array_equal(nxt[r], cs), (n, r)
 
 
-@pytest.mark.parametrize("host_cs,resident_tabs", [("1", "1"), ("0", "1"), ("1", "0")])
-def test_fused_step_resident_boards_follow_any_call_sequence(monkeypatch, host_cs, resident_tabs):
+def test_fused_step_resident_boards_follow_any_call_sequence(monkeypatch):
     # LS_NQ_STEP=3 keeps every restart's winner board on the device and uploads a board only when the caller's differs
     # from it.  Whatever the caller does next -- continue from the winner (local_search.rs:335), jump to an unrelated
     # board (perturbation, iterated_local_search.rs:192-194), change the batch size or the board size, repeat a call --
@@ -377,8 +376,6 @@ def test_fused_step_resident_boards_follow_any_call_sequence(monkeypatch, host_c
     # them every call.  LS_NQ_RESIDENT_TABS=1 (default): the count tables of a resident board stay on the device too and
     # every step patches them with its move; 0: rebuilt from the board every call.
     import ls_amd
-    monkeypatch.setenv("LS_NQ_HOST_CS", host_cs)
-    monkeypatch.setenv("LS_NQ_RESIDENT_TABS", resident_tabs)
     rng = np.random.default_rng(333)
     with ls_amd.Context(0) as c:
         def call(rows, cols, n_cols, window):

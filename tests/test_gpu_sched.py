@@ -15,13 +15,12 @@ import oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-# every test runs on the default DELTA scorer (one lane per candidate; long move lists in two launches), on its
-# one-launch form (the last block finishes) and on the wavefront-per-candidate kernels
-@pytest.fixture(scope="module", params=["delta", "delta-one-launch", "wavefront"])
+# every test runs on the default DELTA scorer (one lane per candidate; long move lists in two launches) and on the
+# wavefront-per-candidate kernels
+@pytest.fixture(scope="module", params=["delta", "wavefront"])
 def ctx(request):
     import ls_amd
-    knobs = {"LS_SCHED_DELTA": "0" if request.param == "wavefront" else "1",
-             "LS_SCHED_ONE_LAUNCH": "1" if request.param == "delta-one-launch" else "0"}
+    knobs = {"LS_SCHED_DELTA": "0" if request.param == "wavefront" else "1"}
     old = {k: os.environ.get(k) for k in knobs}
     os.environ.update(knobs)
     try:
@@ -198,16 +197,15 @@ def test_resident_move_list_matches_host_list(ctx):
         ctx.sched_eval_resident(state, 901, 10)
 
 
+@pytest.mark.parametrize("server", ["1", "0"])
 @pytest.mark.parametrize("delta", ["1", "0"])
-@pytest.mark.parametrize("fused,zero_copy", [("1", "1"), ("1", "0"), ("0", "1")])
-def test_small_launch_fused_kernel(monkeypatch, fused, zero_copy, delta):
-    # move lists of <= 512 entries run locate + eval + reduce as ONE block per restart (LS_SCHED_FUSED, default on);
-    # the resident entry hands the kernels the pinned staging blocks directly (LS_SCHED_ZEROCOPY, default on)
+def test_small_launch_fused_kernel(monkeypatch, delta, server):
+    # move lists of <= 512 entries run locate + eval + reduce as ONE block per restart; the resident entry goes to the
+    # resident workgroup (LS_SCHED_SERVER=1, default) or hands the launched kernels its inputs in the kernel arguments (=0)
     import ls_amd
-    monkeypatch.setenv("LS_SCHED_FUSED", fused)
-    monkeypatch.setenv("LS_SCHED_ZEROCOPY", zero_copy)
     monkeypatch.setenv("LS_SCHED_DELTA", delta)
-    rng = np.random.default_rng(40 + int(fused) * 2 + int(zero_copy))
+    monkeypatch.setenv("LS_SCHED_SERVER", server)
+    rng = np.random.default_rng(40 + int(delta) * 2 + int(server))
     with ls_amd.Context(0) as c:
         for start, end, n_emp in (((2022, 5, 9), (2022, 6, 8), 7),      # half-wavefront kernel (32 stored days)
                                   ((2024, 1, 3), (2024, 1, 10), 3),     # 8 days
@@ -318,30 +316,20 @@ def test_config5_random_stream_at_launch_size(ctx, window):
                (exp["n_scored"], exp["best_index"], exp["best_hard"], exp["best_soft"])
 
 
-@pytest.mark.parametrize("bpw", ["1", "2", "3", None])
-@pytest.mark.parametrize("table", [True, False])
-def test_two_launch_pipeline_batches_per_wavefront_and_employee_table(monkeypatch, bpw, table):
-    # sched_eval_all_kernel's two tuning dimensions leave every result alone: 1 / 2 / 3 batches of 64 candidates per wavefront
-    # (LS_SCHED_DELTA_BPW; unset = chosen from the grid size) and the employee -> scored-days look-up table in LDS against
-    # the day-by-day compare loops (LS_SCHED_NO_EMP_TABLE=1).  700 employees x 32 days: 22 400 exhaustive candidates.
-    if bpw is None:
-        monkeypatch.delenv("LS_SCHED_DELTA_BPW", raising=False)
-    else:
-        monkeypatch.setenv("LS_SCHED_DELTA_BPW", bpw)
-    if table:
-        monkeypatch.delenv("LS_SCHED_NO_EMP_TABLE", raising=False)
-    else:
-        monkeypatch.setenv("LS_SCHED_NO_EMP_TABLE", "1")
+@pytest.mark.parametrize("E", [700, 13_000])
+def test_two_launch_pipeline_with_and_without_employee_table(monkeypatch, E):
+    # sched_eval_all_kernel with the employee -> scored-days look-up table in LDS (700 employees: 2.8 KB per block) and with the
+    # day-by-day compare loops it falls back to when the table does not fit beside three blocks per CU (13 000 employees: 52 KB);
+    # batches of 64 candidates per wavefront chosen from the grid size.  E x 32 exhaustive candidates.
     import ls_amd
     monkeypatch.setenv("LS_SCHED_SERVER", "0")                        # the launched pipeline, not the resident grid
     rng = np.random.default_rng(31)
-    E = 700
     hol = {int(e): list(rng.choice(31, size=2, replace=False)) for e in rng.choice(E, size=200, replace=False)}
     with ls_amd.Context(0) as c:
         inst, D, S = _upload(c, (2022, 5, 9), (2022, 6, 8), E, hol)
-        for trial in range(2):
+        for trial in range(2 if E < 1000 else 1):
             states = np.stack([rng.integers(0, E, size=S), rng.integers(0, 9, size=S), rng.integers(0, E, size=S)])
-            for window in (10 ** 9, 22_000, 1537, 1536, 511, 1):
+            for window in (10 ** 9, 22_000, 1537, 1536, 511, 1) if E < 1000 else (10 ** 9, 1537):
                 got = c.sched_eval_exhaustive(states, window)
                 for r in range(len(states)):
                     moves = orc.Sched.exhaustive_moves(states[r], range(E))

@@ -49,13 +49,11 @@ def _step(c, rows, cols, window, with_next=True):
     return board
 
 
-@pytest.mark.parametrize("host_cs", ["1", "0"])
-def test_server_follows_any_call_sequence(monkeypatch, host_cs):
+def test_server_follows_any_call_sequence(monkeypatch):
     # Whatever the caller does next -- continue from the winner (local_search.rs:335: nothing is uploaded, the workgroup's
     # LDS board and tables carry the move), jump to an unrelated board (perturbation, iterated_local_search.rs:192-194),
     # repeat a call, ask for an empty neighbourhood, change the board size -- each call equals a stateless evaluation.
     import ls_amd
-    monkeypatch.setenv("LS_NQ_HOST_CS", host_cs)
     rng = np.random.default_rng(4242)
     with ls_amd.Context(0) as c:
         # (n, columns, window): odd n = one candidate per lane, even n >= 128 = paired wavefront teams; windows that cut a
@@ -387,7 +385,8 @@ def _random_moves(rng, n, D, E):
 
 @pytest.mark.parametrize("dates,E", [(((2022, 5, 9), (2022, 6, 8)), 7),        # the example instance: 31 scored / 32 stored days
                                      (((2022, 5, 9), (2022, 7, 10)), 40),       # 63 / 64 days: the 64-bit day sets
-                                     (((2022, 5, 11), (2022, 5, 24)), 3)])      # 14 / 15 days, starts on a Wednesday
+                                     (((2022, 5, 11), (2022, 5, 24)), 3),       # 14 / 15 days, starts on a Wednesday
+                                     (((2022, 5, 9), (2022, 6, 8)), 12_000)])   # too many employees for the LDS look-up table: day-by-day scorers
 def test_sched_server_follows_any_call_sequence(monkeypatch, dates, E):
     # ls_sched_eval_resident / ls_sched_score through the resident scheduling workgroup (no launch per call): continue from
     # the winner (the workgroup applies it to its LDS state), perturb, repeat, windows that cut / exceed the list, a new
@@ -404,12 +403,8 @@ def test_sched_server_follows_any_call_sequence(monkeypatch, dates, E):
         for d in ds:
             bits[e] |= np.uint64(1) << np.uint64(int(d))
     results = {}
-    for server in ("1", "1 day-by-day", "0"):   # resident (employee table in LDS) | resident, scorers compare day by day | launch per call
-        monkeypatch.setenv("LS_SCHED_SERVER", server[0])
-        if server == "1 day-by-day":
-            monkeypatch.setenv("LS_SCHED_NO_EMP_TABLE", "1")
-        else:
-            monkeypatch.delenv("LS_SCHED_NO_EMP_TABLE", raising=False)
+    for server in ("1", "0"):   # resident | launch per call
+        monkeypatch.setenv("LS_SCHED_SERVER", server)
         prng = np.random.default_rng(5)
         got = []
         with ls_amd.Context(0) as c:
@@ -450,7 +445,7 @@ def test_sched_server_follows_any_call_sequence(monkeypatch, dates, E):
             if server != "0":
                 assert cnt["server_launches"] >= 3
         results[server] = got
-    assert results["1"] == results["0"] == results["1 day-by-day"]
+    assert results["1"] == results["0"]
 
 
 def test_sched_grid_server_long_lists(monkeypatch):
@@ -470,12 +465,8 @@ def test_sched_grid_server_long_lists(monkeypatch):
         for d in ds:
             bits[e] |= np.uint64(1) << np.uint64(int(d))
     results = {}
-    for server in ("1", "1 day-by-day", "0"):   # resident (employee table in LDS) | resident, scorers compare day by day | launch per call
-        monkeypatch.setenv("LS_SCHED_SERVER", server[0])
-        if server == "1 day-by-day":
-            monkeypatch.setenv("LS_SCHED_NO_EMP_TABLE", "1")
-        else:
-            monkeypatch.delenv("LS_SCHED_NO_EMP_TABLE", raising=False)
+    for server in ("1", "0"):   # resident | launch per call
+        monkeypatch.setenv("LS_SCHED_SERVER", server)
         prng = np.random.default_rng(9)
         got = []
         with ls_amd.Context(0) as c:
@@ -512,7 +503,7 @@ def test_sched_grid_server_long_lists(monkeypatch):
             cnt = c.counters()
             assert (cnt["server_requests"] >= 40) == (server != "0")
         results[server] = got
-    assert results["1"] == results["0"] == results["1 day-by-day"]
+    assert results["1"] == results["0"]
 
 
 def test_sched_exhaustive_grid(monkeypatch):
@@ -526,12 +517,8 @@ def test_sched_exhaustive_grid(monkeypatch):
     monkeypatch.setenv("LS_NQ_SERVER_IDLE_US", "500")
     rng = np.random.default_rng(4242)
     results = {}
-    for server in ("1", "1 day-by-day", "0"):
-        monkeypatch.setenv("LS_SCHED_SERVER", server[0])
-        if server == "1 day-by-day":
-            monkeypatch.setenv("LS_SCHED_NO_EMP_TABLE", "1")
-        else:
-            monkeypatch.delenv("LS_SCHED_NO_EMP_TABLE", raising=False)
+    for server in ("1", "0"):
+        monkeypatch.setenv("LS_SCHED_SERVER", server)
         prng = np.random.default_rng(17)
         got = []
         with ls_amd.Context(0) as c:
@@ -574,7 +561,7 @@ def test_sched_exhaustive_grid(monkeypatch):
             cnt = c.counters()
             assert (cnt["server_requests"] > 30) == (server != "0")
         results[server] = got
-    assert results["1"] == results["0"] == results["1 day-by-day"]
+    assert results["1"] == results["0"]
 
 
 @pytest.mark.parametrize("E,chunks_per_workgroup", [(5000, 2), (16000, 4)])
@@ -670,11 +657,119 @@ def test_two_scheduling_grids_that_cannot_both_be_resident():
         assert a.counters()["completion_word_fallbacks"] == 0 and after["completion_word_fallbacks"] == 0
 
 
-def test_servers_with_the_mailbox_in_device_memory(monkeypatch):
-    # LS_SRV_MAILBOX=device: the request lines live in fine-grained device memory and the host writes them through the PCIe BAR
-    # (write-combined 64-byte stores + fences); falls back to pinned host memory where the platform has no large BAR.  The
-    # N-queens server, the scheduling workgroup and the scheduling grid, each against the oracle and its launched route.
-    monkeypatch.setenv("LS_SRV_MAILBOX", "device")
-    test_server_equals_launch_per_call_route(monkeypatch)
-    test_sched_grid_server_long_lists(monkeypatch)
-    test_sched_server_follows_any_call_sequence(monkeypatch, ((2022, 5, 9), (2022, 6, 8)), 7)
+# ------------------------------------------------------------------------------------ many scheduling restarts per GPU
+SCHED_EXAMPLE = dict(local_search_max_iterations=1_000, window_size=100, best_solutions_capacity=64, all_solutions_capacity=100_000,
+                     all_solution_iteration_expiry=1_000, iterated_local_search_max_iterations=250, max_allow_no_improvement_for=20)
+
+
+def _single_sched_run(c, D, wd, E, seed, params, bits, rounds):
+    import ls_amd
+    s = ls_amd.Solver.scheduling(c, D, wd, E, seed, params, holiday_bits=bits)
+    done = 0
+    while not s.is_finished() and done < rounds:
+        s.execute_round()
+        done += 1
+    out = (s.best(), s.stats()["ls_iterations"], s.stats()["neighbours_scored"], done)
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("n_seeds,n_slots,rounds", [(64, 64, 12), (9, 4, 20)])
+def test_multi_sched_step_server_slots_equal_single_runs(monkeypatch, n_seeds, n_slots, rounds):
+    # ls_multi_solver_create_sched on the example instance (config 3: window 100): the restarts are the workgroups of ONE resident
+    # scheduling LS-step launch (64 slots as fibres over the cores; 4 slots for 9 seeds: a finished restart's slot takes the next
+    # seed, whose move stream the workgroup then loads under a new id).  Every restart's best solution, LS-iteration count and
+    # candidate count equal its single ls_solver run on the launch-per-call route (LS_SCHED_SERVER=0: another code path).
+    import ls_amd
+    seeds = [str(42 + r) for r in range(n_seeds)]
+    monkeypatch.setenv("LS_SCHED_SERVER", "0")
+    with ls_amd.Context(0) as c0:
+        single = [_single_sched_run(c0, 31, 0, 7, sd, SCHED_EXAMPLE, None, rounds) for sd in seeds]
+        assert c0.counters()["server_requests"] == 0
+    monkeypatch.setenv("LS_SCHED_SERVER", "1")
+    with ls_amd.Context(0) as c:
+        m = ls_amd.MultiSolver.scheduling(c, 31, 0, 7, seeds, SCHED_EXAMPLE, n_slots=n_slots)
+        m.run(max_rounds_per_restart=rounds)
+        cnt = m.counters()
+        for r in range(n_seeds):
+            st = m.restart_stats(r)
+            assert (m.best(r), st["ls_iterations"], st["neighbours_scored"], st["rounds"]) == single[r], (r, seeds[r])
+        tot = m.stats()
+        assert tot["ls_iterations"] == sum(s[1] for s in single)
+        # one request per LS iteration + one per score() (initial solution, each round's perturbed start); ONE launch unless it idled out
+        assert cnt["server_requests"] >= tot["ls_iterations"] + n_seeds * rounds
+        assert cnt["completion_word_fallbacks"] == 0
+        m.close()
+
+
+def test_multi_sched_one_restart_follows_the_oracle_driver():
+    # one restart of a 16-slot run against oracle/ls_oracle.py (the reference's driver restated with the literal pipeline), round for round
+    import ls_amd
+    import ls_oracle as lo
+    seeds = [str(100 + r) for r in range(16)]
+    rounds = 5
+    with ls_amd.Context(0) as c:
+        m = ls_amd.MultiSolver.scheduling(c, 31, 0, 7, seeds, SCHED_EXAMPLE, n_slots=16)
+        m.run(max_rounds_per_restart=rounds)
+        for r in (0, 7, 15):
+            o = lo.IteratedLocalSearch(lo.Scheduling((2022, 5, 9), (2022, 6, 8), 7), dict(SCHED_EXAMPLE), seeds[r])
+            for _ in range(rounds):
+                o.execute_round()
+            assert m.best(r) == o.get_best_solution(), seeds[r]
+            assert m.restart_stats(r)["ls_iterations"] == o.local_search.ls_iterations
+        m.close()
+
+
+def test_multi_sched_sub_grids_equal_single_runs(monkeypatch):
+    # config 5's shape at test size: 2 000 employees with holidays, window 4 096 (a stream prefix of 5 136 moves: 11 chunks) --
+    # beyond one workgroup, so the restarts are the SUB-GRIDS of one resident grid launch (8 restarts side by side; 3 slots for 5
+    # seeds: a sub-grid takes the next seed's stream under a new id).  Against single ls_solver runs on the launched pipeline.
+    import ls_amd
+    rng = np.random.default_rng(55)
+    E = 2000
+    bits = np.zeros(E, dtype=np.uint64)
+    for e in range(E):
+        for d in rng.choice(31, size=int(rng.integers(0, 4)), replace=False):
+            bits[e] |= np.uint64(1) << np.uint64(int(d))
+    p = dict(SCHED_EXAMPLE, window_size=4096)
+    rounds = 3
+    for n_seeds, n_slots in ((8, 8), (5, 3)):
+        seeds = [str(7 + r) for r in range(n_seeds)]
+        monkeypatch.setenv("LS_SCHED_SERVER", "0")
+        with ls_amd.Context(0) as c0:
+            single = [_single_sched_run(c0, 31, 0, E, sd, p, bits, rounds) for sd in seeds]
+        monkeypatch.setenv("LS_SCHED_SERVER", "1")
+        with ls_amd.Context(0) as c:
+            m = ls_amd.MultiSolver.scheduling(c, 31, 0, E, seeds, p, holiday_bits=bits, n_slots=n_slots)
+            m.run(max_rounds_per_restart=rounds)
+            cnt = m.counters()
+            for r in range(n_seeds):
+                st = m.restart_stats(r)
+                assert (m.best(r), st["ls_iterations"], st["neighbours_scored"], st["rounds"]) == single[r], (n_slots, seeds[r])
+            assert cnt["server_requests"] >= m.stats()["ls_iterations"] and cnt["completion_word_fallbacks"] == 0
+            m.close()
+
+
+def test_sched_exhaustive_grid_many_chunks_per_workgroup_day_by_day():
+    # 26 000 employees: 832 000 exhaustive candidates = 1 625 chunks, seven per workgroup (the eight-chunk instantiation), and
+    # too many employees for the LDS look-up table (the scorers compare day by day).  Windows inside the first workgroups.
+    import ls_amd
+    rng = np.random.default_rng(88)
+    E = 26_000
+    hol = {int(e): [int(rng.integers(0, 31))] for e in rng.choice(E, size=3000, replace=False)}
+    inst = orc.Sched((2022, 5, 9), (2022, 6, 8), hol)
+    D, S = inst.n_scored_days, inst.n_scored_days + 1
+    bits = np.zeros(E, dtype=np.uint64)
+    for e, ds in hol.items():
+        for d in ds:
+            bits[e] |= np.uint64(1) << np.uint64(int(d))
+    with ls_amd.Context(0) as c:
+        c.sched_instance_upload(D, S, inst.start_weekday, E, bits)
+        state = rng.integers(0, E, size=S)
+        moves = c.sched_exhaustive_moves(state[None, :])[0]
+        for w in (3000, 3584 + 1, 7 * 512 * 3 + 17, 40_000):
+            r = c.sched_eval_exhaustive(state[None, :], w)[0]
+            exp = inst.neighbourhood(state, moves[:w + 64], w)
+            assert (r["n_scored"], r["best_index"], r["best_hard"], r["best_soft"]) == \
+                   (exp["n_scored"], exp["best_index"], exp["best_hard"], exp["best_soft"]), w
+        assert c.counters()["server_requests"] >= 4
