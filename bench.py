@@ -764,6 +764,7 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True, sc
     if e2e:
         out["config4_end_to_end_64_restarts_one_gpu"] = config4_end_to_end(ctx, n)
         out.update(single_restart_end_to_end(ctx))
+        out.update(multi_restart_sched_end_to_end(ctx, out))
     ctx.set_algo("scan")
     out.update(sched_measurements(ctx, torch, dev, timed, issue_roofline, cpu_seconds=max(sched_cpu_seconds, 0.05)))
     # the HBM figure the rooflines divide by is the vendor's 8 TB/s; this is what a plain device-to-device
@@ -890,6 +891,63 @@ def single_restart_end_to_end(ctx):
             ls_amd.Solver.scheduling(ctx, 31, 0, 10_000, "42", dict(sched, window_size=65_536), holiday_bits=bits), 250)
     except Exception as e:  # noqa: BLE001 - a secondary line must not take the bench down
         out["single_restart_end_to_end_error"] = repr(e)
+    return out
+
+
+def multi_restart_sched_end_to_end(ctx, so_far):
+    """Many scheduling restarts on ONE GPU through ls_multi_solver_create_sched (driver per restart:
+    examples/employee-scheduling/src/lib.rs:57-117, seeds by examples/nqueens/src/main.rs:167): config 3 x 64 restarts as the
+    workgroups of one resident LS-step launch, config 5 x 8 restarts as the sub-grids of one resident grid launch.  After the
+    timed runs, sampled restarts are run again alone through ls_solver and must give the same best solution and LS-iteration
+    count; config 5's wall is compared with one restart alone (from the single-restart leg)."""
+    import ls_amd
+    sched = dict(local_search_max_iterations=1_000, window_size=100, best_solutions_capacity=64, all_solutions_capacity=100_000,
+                 all_solution_iteration_expiry=1_000, iterated_local_search_max_iterations=250, max_allow_no_improvement_for=20)
+    out = {}
+
+    def single(args, kw, seed):
+        s = ls_amd.Solver.scheduling(ctx, *args, seed, kw.get("params"), holiday_bits=kw.get("bits"))
+        rounds = 0
+        while not s.is_finished() and rounds < 250:
+            s.execute_round()
+            rounds += 1
+        r = (s.best(), s.stats()["ls_iterations"])
+        s.close()
+        return r
+
+    def leg(name, args, params, bits, seeds, sample):
+        try:
+            m = ls_amd.MultiSolver.scheduling(ctx, *args, seeds, params, holiday_bits=bits, n_slots=len(seeds))
+            t0 = time.perf_counter()
+            m.run(max_rounds_per_restart=250, max_seconds=120.0)
+            dt = time.perf_counter() - t0
+            st, cnt = m.stats(), m.counters()
+            got = {r: (m.best(r), m.restart_stats(r)["ls_iterations"]) for r in sample}
+            scores = sorted(m.best(r)[0] for r in range(len(seeds)) if m.best(r) is not None)
+            m.close()
+            same = all(got[r] == single(args, dict(params=params, bits=bits), seeds[r]) for r in sample)
+            out[name] = {"seconds": dt, "restarts": len(seeds), "neighbours_scored": st["neighbours_scored"],
+                         "neighbours_per_s": st["neighbours_scored"] / dt, "ls_iterations": st["ls_iterations"],
+                         "ls_iterations_per_s": st["ls_iterations"] / dt, "us_per_ls_iteration_per_restart": dt / max(1, st["ls_iterations"]) * len(seeds) * 1e6,
+                         "best_scores": [list(x) for x in scores[:4]], "host_cores": host_core_share(), "counters": cnt,
+                         "equal_single_solver_runs": bool(same), "restarts_compared": [seeds[r] for r in sample]}
+            if not same:
+                out[name]["error"] = "a restart of the timed multi-restart run differs from its single-solver run"
+        except Exception as e:  # noqa: BLE001 - reported through the line; the caller fails the bench on it
+            out[name] = {"error": repr(e)}
+
+    leg("config3_multi_restart_end_to_end", (31, 0, 7), sched, None, [str(42 + r) for r in range(64)], (0, 21, 63))
+    E = 10_000
+    rng = np.random.default_rng(5)
+    bits = np.zeros(E, dtype=np.uint64)
+    for e in range(E):
+        for d in rng.choice(31, size=int(rng.integers(0, 4)), replace=False):
+            bits[e] |= np.uint64(1) << np.uint64(d)
+    leg("config5_multi_restart_end_to_end", (31, 0, E), dict(sched, window_size=65_536), bits, [str(42 + r) for r in range(8)], (0, 5))
+    one = (so_far.get("config5_end_to_end_sched10k_window65536_seed42") or {}).get("seconds")
+    if one and "seconds" in out["config5_multi_restart_end_to_end"]:
+        out["config5_multi_restart_end_to_end"]["single_restart_seconds"] = one
+        out["config5_multi_restart_end_to_end"]["wall_over_single_restart"] = out["config5_multi_restart_end_to_end"]["seconds"] / one
     return out
 
 

@@ -1203,7 +1203,7 @@ int ls_sched_eval_resident(ls_ctx *ctx, const int32_t *state, int64_t n_moves, i
             if (rc_s != LS_ERR_UNSUPPORTED) return rc_s;
         } else {
             SchedGrid *g = nullptr;
-            const int rc0 = sched_ctx_grid(ctx, false, ctx->sc_resident_n, &g);
+            const int rc0 = sched_ctx_grid(ctx, false, n_moves, &g); // sized by the prefix the caller asks for (the driver keeps a longer list resident than it uses)
             if (rc0 != LS_OK) return rc0;
             if (g) {
                 const int rc_g = sched_grid_eval(ctx, g, ctx->sched_grid_sub, state, n_moves, window, out);

@@ -269,6 +269,7 @@ int nq_ctx_prepare_server(ls_ctx *ctx, int n);
                                   (size_t)(bytes), hipGetErrorString(e__));                 \
     } while (0)
 
+#if defined(__HIPCC__) // (the host logic also compiles without a HIP compiler: tests/cpp/srv_host_test.cpp, against a fake runtime)
 // one copy per translation unit that launches it
 static __global__ void fill_i64_kernel(long long *p, long long value, long long count)
 {
@@ -328,5 +329,7 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x)
     const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
     return ((unsigned long long)rhi << 32) | rlo;
 }
+
+#endif // __HIPCC__
 
 } // namespace lsamd

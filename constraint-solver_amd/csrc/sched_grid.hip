@@ -601,9 +601,10 @@ int sched_grid_eval(ls_ctx *ctx, SchedGrid *s, int sub, const int32_t *state, lo
     if (rc != LS_OK) return rc;
     SchedGrid::Sub &b = s->subs[(size_t)sub];
     const int S = ctx->sched.n_days_stored;
+    if (!s->gen && n_moves > s->stream_cap) return set_err(ctx, LS_ERR_UNSUPPORTED, "scheduling grid: %lld moves exceed the sub-grid's %lld", n_moves, s->stream_cap);
     if (!s->gen && (b.stream_ctx != ctx || b.stream_gen != ctx->sc_resident_gen)) { // a new list (a new restart on this sub-grid): into its pinned block, under a new id
-        const size_t n = ctx->sc_resident_host.size();
-        if ((long long)n > s->stream_cap) return set_err(ctx, LS_ERR_UNSUPPORTED, "scheduling grid: a list of %zu moves exceeds the sub-grid's %lld", n, s->stream_cap);
+        // (the prefix the sub-grid can hold: the caller's list may be longer than what its requests use)
+        const size_t n = ctx->sc_resident_host.size() < (size_t)s->stream_cap ? ctx->sc_resident_host.size() : (size_t)s->stream_cap;
         if (n) memcpy(s->stream(sub), ctx->sc_resident_host.data(), n * sizeof(ls_sched_move));
         b.stream_ctx = ctx;
         b.stream_gen = ctx->sc_resident_gen;

@@ -145,10 +145,12 @@ __attribute__((target("avx512f"))) inline void srv_store_line_wide(volatile unsi
 inline void srv_store_line(volatile unsigned *dst, const unsigned *line)
 {
 #if defined(__x86_64__)
+#if !defined(__SANITIZE_THREAD__) // (ThreadSanitizer sees the dword-wise form below: every access of a line is an atomic one there)
     static const bool wide = __builtin_cpu_supports("avx512f") && getenv("LS_HOST_NO_AVX512") == nullptr;
     if (wide) { srv_store_line_wide(dst, line); return; }
 #endif
-    for (int d = 0; d < 16; d++) dst[d] = line[d];
+#endif
+    for (int d = 0; d < 16; d++) __atomic_store_n(const_cast<unsigned *>(dst) + d, line[d], __ATOMIC_RELAXED);
 }
 
 struct SrvHost {
@@ -165,6 +167,7 @@ struct SrvHost {
     std::atomic<unsigned long long> relaunches{0}, slow_waits{0}, requests{0};
     bool failed = false;
     unsigned relaunch_limit = 0;  // wait(): give up (SRV_RC_GIVE_UP) after this many relaunches under one request; 0: never
+    double no_answer_seconds = 10.0; // wait(): an error after this long without an answer from a launch that has not drained
     std::vector<unsigned> tags;   // last tag posted per slot
     std::function<hipError_t(const SrvLink &)> launch; // set by the owner: starts the resident kernel on `stream`
 
@@ -304,7 +307,7 @@ struct SrvHost {
         for (unsigned spins = 0;; spins++) {
             unsigned v[8];
             bool ok = true;
-            for (int d = 0; d < 8; d++) { v[d] = r[d]; ok = ok && (v[d] >> 16) == tag; }
+            for (int d = 0; d < 8; d++) { v[d] = __atomic_load_n(const_cast<const unsigned *>(r) + d, __ATOMIC_RELAXED); ok = ok && (v[d] >> 16) == tag; }
             if (ok) {
                 __atomic_thread_fence(__ATOMIC_ACQUIRE);
                 for (int d = 0; d < 8; d++) out[d] = v[d] & 0xffffu;
@@ -327,9 +330,9 @@ struct SrvHost {
                 }
                 if ((spins & 0x3ffu) == 0x3ffu) {
                     if (!timed) { t0 = std::chrono::steady_clock::now(); timed = true; }
-                    else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+                    else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > no_answer_seconds) {
                         const hipError_t e = hipStreamQuery(stream);
-                        return set_err(ctx, LS_ERR_HIP, "%s: no answer from slot %d within 10 s (stream: %s)", what, slot, hipGetErrorString(e));
+                        return set_err(ctx, LS_ERR_HIP, "%s: no answer from slot %d within %.1f s (stream: %s)", what, slot, no_answer_seconds, hipGetErrorString(e));
                     }
                 }
             }

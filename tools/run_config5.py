@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """BASELINE.json config 5, end to end: synthetic employee scheduling, 10 000 employees x 31 scored days (32 stored),
-holidays h ~ U{0..3} per employee, ONE independent restart per GPU (seed "42"+global restart id), random move stream
-with window 65 536, reference hyper-parameters of examples/employee-scheduling/src/main.rs:22-31.  Restart r on rank
+holidays h ~ U{0..3} per employee, independent restarts (seed "42"+global restart id; ONE per GPU by default), random move
+stream with window 65 536, reference hyper-parameters of examples/employee-scheduling/src/main.rs:22-31.  Restart r on rank
 r mod N, no data-path collective: a host-side gather of one (score, solution) record per restart and a minimum in
-ScoredSolution order.  One process per GPU:
+ScoredSolution order.  Several restarts on one GPU (--restarts-per-gpu 8: the whole of config 5 on ONE GPU) run side by
+side as the sub-grids of one resident launch (ls_multi_solver_create_sched).  One process per GPU:
 
-    python tools/run_config5.py [--employees 10000] [--window 65536] [--rounds 250] [--seconds 60]
+    python tools/run_config5.py [--employees 10000] [--window 65536] [--rounds 250] [--seconds 60] [--restarts-per-gpu 1]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/run_config5.py ...
 """
 import argparse
@@ -61,7 +62,8 @@ def main():
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        for rid in ids:                               # restarts of one rank run back to back (one per GPU by default)
+        if len(ids) == 1:                             # one restart per GPU: the plain solver (its own one-sub-grid launch)
+            rid = ids[0]
             s = ls_amd.Solver.scheduling(ctx, D, 0, E, str(42 + rid), params, holiday_bits=bits)
             rounds = 0
             while not s.is_finished() and rounds < args.rounds and time.perf_counter() - t0 < args.seconds:
@@ -72,6 +74,16 @@ def main():
             if b is not None:
                 recs.append(sharding.record(rid, b[0], b[1]))
             s.close()
+        else:                                         # several: side by side, the sub-grids of ONE resident launch
+            m = ls_amd.MultiSolver.scheduling(ctx, D, 0, E, [str(42 + rid) for rid in ids], params, holiday_bits=bits, n_slots=len(ids))
+            m.run(max_rounds_per_restart=args.rounds, max_seconds=args.seconds)
+            st = m.stats()
+            tot += (st["neighbours_scored"], st["ls_iterations"], st["rounds"])
+            for i, rid in enumerate(ids):
+                b = m.best(i)
+                if b is not None:
+                    recs.append(sharding.record(rid, b[0], b[1]))
+            m.close()
         dt = time.perf_counter() - t0
     best, allr = sharding.gather_best(recs)
     t_tot = torch.tensor(tot, dtype=torch.float64, device=red_dev)
