@@ -286,8 +286,15 @@ struct SrvHost {
     {
         if (!stream) return;
         (void)hipSetDevice(device);
-        if (pinned && !drained()) post_quit_all();
+        const bool asked = pinned && !drained();
+        if (asked) post_quit_all();
         (void)hipStreamSynchronize(stream);
+        // The QUIT messages stay in the request lines; a reader of the NEXT launch takes "the last request served" from its
+        // answer line (srv_poll_begin), so the QUIT is marked served there -- else that reader would leave the moment it starts
+        // and its slot would have nobody until the whole launch has drained.
+        if (asked)
+            for (int i = 0; i + lines_per_msg <= n_slots; i += lines_per_msg)
+                __atomic_store_n(resp(i), tags[(size_t)i] << 16, __ATOMIC_RELAXED);
     }
     // Poll the slot's answer line for the tag of the request just posted (the same hooks as the completion-word wait of a
     // launched step: the caller's idle work, another restart's fibre, sched_yield).

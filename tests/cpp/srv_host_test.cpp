@@ -91,6 +91,7 @@ struct Harness {
         h.idle_ticks = idle_us * 100;
         h.launch = [this](const SrvLink &L) -> hipError_t {
             if (fail_launch.load()) return hipErrorLaunchFailure;
+            (void)hipStreamSynchronize(h.stream); // a launch is only asked for once the previous one has drained: its thread has ended (or is ending)
             std::lock_guard<std::mutex> lk(h.stream->mu);
             h.stream->running.emplace_back(fake_kernel, L, readers, lpm, &mode);
             return hipSuccess;
@@ -101,13 +102,14 @@ struct Harness {
 static void request(Harness &H, ls_ctx *ctx, int reader, unsigned x, int expect_rc = LS_OK)
 {
     unsigned pay[64] = {0};
-    pay[0] = 1; pay[1] = x & 0xffffu; pay[2] = (x * 7u) & 0xffffu; pay[17 % (16 * H.lpm)] += 0; // (payload dwords of every line take part in the checksum)
+    pay[0] = 1; pay[1] = x & 0xffffu; pay[2] = (x * 7u) & 0xffffu; // (the payload dwords of every line take part in the checksum)
     if (H.lpm > 1) { pay[16] = x & 0xffu; pay[63] = (x >> 3) & 0xffffu; }
     CHECK(H.h.ensure_running(ctx) == LS_OK);
     if (H.lpm == 1) H.h.post(reader, pay);
     else H.h.post_lines(reader * H.lpm, pay, H.lpm);
     unsigned r[8];
     const int rc = H.h.wait(ctx, reader * H.lpm, r);
+    if (rc != expect_rc) fprintf(stderr, "request(reader %d, x %u): rc %d, expected %d (%s)\n", reader, x, rc, expect_rc, ctx->err.c_str());
     CHECK(rc == expect_rc);
     if (rc != LS_OK) return;
     unsigned sum = 0;
@@ -118,20 +120,21 @@ static void request(Harness &H, ls_ctx *ctx, int reader, unsigned x, int expect_
 
 int main()
 {
-    {   // 1. many slots on many threads, idle time-out far below the callers' pauses: dozens of relaunches, every answer right
+    {   // 1. many slots on many threads, the launch idles out between the phases and comes back: every answer right
         Harness H;
         H.start(6, 1, 200);
-        std::vector<std::thread> ts;
         std::vector<ls_ctx> ctxs(6);
-        for (int t = 0; t < 6; t++)
-            ts.emplace_back([&, t]() {
-                for (unsigned i = 0; i < 3000; i++) {
-                    request(H, &ctxs[(size_t)t], t, i * 13u + (unsigned)t);
-                    if (i % 500 == 499) std::this_thread::sleep_for(std::chrono::milliseconds(2)); // all six pause: the launch idles out
-                }
-            });
-        for (auto &t : ts) t.join();
-        CHECK(H.h.relaunches.load() >= 2);
+        for (int phase = 0; phase < 4; phase++) {
+            std::vector<std::thread> ts;
+            for (int t = 0; t < 6; t++)
+                ts.emplace_back([&, t]() {
+                    for (unsigned i = 0; i < 750; i++) request(H, &ctxs[(size_t)t], t, (unsigned)phase * 9973u + i * 13u + (unsigned)t);
+                });
+            for (auto &t : ts) t.join();
+            std::this_thread::sleep_for(std::chrono::milliseconds(5)); // nobody asks: the launch idles out, the next phase starts it again
+            CHECK(H.h.drained());
+        }
+        CHECK(H.h.relaunches.load() >= 4);
         CHECK(H.h.requests.load() == 6 * 3000);
         H.h.shutdown();
     }

@@ -42,3 +42,19 @@ def test_fibre_pool(tmp_path):
         for _ in range(3):
             r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
             assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (flags, r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("sanitizer", ["address,undefined", "thread"])
+def test_server_host_state_machine_under_sanitizers(tmp_path, sanitizer):
+    # csrc/srv_common.hpp (SrvHost: post / wait / relaunch / give-up / pause of the resident servers) against a fake HIP runtime
+    # and a fake device thread that answers, drains and goes silent (tests/cpp/srv_host_test.cpp): the 16-bit tag wrap, the
+    # no-answer error, SRV_RC_GIVE_UP, a failing launch, QUIT as a whole multi-line message
+    src = os.path.join(ROOT, "tests", "cpp", "srv_host_test.cpp")
+    exe = str(tmp_path / "srv_host_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", f"-fsanitize={sanitizer}", "-fno-omit-frame-pointer", "-Wno-tsan",
+                    "-I", os.path.join(ROOT, "tests", "cpp", "fake_hip"), src, "-o", exe, "-lpthread"],
+                   check=True, capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", TSAN_OPTIONS="halt_on_error=1")
+    for _ in range(2):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-2000:], r.stderr[-4000:])
