@@ -915,9 +915,9 @@ def multi_restart_sched_end_to_end(ctx, so_far):
         s.close()
         return r
 
-    def leg(name, args, params, bits, seeds, sample):
+    def leg(name, args, params, bits, seeds, sample, n_slots=None):
         try:
-            m = ls_amd.MultiSolver.scheduling(ctx, *args, seeds, params, holiday_bits=bits, n_slots=len(seeds))
+            m = ls_amd.MultiSolver.scheduling(ctx, *args, seeds, params, holiday_bits=bits, n_slots=n_slots)
             t0 = time.perf_counter()
             m.run(max_rounds_per_restart=250, max_seconds=120.0)
             dt = time.perf_counter() - t0
@@ -943,7 +943,7 @@ def multi_restart_sched_end_to_end(ctx, so_far):
     for e in range(E):
         for d in rng.choice(31, size=int(rng.integers(0, 4)), replace=False):
             bits[e] |= np.uint64(1) << np.uint64(d)
-    leg("config5_multi_restart_end_to_end", (31, 0, E), dict(sched, window_size=65_536), bits, [str(42 + r) for r in range(8)], (0, 5))
+    leg("config5_multi_restart_end_to_end", (31, 0, E), dict(sched, window_size=65_536), bits, [str(42 + r) for r in range(8)], (0, 5), n_slots=8)
     one = (so_far.get("config5_end_to_end_sched10k_window65536_seed42") or {}).get("seconds")
     if one and "seconds" in out["config5_multi_restart_end_to_end"]:
         out["config5_multi_restart_end_to_end"]["single_restart_seconds"] = one

@@ -81,6 +81,34 @@ static int bind(ls_ctx *ctx)
 {
     if (!ctx) return LS_ERR_INVALID;
     LS_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->stream) { // a light clone (ctx_clone_light): its stream is made when a launched route first needs one
+        LS_HIP(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+        ctx->stream = ctx->own_stream;
+    }
+    return LS_OK;
+}
+
+// A context for one slot of a launch shared with `base` (ls_multi_solver): same device, same kernel-family choices, the
+// scheduling instance BORROWED from base (which outlives it), no stream, no allocation -- the steady-state path of such a
+// slot makes no runtime call, so creating and destroying dozens of full contexts per run was most of a short run's wall time.
+int ctx_clone_light(const ls_ctx *base, ls_ctx **out)
+{
+    *out = nullptr;
+    ls_ctx *c = new (std::nothrow) ls_ctx();
+    if (!c) return set_err(base, LS_ERR_NOMEM, "out of host memory");
+    c->device = base->device;
+    c->nq_algo = base->nq_algo; c->nq_step_mode = base->nq_step_mode; c->nq_scan_variant = base->nq_scan_variant;
+    c->sched_delta = base->sched_delta; c->sched_server_on = base->sched_server_on;
+    c->n_cus = base->n_cus; c->wave_size = base->wave_size; c->clock_khz = base->clock_khz;
+    memcpy(c->dev_name, base->dev_name, sizeof c->dev_name);
+    if (base->sched.valid) {
+        c->sched.valid = true;
+        c->sched.n_days_scored = base->sched.n_days_scored; c->sched.n_days_stored = base->sched.n_days_stored;
+        c->sched.start_weekday = base->sched.start_weekday; c->sched.n_employees = base->sched.n_employees;
+        c->sched.holiday_bits.borrow(base->sched.holiday_bits);
+        c->sched.lane_tab.borrow(base->sched.lane_tab);
+    }
+    *out = c;
     return LS_OK;
 }
 
@@ -194,7 +222,10 @@ static int sched_ctx_grid(ls_ctx *ctx, bool gen, long long n_list, SchedGrid **o
 static int sched_resident_dev(ls_ctx *ctx)
 {
     if (ctx->sc_resident_dev_gen == ctx->sc_resident_gen) return LS_OK;
-    LS_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        const int rc0 = bind(ctx);
+        if (rc0 != LS_OK) return rc0;
+    }
     const size_t bytes = ctx->sc_resident_host.size() * sizeof(ls_sched_move);
     int rc = sync_and_collect(ctx); // the stream may still read the previous list
     if (rc != LS_OK) return rc;
@@ -287,7 +318,7 @@ int ls_ctx_destroy(ls_ctx *ctx)
     if (ctx->server && ctx->server_owned) nq_server_destroy(ctx->server); // the resident launches leave before anything is freed
     ctx->server = nullptr;
     sched_ctx_drop_servers(ctx, true);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for_each_buf(ctx, [](DevBuf &b) { b.release(); });
     ctx->stage_in.release();
     ctx->stage_out.release();

@@ -22,6 +22,7 @@ namespace lsamd {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool owned = true; // false: the block belongs to another DevBuf (borrow()) and is never freed or retired here
     // Buffers this one outgrew.  Launches already queued on the context's stream may still use them, so they
     // are not freed on the spot (hipFree would also stall the whole device until it drains): they are handed
     // back by collect(), which the API calls right after a stream synchronisation, and by release().
@@ -36,8 +37,8 @@ struct DevBuf {
         hipError_t e = hipMalloc(&q, want);
         if (e != hipSuccess && want > bytes) { want = bytes; e = hipMalloc(&q, want); }
         if (e != hipSuccess) return e;
-        if (p) retired.push_back(p);
-        p = q; cap = want;
+        if (p && owned) retired.push_back(p);
+        p = q; cap = want; owned = true;
         return hipSuccess;
     }
     void collect() // only when the stream that used the retired buffers has drained
@@ -48,9 +49,11 @@ struct DevBuf {
     void release()
     {
         collect();
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
+        if (p && owned) (void)hipFree(p);
+        p = nullptr; cap = 0; owned = true;
     }
+    // read-only view of a block another DevBuf owns (and keeps alive for as long as this view is used)
+    void borrow(const DevBuf &o) { release(); p = o.p; cap = o.cap; owned = false; }
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
@@ -247,6 +250,7 @@ void sched_grid_counters(const SchedGrid *s, unsigned long long out[3]);
 int sched_grid_score(ls_ctx *ctx, SchedGrid *s, int sub, const int32_t *state, int64_t *hard, int64_t *soft);
 int sched_grid_eval(ls_ctx *ctx, SchedGrid *s, int sub, const int32_t *state, long long n_moves, long long window, ls_sched_result *out);
 // ls_api.hip
+int ctx_clone_light(const ls_ctx *base, ls_ctx **out); // a context on the same device without a stream of its own yet (made on first use): what a slot of a shared resident launch needs
 int nq_ctx_server(ls_ctx *ctx, int n, NqServer **out, int slots = 1);
 int nq_server_post(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, const int32_t *cols, int32_t n_cols, long long window,
                    bool has_next_col_scores);

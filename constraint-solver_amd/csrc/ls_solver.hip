@@ -40,6 +40,22 @@ struct ls_multi_solver {
     int32_t sc_days_scored = 0, sc_start_weekday = 0, sc_employees = 0;
     std::vector<uint64_t> sc_holidays;
     std::vector<ScoredSolution<SchedProblem>> sc_best;
+    // the resident launch the slots share and the slots' contexts: made by the first run, kept for later runs (pinned memory, a
+    // stream on its own hardware queue), released by ls_multi_solver_free; the launch itself leaves at the end of every run
+    lsamd::SchedStepServer *sc_step = nullptr;
+    lsamd::SchedGrid *sc_grid = nullptr;
+    std::vector<ls_ctx *> sc_slot_ctx;
+    int sc_slots_made = 0;
+    void sc_release()
+    {
+        if (sc_step) lsamd::sched_step_destroy(sc_step);
+        if (sc_grid) lsamd::sched_grid_destroy(sc_grid);
+        sc_step = nullptr; sc_grid = nullptr;
+        for (ls_ctx *c : sc_slot_ctx) if (c) (void)ls_ctx_destroy(c); // after the launches have left (hipHostFree waits for resident kernels)
+        sc_slot_ctx.clear();
+        sc_slots_made = 0;
+    }
+    ~ls_multi_solver() { sc_release(); }
     std::vector<std::string> seeds;
     std::vector<ScoredSolution<NQueensProblem>> best;
     std::vector<int> have;
@@ -324,8 +340,11 @@ int ls_multi_solver_create_sched(ls_ctx *ctx, int32_t n_days_scored, int32_t sta
         }
         m->sc_best.resize((size_t)n_restarts);
         m->have.assign((size_t)n_restarts, 0);
+        // two restarts in flight per usable core: a scheduling LS iteration is ~1.5 us of host work around a ~4.5 us round trip, and
+        // more fibres per core than it takes to hide that only add switches and cache misses (measured on the example instance with
+        // 64 seeds: 16 / 32 / 64 / 128 slots on 16 cores -> 1.7 / 3.0 / 2.5 / 3.0-3.6 x 10^8 neighbours/s, the last with 256 seeds)
         const unsigned hw = usable_cores();
-        m->n_slots = (int)(4 * hw > 256 ? 256 : (4 * hw < 1 ? 1 : 4 * hw));
+        m->n_slots = (int)(2 * hw > 256 ? 256 : (2 * hw < 1 ? 1 : 2 * hw));
         *out = m.release();
         return LS_OK;
     });
@@ -338,7 +357,7 @@ int ls_multi_solver_configure(ls_multi_solver *m, int32_t n_slots, int32_t mode)
         return lsamd::set_err(m->ctx, LS_ERR_INVALID, "ls_multi_solver_configure: n_slots %d (0..256), mode %d", n_slots, mode);
     if (n_slots == 0) { // the mode's default: lockstep slots are host threads, free-running slots may share them
         const unsigned hw = usable_cores();
-        const unsigned want = mode == LS_MULTI_LOCKSTEP ? hw : 4 * hw;
+        const unsigned want = mode == LS_MULTI_LOCKSTEP ? hw : (m->kind == 1 ? 2 * hw : 4 * hw);
         n_slots = (int)(want > 256 ? 256 : (want < 1 ? 1 : want));
     }
     m->n_slots = n_slots;
@@ -386,10 +405,8 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
             try {
                 ls_ctx *ctx = m->ctx;
                 if (!lockstep && t > 0) { // free-running: one context (stream, staging block) per slot; slot 0 uses the caller's
-                    check_rc(nullptr, ls_ctx_create(m->ctx->device, &own), "ls_ctx_create");
+                    check_rc(m->ctx, lsamd::ctx_clone_light(m->ctx, &own), "context for a slot");
                     shared.owned[(size_t)t] = own;
-                    own->nq_algo = m->ctx->nq_algo;
-                    own->nq_step_mode = m->ctx->nq_step_mode;
                     ctx = own;
                 }
                 struct Attach { // this slot's workgroup of the shared server (slot 0: the caller's context lends itself for the run)
@@ -618,28 +635,34 @@ static int multi_run_sched(ls_multi_solver *m, uint64_t max_rounds_per_restart, 
     int T = m->n_slots < R ? m->n_slots : R;
     const ls_solver_params &p = m->params;
     ls_ctx *base = m->ctx;
-    struct Shared {
-        lsamd::SchedStepServer *step = nullptr;
-        lsamd::SchedGrid *grid = nullptr;
-        std::vector<ls_ctx *> owned; // per-slot contexts: destroyed after the shared launches have left (hipHostFree waits for resident kernels)
-        ~Shared()
-        {
-            if (step) lsamd::sched_step_destroy(step);
-            if (grid) lsamd::sched_grid_destroy(grid);
-            for (ls_ctx *c : owned) if (c) (void)ls_ctx_destroy(c);
-        }
-    } shared;
+    static const bool trace = getenv("LS_AMD_TRACE") != nullptr;
+    const auto T_begin = std::chrono::steady_clock::now();
+    struct Phase { // LS_AMD_TRACE: where a run's wall time goes besides the restarts themselves
+        std::chrono::steady_clock::time_point t0; bool on; double setup = 0, run = 0;
+        ~Phase() { if (on) fprintf(stderr, "multi-restart scheduling run: set-up %.2f ms, restarts %.2f ms, tear-down %.2f ms\n", setup * 1e3, run * 1e3,
+                                   (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - setup - run) * 1e3); }
+    } phase{T_begin, trace};
     const long long want = (long long)p.window_size + (long long)p.window_size / 4 + 16; // the list prefix an LS iteration asks for (SchedProblem::best_of_neighbourhood)
     const bool resident = base->sched_server_on && base->sched_delta && m->sc_employees <= 32768 && p.all_solution_iteration_expiry >= 1;
     if (resident && want <= 512) {
         const int cap = lsamd::sched_step_max_slots(base);
         if (T > cap) T = cap;
-        check_rc(base, lsamd::sched_step_create(base, T, &shared.step), "scheduling LS-step server");
     } else if (resident) {
         while (T > 1 && !lsamd::sched_grid_fits(base, T, false, want)) T--; // as many sub-grids as the device holds side by side
-        if (lsamd::sched_grid_fits(base, T, false, want)) check_rc(base, lsamd::sched_grid_create(base, T, false, want, &shared.grid), "scheduling grid");
     }
-    shared.owned.assign((size_t)T, nullptr);
+    if (m->sc_slots_made != T) { // (first run, or another slot count: the shared launch is sized by it)
+        m->sc_release();
+        if (resident && want <= 512) check_rc(base, lsamd::sched_step_create(base, T, &m->sc_step), "scheduling LS-step server");
+        else if (resident && lsamd::sched_grid_fits(base, T, false, want)) check_rc(base, lsamd::sched_grid_create(base, T, false, want, &m->sc_grid), "scheduling grid");
+        m->sc_slot_ctx.assign((size_t)T, nullptr);
+        for (int t = 1; t < T; t++) check_rc(base, lsamd::ctx_clone_light(base, &m->sc_slot_ctx[(size_t)t]), "context for a slot"); // (the instance is base's: create_sched uploaded it)
+        m->sc_slots_made = T;
+    }
+    struct Shared { lsamd::SchedStepServer *step; lsamd::SchedGrid *grid; } shared{m->sc_step, m->sc_grid};
+    struct LeaveAtEnd { // the resident launch leaves with the run (it would idle out by itself 2 ms later)
+        Shared &s;
+        ~LeaveAtEnd() { if (s.step) lsamd::sched_step_pause(s.step); if (s.grid) lsamd::sched_grid_pause(s.grid); }
+    } leave_at_end{shared};
     std::vector<std::string> errors((size_t)T);
     std::vector<uint64_t> ls_it((size_t)R, 0), scored((size_t)R, 0), rounds((size_t)R, 0), launches((size_t)T, 0);
     std::atomic<int> next_restart{0};
@@ -648,15 +671,7 @@ static int multi_run_sched(ls_multi_solver *m, uint64_t max_rounds_per_restart, 
     auto worker = [&](int t, bool as_fibre) {
         try {
             ls_ctx *ctx = base;
-            if (t > 0) { // one context per slot (the drivers are independent); slot 0 uses the caller's
-                ls_ctx *own = nullptr;
-                check_rc(nullptr, ls_ctx_create(base->device, &own), "ls_ctx_create");
-                shared.owned[(size_t)t] = own;
-                own->sched_delta = base->sched_delta; own->sched_server_on = base->sched_server_on;
-                check_rc(own, ls_sched_instance_upload(own, m->sc_days_scored, m->sc_days_scored + 1, m->sc_start_weekday, m->sc_employees,
-                                                       m->sc_holidays.data()), "ls_sched_instance_upload");
-                ctx = own;
-            }
+            if (t > 0) ctx = m->sc_slot_ctx[(size_t)t]; // one context per slot (the drivers are independent); slot 0 uses the caller's
             struct Attach { // this slot's workgroup / sub-grid of the shared launch (slot 0: the caller's context lends itself for the run)
                 ls_ctx *c; lsamd::SchedStepServer *s0; int slot0; bool owned0; lsamd::SchedGrid *g0; int sub0; bool gowned0; bool un0;
                 ~Attach() { c->sched_step = s0; c->sched_step_slot = slot0; c->sched_step_owned = owned0; c->sched_grid = g0; c->sched_grid_sub = sub0; c->sched_grid_owned = gowned0; c->sched_grid_unavailable = un0; }
@@ -705,6 +720,8 @@ static int multi_run_sched(ls_multi_solver *m, uint64_t max_rounds_per_restart, 
     const int hwc = (int)usable_cores();
     const int n_threads = (hwc >= 1 && T > hwc) ? hwc : T;
     m->fibre_steals = 0;
+    phase.setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - T_begin).count();
+    const auto T_run = std::chrono::steady_clock::now();
     if (n_threads == T) {
         std::vector<std::thread> threads;
         for (int th = 0; th < n_threads; th++) threads.emplace_back([&, th]() { worker(th, false); });
@@ -715,6 +732,7 @@ static int multi_run_sched(ls_multi_solver *m, uint64_t max_rounds_per_restart, 
         pool.run();
         m->fibre_steals = pool.steals();
     }
+    phase.run = std::chrono::duration<double>(std::chrono::steady_clock::now() - T_run).count();
     for (const std::string &e : errors)
         if (!e.empty()) throw std::runtime_error(e);
     m->restart_ls_iterations = ls_it; m->restart_scored = scored; m->restart_rounds = rounds;

@@ -837,14 +837,14 @@ __global__ __launch_bounds__(256 * TEAMS) void nq_table_teams_kernel(NqArgs a, i
 }
 
 
+// the whole block's work of nq_table_pairs_kernel (also the fall-back of nq_table_quads_kernel for boards its 8-bit counts cannot hold)
 template <int NT, int TL, bool WANT_SCORES>
-__global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts, int whole_max /* min(window / (n - 1), max_cols): divided on the host */)
+__device__ __forceinline__ void nq_pairs_block(const NqArgs &a, int parts, int whole_max, unsigned *s_t16, unsigned long long *s_best)
 {
-    extern __shared__ unsigned s_t16[]; // packed u16: R[n] | R1[n] | A[2n+2] | B[2n+2], then int4 records [NQ_REC_CAP]
+    // s_t16: packed u16: R[n] | R1[n] | A[2n+2] | B[2n+2], then int4 records [NQ_REC_CAP]
     constexpr int TEAMS = NT / TL;            // a team = TL lanes (one wavefront or four) walking one column
     constexpr int SH = TL == 64 ? 6 : 8;      // log2(TL)
     static_assert(TL == 64 || TL == 256, "team width");
-    __shared__ unsigned long long s_best[NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
     const int team = __builtin_amdgcn_readfirstlane(tid >> SH), tv = tid & (TL - 1);
     const int restart = blockIdx.x % a.n_restarts;
@@ -973,6 +973,224 @@ __global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts,
     if (lane == 0) s_best[wib] = best;
     __syncthreads();
     LS_STAMP(6);
+    if (tid == 0) {
+        unsigned long long b = s_best[0];
+        for (int i = 1; i < NT / 64; i++) b = u64min(b, s_best[i]);
+        if (b != NQ_KEY_EMPTY) atomicMin(&a.best_keys[restart], b);
+    }
+}
+
+template <int NT, int TL, bool WANT_SCORES>
+__global__ __launch_bounds__(NT) void nq_table_pairs_kernel(NqArgs a, int parts, int whole_max /* min(window / (n - 1), max_cols): divided on the host */)
+{
+    extern __shared__ unsigned s_t16[];
+    __shared__ unsigned long long s_best[NT / 64];
+    nq_pairs_block<NT, TL, WANT_SCORES>(a, parts, whole_max, s_t16, s_best);
+}
+
+// TABLE, FOUR candidates per lane and LDS look-up (n a multiple of 256, 512 <= n <= NQ_TABLE_LDS_MAX_N, no score dump): the pairs
+// kernel above is bound by the LDS array and by half-rate VALU work in equal parts (three 4-byte look-ups and ~8 instructions
+// per two candidates).  Here the counts are 8-BIT: a lane owns the quad (v .. v + 3), one ds_read_b32 per table returns all
+// four candidates' counts and ONE v_add3_u32 adds them as packed bytes (a count is at most NQ_QUAD_MAX = 50 here, so a sum
+// stays below 256 also beside the sentinel: no carry between the bytes).  The per-lane running minimum does not unpack them
+// either: two v_perm_b32 spread the four sums over two registers as 16-bit fields (sum << 8 | step) and two v_pk_min_u16 keep,
+// per byte position, the smallest (sum, first step) -- five instructions per FOUR candidates; positions are rebuilt once per
+// column.  The three quads are 4-byte aligned when v = c (mod 4) (then v - c + n is a multiple of 4), so the row table is kept
+// in four copies shifted by 0..3 entries and the B diagonal table in two (v + c = 2c mod 4 is 0 or 2): 10n bytes of LDS against
+// 12n for the u16 pairs.  Squares v >= n of a lane's last quad read a sentinel count that can never win; squares v < c mod 4
+// belong to no quad and are scored by the first lanes of the column's first part.
+// A board with more than NQ_QUAD_MAX queens on one row or diagonal does not fit 8-bit sums: every block finds that out while it
+// builds its tables (the old value of each increment) and takes nq_pairs_block instead -- block-uniform, same results.
+constexpr unsigned NQ_QUAD_MAX = 50;        // largest count the quads formulation accepts
+constexpr unsigned NQ_QUAD_SENTINEL = 151;  // > 3 NQ_QUAD_MAX (never the minimum), and sentinel + 2 NQ_QUAD_MAX < 256 (no carry)
+
+__device__ __forceinline__ unsigned tab8_inc(unsigned *t, int idx) // returns the byte's old value
+{
+    const unsigned old = atomicAdd(&t[idx >> 2], 1u << (8 * (idx & 3)));
+    return (old >> (8 * (idx & 3))) & 0xffu;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void nq_table_quads_kernel(NqArgs a, int parts, int whole_max)
+{
+    // bytes: R0[n] | R1[n] | R2[n] | R3[n] (Rs[i] = cntR[i + s]) | A[2n] | B0[2n] | B2[2n] (B2[i] = cntB[i + 2]), then int4 records
+    extern __shared__ unsigned s_t8[];
+    __shared__ unsigned long long s_best[NT / 64];
+    __shared__ int s_overflow;
+    constexpr int TEAMS = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    const int team = __builtin_amdgcn_readfirstlane(wib);
+    const int restart = blockIdx.x % a.n_restarts;
+    const int chunk = blockIdx.x / a.n_restarts;
+    const int n_chunks = gridDim.x / a.n_restarts;
+    const int n = a.n;
+    const int *__restrict__ rows = a.rows + (long long)restart * n;
+    const int *__restrict__ cols = a.cols + (long long)restart * a.max_cols;
+    int ncols = a.n_cols[restart];
+    ncols = ncols < 0 ? 0 : (ncols > a.max_cols ? a.max_cols : ncols);
+    const int n_whole = whole_max < ncols ? whole_max : ncols;
+    const long long rem = n_whole < ncols ? a.window - (long long)n_whole * (n - 1) : 0;
+    const unsigned units = (unsigned)n_whole * (unsigned)parts;
+    const long long u0 = units * (unsigned)chunk / (unsigned)n_chunks, u1 = units * (unsigned)(chunk + 1) / (unsigned)n_chunks;
+    const bool do_partial = rem > 0 && chunk == n_chunks - 1;
+    unsigned long long best = NQ_KEY_EMPTY;
+    if (!(u0 < u1 || do_partial)) return; // block-uniform: nothing to do (and nothing to contribute to the minimum)
+    const int oA = 4 * n, oB0 = 6 * n, oB2 = 8 * n; // byte offsets (all multiples of 4)
+    const int words = (10 * n) >> 2;
+    int4 *s_rec = reinterpret_cast<int4 *>(s_t8 + words);
+    const int slot_lo = (int)((unsigned)u0 / (unsigned)parts);
+    const int slot_hi = u0 < u1 ? (int)((unsigned)(u1 - 1) / (unsigned)parts) : slot_lo - 1; // inclusive
+    // every global read of the set-up is issued before the first LDS store: the board into registers, the first pass's columns
+    int pre_c = -1, pre_rc = -1;
+    if (tid < NQ_REC_CAP && slot_lo + tid <= slot_hi) {
+        pre_c = cols[slot_lo + tid];
+        pre_rc = (unsigned)pre_c < (unsigned)n ? rows[pre_c] : -1;
+    }
+    constexpr int QV = NQ_TABLE_LDS_MAX_N / NT;
+    int qv[QV];
+#pragma unroll
+    for (int kk = 0; kk < QV; kk++) {
+        const int j = tid + NT * kk;
+        qv[kk] = j < n ? rows[j] : -1;
+    }
+    for (int i = tid; i < words; i += NT) s_t8[i] = 0;
+    if (tid == 0) s_overflow = 0;
+    __syncthreads();
+    {
+        unsigned worst = 0;
+#pragma unroll
+        for (int kk = 0; kk < QV; kk++) {
+            const int j = tid + NT * kk, q = qv[kk];
+            if ((unsigned)q < (unsigned)n) {
+#pragma unroll
+                for (int sft = 0; sft < 4; sft++)
+                    if (q >= sft) { const unsigned o = tab8_inc(s_t8, sft * n + q - sft); worst = o > worst ? o : worst; }
+                unsigned o = tab8_inc(s_t8, oA + (q - j + n));
+                worst = o > worst ? o : worst;
+                o = tab8_inc(s_t8, oB0 + (q + j));
+                worst = o > worst ? o : worst;
+                if (q + j >= 2) tab8_inc(s_t8, oB2 + (q + j - 2));
+            }
+        }
+        if (worst >= NQ_QUAD_MAX) s_overflow = 1; // (old value >= MAX: the count reached MAX + 1)
+        // squares beyond the board, seen by the shifted row copies: Rs[i] for i + s >= n
+        if (tid < 6) {
+            const int sft = tid < 1 ? 1 : (tid < 3 ? 2 : 3), k = tid < 1 ? 0 : (tid < 3 ? tid - 1 : tid - 3);
+            const int idx = sft * n + (n - sft) + k;
+            atomicAdd(&s_t8[idx >> 2], NQ_QUAD_SENTINEL << (8 * (idx & 3)));
+        }
+    }
+    __syncthreads();
+    if (s_overflow) { // block-uniform: this board needs 16-bit counts
+        __syncthreads();
+        nq_pairs_block<NT, 64, false>(a, parts, whole_max, s_t8, s_best);
+        return;
+    }
+    const unsigned char *t8 = reinterpret_cast<const unsigned char *>(s_t8);
+    const int steps = n >> 8;                    // 64 quads = 256 values per step
+    const int per_part = (steps + parts - 1) / parts;
+    for (int pass_lo = slot_lo; pass_lo <= slot_hi; pass_lo += NQ_REC_CAP) {
+        const int pass_hi = pass_lo + NQ_REC_CAP - 1 < slot_hi ? pass_lo + NQ_REC_CAP - 1 : slot_hi;
+        __syncthreads(); // the previous pass's records are no longer read
+        for (int sl = pass_lo + tid; sl <= pass_hi; sl += NT) {
+            const bool pre = pass_lo == slot_lo;
+            const int c = pre ? pre_c : cols[sl];
+            const int rc = pre ? pre_rc : ((unsigned)c < (unsigned)n ? rows[c] : -1);
+            int conf_old = 0;
+            if ((unsigned)rc < (unsigned)n) conf_old = (int)t8[rc] + (int)t8[oA + rc - c + n] + (int)t8[oB0 + rc + c] - 3;
+            s_rec[sl - pass_lo] = make_int4(c, (unsigned)rc < (unsigned)n ? rc : -1, conf_old, 0);
+        }
+        __syncthreads();
+        long long ua = (long long)pass_lo * parts, ub = (long long)(pass_hi + 1) * parts;
+        ua = ua < u0 ? u0 : ua;
+        ub = ub > u1 ? u1 : ub;
+        const unsigned first = (unsigned)(ua + team);
+        int slot = (int)(first / (unsigned)parts), part = (int)(first - (unsigned)slot * (unsigned)parts);
+        const int dq = TEAMS / parts, dr = TEAMS - dq * parts;
+        for (long long u = ua + team; u < ub; u += TEAMS, slot += dq, part += dr) { // wavefront-uniform
+            if (part >= parts) { part -= parts; slot++; }
+            const int4 rec = s_rec[slot - pass_lo];
+            const int c = __builtin_amdgcn_readfirstlane(rec.x), rc = __builtin_amdgcn_readfirstlane(rec.y),
+                      conf_old = __builtin_amdgcn_readfirstlane(rec.z);
+            if (rc < 0) continue; // unvalidated device-pointer input: the slot is skipped (nq_slot_scored)
+            const int sft = c & 3, bsh = (2 * c) & 3; // v = sft (mod 4); B copy shifted by bsh (0 or 2)
+            const int i0 = part * per_part;
+            int i1 = i0 + per_part;
+            i1 = i1 > steps ? steps : i1;
+            // dword pointers: lane `lane` owns the quad starting at v = sft + 4 lane (+ 256 i)
+            const unsigned *pR = s_t8 + ((sft * n) >> 2) + lane;                                   // R[v ..] = Rs[v - sft ..]
+            const unsigned *pA = s_t8 + ((oA + sft - c + n) >> 2) + lane;                          // A[v - c + n ..]
+            const unsigned *pB = s_t8 + (((bsh ? oB2 : oB0) + sft + c - bsh) >> 2) + lane;         // B[v + c ..]
+            us2 me = as_us2(0xffffffffu), mo = as_us2(0xffffffffu); // per byte position: the smallest (sum << 8 | step)
+            int i = i0;
+#define LS_QUAD(J)                                                                                                 \
+    {                                                                                                              \
+        const unsigned sum = pR[(i + J) << 6] + pA[(i + J) << 6] + pB[(i + J) << 6];                               \
+        me = pk_min_u16_raw(me, as_us2(__builtin_amdgcn_perm(sum, (unsigned)(i + J), 0x06000400u)));               \
+        mo = pk_min_u16_raw(mo, as_us2(__builtin_amdgcn_perm(sum, (unsigned)(i + J), 0x07000500u)));               \
+    }
+            for (; i + 4 <= i1; i += 4) { LS_QUAD(0) LS_QUAD(1) LS_QUAD(2) LS_QUAD(3) }
+            for (; i < i1; i++) LS_QUAD(0)
+#undef LS_QUAD
+            // the lane's minimum (count, v): per byte position p the field is (sum << 8 | first step with that sum); v = sft + 4 lane + 256 step + p
+            const unsigned f0 = as_u32(me) & 0xffffu, f2 = as_u32(me) >> 16, f1 = as_u32(mo) & 0xffffu, f3 = as_u32(mo) >> 16;
+            const int vb = sft + 4 * lane;
+            auto key_of = [&](unsigned f, int p) { return ((f >> 8) << 15) | (unsigned)(vb + (int)((f & 0xffu) << 8) + p); };
+            unsigned m = NQ_KEY32_EMPTY;
+            if (i0 < i1) {
+                const unsigned k0 = key_of(f0, 0), k1 = key_of(f1, 1), k2 = key_of(f2, 2), k3 = key_of(f3, 3);
+                const unsigned m01 = k0 < k1 ? k0 : k1, m23 = k2 < k3 ? k2 : k3;
+                m = m01 < m23 ? m01 : m23;
+            }
+            const unsigned noop = ((unsigned)(conf_old + 3) << 15) | (unsigned)rc;
+            if (m == noop) { // this lane's minimum is the tabu square itself: walk again without it
+                m = NQ_KEY32_EMPTY;
+                for (int i2 = i0; i2 < i1; i2++) {
+                    const unsigned sum = pR[i2 << 6] + pA[i2 << 6] + pB[i2 << 6];
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const int v = vb + (i2 << 8) + p;
+                        const unsigned k = (((sum >> (8 * p)) & 0xffu) << 15) | (unsigned)v;
+                        if (v != rc) m = k < m ? k : m;
+                    }
+                }
+            }
+            // squares v < sft belong to no quad: the first lanes of the column's first part score them (v = lane)
+            if (i0 == 0 && lane < sft && lane != rc) {
+                const unsigned k = (((unsigned)t8[lane] + (unsigned)t8[oA + lane - c + n] + (unsigned)t8[oB0 + lane + c]) << 15) | (unsigned)lane;
+                m = k < m ? k : m;
+            }
+            if (m != NQ_KEY32_EMPTY && (m & 0x7fffu) < (unsigned)n) { // (a lane whose only squares lie beyond the board holds a sentinel sum)
+                const int v = (int)(m & 0x7fffu);
+                best = u64min(best, nq_key((int)(m >> 15) - conf_old, nq_key_hi(v > rc ? 1 : 0, c, n, slot), v));
+            }
+        }
+    }
+    if (do_partial) { // the slot the window cuts: per-range loops, all lanes of the block
+        const int slot = (int)n_whole;
+        const int c = cols[slot];
+        const int rc = (unsigned)c < (unsigned)n ? rows[c] : -1;
+        if ((unsigned)rc < (unsigned)n) {
+            const NqRanges rg = nq_ranges(0, n, rc, (long long)slot * (n - 1), a.window);
+            const int conf_old = (int)t8[rc] + (int)t8[oA + rc - c + n] + (int)t8[oB0 + rc + c] - 3;
+            unsigned m = NQ_KEY32_EMPTY;
+            for (int v = rg.d0 + tid; v < rg.d1; v += NT) {
+                const unsigned k = (((unsigned)t8[v] + (unsigned)t8[oA + v - c + n] + (unsigned)t8[oB0 + v + c]) << 15) | (unsigned)v;
+                m = k < m ? k : m;
+            }
+            for (int v = rg.u0 + tid; v < rg.u1; v += NT) {
+                const unsigned k = (((unsigned)t8[v] + (unsigned)t8[oA + v - c + n] + (unsigned)t8[oB0 + v + c]) << 15) | (unsigned)v;
+                m = k < m ? k : m;
+            }
+            if (m != NQ_KEY32_EMPTY) {
+                const int v = (int)(m & 0x7fffu);
+                best = u64min(best, nq_key((int)(m >> 15) - conf_old, nq_key_hi(v > rc ? 1 : 0, c, n, slot), v));
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) s_best[wib] = best;
+    __syncthreads();
     if (tid == 0) {
         unsigned long long b = s_best[0];
         for (int i = 1; i < NT / 64; i++) b = u64min(b, s_best[i]);
@@ -1665,10 +1883,52 @@ static int launch_table_teams_t(ls_ctx *ctx, const NqArgs &a, long long window)
     return LS_OK;
 }
 
-// even 512 <= n: two candidates per lane and look-up, one wavefront per column (nq_table_pairs_kernel); else one candidate per
-// lane, 256-lane teams (nq_table_teams_kernel)
+// four candidates per lane and look-up, 8-bit counts (nq_table_quads_kernel): n a multiple of 256, no score dump
+static int launch_table_quads(ls_ctx *ctx, const NqArgs &a, long long window)
+{
+    constexpr int NT = 1024, TEAMS = NT / 64;
+    const int n = a.n;
+    auto lds_for = [](int nn) { // the larger of the two layouts: a block may fall back to the u16 pairs (nq_pairs_block)
+        const size_t pairs_words = (((size_t)(6 * nn + 4) >> 1) + 3) & ~(size_t)3;
+        return (pairs_words + 4 * (size_t)NQ_REC_CAP) * 4;
+    };
+    const size_t lds = lds_for(n);
+    const void *k = reinterpret_cast<const void *>(&nq_table_quads_kernel<NT>);
+    static std::atomic<bool> attr_done_dev[64];
+    if (!attr_done_dev[ctx->device & 63].load(std::memory_order_acquire)) {
+        LS_HIP(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_for(NQ_TABLE_LDS_MAX_N)));
+        attr_done_dev[ctx->device & 63].store(true, std::memory_order_release);
+    }
+    long long per_cu = (160 * 1024) / (long long)(lds + 512);
+    per_cu = per_cu > 2 ? 2 : (per_cu < 1 ? 1 : per_cu); // wave slots: 32 per CU
+    long long bpr = ((long long)ctx->n_cus * per_cu) / a.n_restarts;
+    if (bpr < 1) bpr = 1;
+    long long n_whole = window / (n - 1);
+    if (n_whole > a.max_cols) n_whole = a.max_cols;
+    const int steps = n >> 8;
+    long long parts = 1;
+    if (n_whole > 0 && n_whole < bpr * TEAMS) {
+        parts = (bpr * TEAMS) / n_whole;
+        const long long max_parts = steps >= 4 ? steps / 4 : 1;
+        parts = parts > max_parts ? max_parts : parts;
+        parts = parts < 1 ? 1 : parts;
+    }
+    long long want_blocks = (n_whole * parts + TEAMS - 1) / TEAMS;
+    if (want_blocks < 1) want_blocks = 1;
+    if (bpr > want_blocks) bpr = want_blocks;
+    while (bpr > 1 && n_whole * parts * bpr >= (1ll << 32)) bpr /= 2;
+    if (n_whole * parts >= (1ll << 32)) return set_err(ctx, LS_ERR_UNSUPPORTED, "max_cols = %d is too large for the count-table kernels", a.max_cols);
+    int parts_i = (int)parts, whole_max = (int)n_whole;
+    void *args[] = {const_cast<NqArgs *>(&a), &parts_i, &whole_max};
+    LS_HIP(ctx, hipLaunchKernel(k, dim3((unsigned)(bpr * a.n_restarts)), dim3(NT), args, lds, ctx->stream));
+    return LS_OK;
+}
+
+// n a multiple of 256 and no score dump: four candidates per lane and look-up (nq_table_quads_kernel); other even n >= 512: two
+// (nq_table_pairs_kernel), one wavefront per column either way; else one candidate per lane, 256-lane teams (nq_table_teams_kernel)
 static int launch_table_teams(ls_ctx *ctx, const NqArgs &a, long long window)
 {
+    if ((a.n & 255) == 0 && a.n >= 512 && !a.scores_out) return launch_table_quads(ctx, a, window);
     if ((a.n & 1) == 0 && a.n >= 512) return launch_table_teams_t<1024, 64, true>(ctx, a, window);
     return launch_table_teams_t<1024, 256, false>(ctx, a, window);
 }

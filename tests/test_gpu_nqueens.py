@@ -594,3 +594,31 @@ def test_general_tabu_set_exclusion_list(ctx, n, n_cols):
         ctx.nqueens_eval_tabu([1, 3, 0, 2], 0, [0], 10, [1])            # (col 0, value 1) is the no-op
     with pytest.raises(ls_amd.LsError):
         ctx.nqueens_eval_tabu([1, 3, 0, 2], 0, [0], 10, [2, 0])         # not ascending
+
+
+@pytest.mark.parametrize("n", [512, 1024, 4096, 12288])
+def test_table_quads_kernel_and_its_u16_fallback(ctx, n):
+    # TABLE without a score dump at n = 0 (mod 256): four candidates per lane and look-up on 8-BIT counts (nq_table_quads_kernel).
+    # Boards whose rows / diagonals hold at most 50 queens stay on it -- incl. exactly 50 on one row, every column residue mod 4
+    # (shifted table copies), windows that cut a column, duplicated columns, a queen on the board's last rows (sentinel squares) --;
+    # 51 on a row, a constant board and a full diagonal trip the per-block fallback to the 16-bit pairs.  Ragged batches mix both.
+    rng = np.random.default_rng(n)
+    def with_row(k):
+        b = rng.integers(0, n, size=n)
+        b[b == 7] = 8
+        b[rng.permutation(n)[:k]] = 7          # exactly k queens on row 7
+        return b
+    boards = [rng.integers(0, n, size=n), rng.permutation(n), with_row(50), with_row(51), np.zeros(n, dtype=np.int64),
+              np.arange(n), np.full(n, n - 1), (np.arange(n) * 5 + 3) % n]
+    R = len(boards)
+    rows = np.stack(boards)
+    mc = 9
+    cols = np.stack([np.concatenate([[0, 1, 2, 3], rng.permutation(n)[:mc - 4]]) for _ in range(R)])
+    cols[1, 5] = cols[1, 4]                    # a duplicated column: the earlier slot wins
+    cols[0, 4:8] = [n - 4, n - 3, n - 2, n - 1]
+    for window in (10 ** 12, 4 * (n - 1) + n // 2, 3, (n - 1) * mc - 1):
+        _check_batch_noscores(ctx, "table", rows, cols, np.array([mc, mc, mc, mc, mc, 5, 1, 0]), window)
+    # the full neighbourhood of one board per launch (many blocks per restart, parts > 1)
+    if n <= 4096:
+        full = np.tile(np.arange(n), (2, 1))
+        _check_batch_noscores(ctx, "table", rows[[0, 3]], full, np.full(2, n), n * (n - 1))
