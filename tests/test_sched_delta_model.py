@@ -1,4 +1,4 @@
-"""The arithmetic of the scheduling DELTA scorer (sched_kernels.hip, sched_eval_delta_kernel), restated with Python
+"""The arithmetic of the scheduling DELTA scorer (sched_device.hpp: sched_delta_score), restated with Python
 integers and checked against the CPU oracle's full rescoring (examples/employee-scheduling/src/lib.rs:261-375):
 
   * every term of the score is a function of the per-employee day sets, and a ChangeDay / SwapDays candidate

@@ -7,7 +7,7 @@ import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "tools", "_build", "libls_amd_stamps.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
-    src = [os.path.join(ROOT, "constraint-solver_amd", "csrc", f) for f in ("ls_api.hip", "nq_kernels.hip", "nq_server.hip", "sched_kernels.hip", "ls_solver.hip")]
+    src = [os.path.join(ROOT, "constraint-solver_amd", "csrc", f) for f in ("ls_api.hip", "nq_kernels.hip", "nq_server.hip", "sched_wave.hip", "sched_delta.hip", "sched_server.hip", "sched_grid.hip", "ls_solver.hip")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLS_NQ_STAMPS",
                            "-Wno-unused-function", "-o", SO] + src)
     print(SO); sys.exit(0)
