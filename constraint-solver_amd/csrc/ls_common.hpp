@@ -311,27 +311,32 @@ __device__ __forceinline__ int wave_sum_i32(int x)
     return __builtin_amdgcn_readlane(x, 63);
 }
 
-// Minimum over the 64 lanes of a wavefront, returned wave-uniform: the same six DPP steps as wave_sum_i32 (no LDS
-// round trips: a __shfl_xor butterfly costs twelve dependent ds_bpermute operations).
+// Minimum over the 64 lanes of a wavefront, returned wave-uniform: the same six DPP steps as wave_sum_i32 (no LDS round trips:
+// a __shfl_xor butterfly costs twelve dependent ds_bpermute operations); each step is one v_min_u32 with a DPP operand.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x)
+{
+    // written out: hipcc expands the builtin form into v_mov + s_nop + v_mov_dpp + v_min per step.  (s_nop 1: a DPP operand may
+    // not be read for two wait states after a VALU wrote it, and nothing inserts them inside an asm statement.)  Lanes a step
+    // does not address (row_mask, a broadcast's missing source) keep their value.
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 0"
+                 : "+v"(x));
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// 64-bit minimum as two 32-bit ones: the high words, then the low words of the lanes that hold the smallest high word
+// (twelve single-instruction steps instead of six steps of two DPP moves + a 64-bit compare + two selects)
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x)
 {
-#define LS_MIN_STEP(CTRL, ROWMASK)                                                                                   \
-    {                                                                                                                \
-        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)x, (int)(unsigned)x, CTRL, ROWMASK, 0xf, false);          \
-        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(x >> 32), (int)(unsigned)(x >> 32), CTRL, ROWMASK, 0xf, false); \
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;                                            \
-        x = o < x ? o : x;                                                                                           \
-    }
-    LS_MIN_STEP(LS_DPP_QUAD_1032, 0xf)
-    LS_MIN_STEP(LS_DPP_QUAD_2301, 0xf)
-    LS_MIN_STEP(LS_DPP_ROW_HALF_MIRROR, 0xf)
-    LS_MIN_STEP(LS_DPP_ROW_MIRROR, 0xf)
-    LS_MIN_STEP(LS_DPP_ROW_BCAST15, 0xa)
-    LS_MIN_STEP(LS_DPP_ROW_BCAST31, 0xc)
-#undef LS_MIN_STEP
-    const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 63);
-    const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
-    return ((unsigned long long)rhi << 32) | rlo;
+    const unsigned hi = (unsigned)(x >> 32);
+    const unsigned mh = wave_min_u32(hi);
+    const unsigned ml = wave_min_u32(hi == mh ? (unsigned)x : 0xffffffffu);
+    return ((unsigned long long)mh << 32) | ml;
 }
 
 #endif // __HIPCC__

@@ -324,6 +324,18 @@ __device__ __forceinline__ unsigned wave_prefix_or_u32(unsigned x)
     return x;
 }
 
+// inclusive prefix sum over the lanes of the wavefront (six DPP adds; a __shfl_up scan costs six dependent LDS-crossbar round trips)
+__device__ __forceinline__ int wave_prefix_sum_i32(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_ROW_SHR(1), 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_ROW_SHR(2), 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_ROW_SHR(4), 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_ROW_SHR(8), 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_ROW_BCAST15, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, LS_DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return x;
+}
+
 // every lane contributes one value as a one-hot word (or 0): which values are contributed by >= 1, >= 2, >= 3 lanes.
 // A lane's value is a repeat if an earlier lane has it (exclusive prefix OR), a second repeat if an earlier lane was
 // already a repeat of it -- no atomics, no serialisation on popular values.

@@ -38,7 +38,6 @@ constexpr int SCG_MAXC = 8;      // chunks per workgroup, at most
 struct SchedGridCtl {            // device memory
     unsigned long long ready;    // workgroups that have started, over all launches of this server
     unsigned long long pad[7];
-    unsigned go[1][64];          // [n_sub][64] the current request of every sub-grid, as the host wrote it (tagged dwords)
 };
 
 struct SchedGridArgs {
@@ -48,6 +47,8 @@ struct SchedGridArgs {
     long long stream_cap;        // = G * cpw * 512
     long long gen_total;         // exhaustive grid: S x E candidates
     SchedGridCtl *g;
+    unsigned *go;                // [n_sub][64] the current request of every sub-grid, as the host wrote it (tagged dwords): device memory
+                                 // the masters copy it to -- or, DIRECT (go == link.req), fine-grained device memory the host itself writes
     unsigned long long ready_target; // g->ready once every workgroup of THIS launch has started (the host adds the grid size per launch)
     unsigned *rec;               // [n_sub][G][4] every workgroup's record of its sub-grid's current request (tagged dwords)
     int G;                       // workgroups per sub-grid
@@ -69,12 +70,13 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
     const int S = a.in.S, D = a.in.D, E = a.in.n_employees;
     const unsigned *req = a.link.req + (size_t)sub * 64;
     unsigned *resp = a.link.resp + (size_t)sub * 64;
-    unsigned *go = a.g->go[sub];
+    unsigned *go = a.go + (size_t)sub * 64;
+    const bool direct = a.go == a.link.req; // the host writes the go records itself (through the PCIe BAR): no relay by the master
     unsigned *rec = a.rec + (size_t)sub * G * 4;
     const ls_sched_move *stream = GEN ? nullptr : a.streams + (size_t)sub * a.stream_cap;
     __shared__ SchedBaseTab<M> T;
-    __shared__ u64 s_minkey;
-    __shared__ unsigned s_minidx;
+    __shared__ u64 s_wkey[NW];      // per wavefront: its minimum key and that key's first position
+    __shared__ unsigned s_wrel[NW];
     __shared__ int s_cnt[NW];
     __shared__ int s_cntc[MAXC][NW]; // real candidates per chunk and wavefront
     __shared__ int s_quit;           // the finisher: the launch is leaving, the records will not come
@@ -107,8 +109,15 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
 #else
 #define SCG_STAMP(I) do { } while (0)
 #endif
+#if defined(LS_NQ_STAMPS) && defined(SCG_FINE) // experiment: stamps 1, 2 and 5 moved into the record phase
+#define SCG_FSTAMP(I) do { gst[I] = wall_clock64(); } while (0)
+#else
+#define SCG_FSTAMP(I) do { } while (0)
+#endif
     if (wib == 0) {
-        last_seq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&go[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16);
+        // the last request this sub-grid ANSWERED (the answer line's tag, as srv_poll_begin reads it): a request that is still in the go
+        // record from before this launch is served if, and only if, it has not been answered
+        last_seq = __builtin_amdgcn_readfirstlane(srv_sys_load(resp) >> 16);
         if (c == 0) srv_poll_begin(poll, a.link, resp, lane);
         if (lane == 0) __hip_atomic_fetch_add(&a.g->ready, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c == 0) { // a master serves only once every workgroup of THIS launch polls its go record
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                         break;
                     }
                     if (!(s_req[0] & SCG_F_SCORE)) { // wave-uniform (LDS written by this wavefront, in order)
-                        __hip_atomic_store(&go[lane], raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!direct) __hip_atomic_store(&go[lane], raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
                     // get_scored_solution of the message's state, by the wavefront-per-state scorer (sched_wave.hip's sched_score_kernel)
@@ -159,10 +168,15 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                     const unsigned v = __hip_atomic_load(&go[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned t0 = __builtin_amdgcn_readfirstlane(v >> 16);
                     if (t0 != last_seq && t0 != 0 && __builtin_amdgcn_ballot_w64((v >> 16) != t0) == 0) {
-                        s_req[lane] = v & 0xffffu;
                         last_seq = t0;
-                        SCG_STAMP(0);
-                        break;
+                        const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffu));
+                        if (flags & SRV_F_QUIT) { leave = 1; break; }   // (DIRECT only: the host's messages arrive here unfiltered)
+                        if (flags & SCG_F_EVAL) {
+                            s_req[lane] = v & 0xffffu;
+                            SCG_STAMP(0);
+                            break;
+                        }
+                        continue; // a score request: the master's alone
                     }
                     unsigned long long q = 0;
                     if (lane == 0) q = __hip_atomic_load(&a.link.ctl->quit_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -211,13 +225,15 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
             ed[j] = sched_edit_of(e_lane, S, E, ty, xa, xb);
             hbits[j] = sched_edit_hbits(in, ed[j]);
         }
-#ifdef LS_NQ_STAMPS
+#if defined(LS_NQ_STAMPS) && !defined(SCG_FINE)
         { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); gst[1] = wall_clock64(); }
 #endif
-        if (tid == 0) { s_minkey = SC_KEY_EMPTY; s_minidx = 0xffffffffu; s_cut = -1; s_before = 0; }
+        if (tid == 0) { s_cut = -1; s_before = 0; }
         if (wib < 3) sched_build_base_tab<M>(in, wib, e_lane, hol_base, L, lane, T, emp);
         __syncthreads();
+#ifndef SCG_FINE
         SCG_STAMP(2);
+#endif
         u64 best_key = SC_KEY_EMPTY;
         int best_rel = 0; // position of the lane's best candidate, relative to the workgroup's first
         u64 my_key[MAXC], my_bal[MAXC]; // this lane's own candidates: what the finisher needs if the window cuts ITS chunks
@@ -233,31 +249,32 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
             if (lane == 0) s_cntc[j][wib] = __popcll(my_bal[j]);
         }
         SCG_STAMP(3);
-        // the workgroup's minimum (key, first position): one LDS atomic per wavefront and value (no serial walk, no second reduction)
+        // the workgroup's minimum (key, first position): every wavefront's pair through LDS, ONE barrier, then every wavefront
+        // reduces the NW pairs itself (no second barrier, no serial walk)
         {
             const u64 wk = wave_min_u64(best_key);
-            if (lane == 0 && wk != SC_KEY_EMPTY) __hip_atomic_fetch_min(&s_minkey, wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u64 wr = wave_min_u64(best_key == wk && wk != SC_KEY_EMPTY ? (u64)(unsigned)best_rel : ~0ull);
+            if (lane == 0) { s_wkey[wib] = wk; s_wrel[wib] = (unsigned)wr; }
         }
-        __syncthreads(); // the key minimum and the per-chunk counts are in LDS
-        const u64 wg_key = s_minkey;
+        SCG_FSTAMP(1);
+        __syncthreads(); // the wavefronts' minima and the per-chunk counts are in LDS
+        SCG_FSTAMP(2);
+        u64 wg_key;
+        unsigned wg_rel;
         {
-            const u64 wr = wave_min_u64(best_key == wg_key && wg_key != SC_KEY_EMPTY ? (u64)(unsigned)best_rel : ~0ull);
-            if (lane == 0 && wr != ~0ull) __hip_atomic_fetch_min(&s_minidx, (unsigned)wr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u64 k8 = lane < NW ? s_wkey[lane] : SC_KEY_EMPTY;
+            wg_key = wave_min_u64(k8);
+            wg_rel = (unsigned)wave_min_u64(lane < NW && k8 == wg_key ? (u64)s_wrel[lane] : ~0ull);
         }
-        int my_rank[MAXC], total = 0; // 1-based among the workgroup's real candidates, in candidate order (chunk, wavefront, lane)
+        int total = 0;
 #pragma unroll
-        for (int j = 0; j < MAXC; j++) {
-            my_rank[j] = total + __popcll(my_bal[j] & ((2ull << lane) - 1));
-            for (int i = 0; i < NW; i++) {
-                if (i < wib) my_rank[j] += s_cntc[j][i];
-                total += s_cntc[j][i];
-            }
-        }
-        __syncthreads(); // the position of the minimum is in LDS
+        for (int j = 0; j < MAXC; j++)
+            for (int i = 0; i < NW; i++) total += s_cntc[j][i];
+        SCG_FSTAMP(5);
         // ---- this workgroup's record: four tagged dwords (count | key in 24 + 24 + 16 bits | position in 8 + 4 bits), ONE store by
         // four lanes, no acknowledgement wait and no ticket: the request's finisher polls the records until all carry the tag
         if (wib == 0) {
-            const unsigned rel = s_minidx & 0xfffu; // < 512 MAXC = 4096
+            const unsigned rel = wg_rel & 0xfffu; // < 512 MAXC = 4096
             unsigned pay = 0;
             if (lane == 0) pay = (unsigned)total | ((rel >> 8) << 13); // total <= 4096
             else if (lane == 1) pay = (unsigned)wg_key & 0xffffffu;
@@ -267,6 +284,18 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         }
         SCG_STAMP(4);
         if (c == fin) { // ---- the finish step: prefix over the counts, minima of the workgroups inside the window, the cut workgroup up to the window
+            int my_rank[MAXC]; // 1-based among the workgroup's real candidates, in candidate order (chunk, wavefront, lane): for a cut through THIS workgroup
+            {
+                int run0 = 0;
+#pragma unroll
+                for (int j = 0; j < MAXC; j++) {
+                    my_rank[j] = run0 + __popcll(my_bal[j] & ((2ull << lane) - 1));
+                    for (int i = 0; i < NW; i++) {
+                        if (i < wib) my_rank[j] += s_cntc[j][i];
+                        run0 += s_cntc[j][i];
+                    }
+                }
+            }
             // the records of THIS request: one 16-byte read per lane and pass (two 8-byte loads that go to the coherence point,
             // past the L2), by as many wavefronts as there are 64 records; no barrier inside the poll
             const int npw = (G + 63) >> 6;
@@ -296,16 +325,13 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                     crel = (int)(((d0 >> 13) << 8) | (d3 >> 16));
                     ckey = (u64)d1 | ((u64)d2 << 24) | ((u64)(d3 & 0xffffu) << 48);
                 }
-                incl = cb;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int o = __shfl_up(incl, off, 64);
-                    if (lane >= off) incl += o;
-                }
+                incl = wave_prefix_sum_i32(cb);
                 if (lane == 63) s_cnt[wib] = incl;
             }
             __syncthreads(); // the wavefront totals of the counts (and s_quit) are in LDS
+#ifndef SCG_FINE
             SCG_STAMP(5);
+#endif
             if (s_quit) continue; // block-uniform; no answer: the host's wait finds the launch drained
             int run = 0;
             u64 fkey = SC_KEY_EMPTY; // this lane's candidate for the answer (key, position in the list)
@@ -358,24 +384,19 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                     }
                 }
             }
-            // the minimum (key, first position) over the lanes' candidates: the same two LDS atomics
-            if (tid == 0) { s_minkey = SC_KEY_EMPTY; s_minidx = 0xffffffffu; }
-            __syncthreads();
+            // the minimum (key, first position) over the lanes' candidates: the wavefronts' pairs through LDS, one barrier
             {
                 const u64 wk = wave_min_u64(fkey);
-                if (lane == 0 && wk != SC_KEY_EMPTY) __hip_atomic_fetch_min(&s_minkey, wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            __syncthreads();
-            const u64 akey = s_minkey;
-            {
-                const u64 wr = wave_min_u64(fkey == akey && akey != SC_KEY_EMPTY ? (u64)(unsigned)fidx : ~0ull);
-                if (lane == 0 && wr != ~0ull) __hip_atomic_fetch_min(&s_minidx, (unsigned)wr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const u64 wr = wave_min_u64(fkey == wk && wk != SC_KEY_EMPTY ? (u64)(unsigned)fidx : ~0ull);
+                if (lane == 0) { s_wkey[wib] = wk; s_wrel[wib] = (unsigned)wr; }
             }
             __syncthreads();
             SCG_STAMP(6);
             if (wib == 0) { // the answer: d0 has-move, d1-2 n_scored, d3-4 best_index, d5 hard, d6 soft, d7 the cut workgroup + 1 (0: none)
+                const u64 k8 = lane < NW ? s_wkey[lane] : SC_KEY_EMPTY;
+                const u64 akey = wave_min_u64(k8);
+                const unsigned aidx = (unsigned)wave_min_u64(lane < NW && k8 == akey ? (u64)s_wrel[lane] : ~0ull);
                 const bool has = akey != SC_KEY_EMPTY;
-                const unsigned aidx = s_minidx;
                 unsigned pay = 0;
                 if (lane == 0) pay = has ? 1u : 0u;
                 else if (lane == 1) pay = has ? (unsigned)n_scored & 0xffffu : 0u;
@@ -408,6 +429,8 @@ struct SchedGrid {
     int n_sub = 0, G = 0, cpw = 0, maxc = 0;
     long long stream_cap = 0;    // moves per sub-grid = G * cpw * 512
     SchedGridCtl *g = nullptr;
+    unsigned *go = nullptr;      // [n_sub][64]: fine-grained device memory the host writes through the BAR (go_direct), else plain device memory
+    bool go_direct = false;
     DevBuf rec;
     unsigned long long ready_total = 0;
     struct Sub {
@@ -484,6 +507,7 @@ void sched_grid_destroy(SchedGrid *s)
     }
     s->h.shutdown();
     if (s->g) (void)hipFree(s->g);
+    if (s->go) (void)hipFree(s->go);
     s->rec.release();
     delete s;
 }
@@ -509,12 +533,26 @@ int sched_grid_create(ls_ctx *ctx, int n_sub, bool gen, long long capacity, Sche
     s->h.lines_per_msg = 4;
     s->h.relaunch_limit = 2;
     // everything the launch needs exists before the first launch can be asked for; a failure leaves nothing half-made behind
-    const size_t ctl_bytes = 64 + (size_t)n_sub * 256;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&s->g), ctl_bytes);
+    const size_t go_bytes = (size_t)n_sub * 256;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&s->g), sizeof(SchedGridCtl));
+    if (e == hipSuccess) {
+        // The go records in fine-grained device memory when the host can write there (large-BAR platform): every workgroup then
+        // polls the request itself -- no PCIe read by a master, no relay.  Else plain device memory, filled by the masters.
+        int large_bar = 0;
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) == hipSuccess && large_bar &&
+            hipExtMallocWithFlags(reinterpret_cast<void **>(&s->go), go_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+            s->go_direct = true;
+        } else {
+            (void)hipGetLastError();
+            s->go = nullptr;
+            e = hipMalloc(reinterpret_cast<void **>(&s->go), go_bytes);
+        }
+    }
     if (e == hipSuccess) e = s->rec.reserve(align256((size_t)n_sub * G * 16));
     if (e == hipSuccess) {
         // tag 0 everywhere: an uninitialised record or go line must not look like a message of the current request
-        hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, s->h.stream, reinterpret_cast<int *>(s->g), 0, (long long)(ctl_bytes / 4));
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, s->h.stream, reinterpret_cast<int *>(s->g), 0, (long long)(sizeof(SchedGridCtl) / 4));
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, s->h.stream, reinterpret_cast<int *>(s->go), 0, (long long)(go_bytes / 4));
         hipLaunchKernelGGL(fill_i32_kernel, dim3(8), dim3(256), 0, s->h.stream, s->rec.as<int>(), 0, (long long)(s->rec.cap / 4));
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(s->h.stream);
@@ -522,11 +560,13 @@ int sched_grid_create(ls_ctx *ctx, int n_sub, bool gen, long long capacity, Sche
     if (e != hipSuccess) {
         rc = set_err(ctx, LS_ERR_HIP, "scheduling grid: set-up failed: %s", hipGetErrorString(e));
         if (s->g) (void)hipFree(s->g);
+        if (s->go) (void)hipFree(s->go);
         s->rec.release();
         s->h.release();
         delete s;
         return rc;
     }
+    if (s->go_direct) s->h.req_dev = s->go; // the host's request lines ARE the go records
     s->h.launch = [s](const SrvLink &L) {
         ls_ctx *ctx = s->owner;
         SchedGridArgs a;
@@ -536,6 +576,7 @@ int sched_grid_create(ls_ctx *ctx, int n_sub, bool gen, long long capacity, Sche
         a.stream_cap = s->stream_cap;
         a.gen_total = (long long)ctx->sched.n_days_stored * ctx->sched.n_employees;
         a.g = s->g;
+        a.go = s->go;
         s->ready_total += (unsigned long long)s->n_sub * s->G;
         a.ready_target = s->ready_total;
         a.rec = s->rec.as<unsigned>();

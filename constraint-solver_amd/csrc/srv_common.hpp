@@ -171,7 +171,17 @@ struct SrvHost {
     std::vector<unsigned> tags;   // last tag posted per slot
     std::function<hipError_t(const SrvLink &)> launch; // set by the owner: starts the resident kernel on `stream`
 
-    unsigned *req(int s) const { return reinterpret_cast<unsigned *>(pinned) + (size_t)s * 16; } // request lines: pinned host memory, polled over PCIe
+    // Request lines: pinned host memory, polled by the device over PCIe -- or, when the owner sets req_dev, fine-grained DEVICE
+    // memory the host writes through the PCIe BAR (write-combined: 64-byte stores, then sfence): a poll is then a local read, a
+    // request crosses PCIe once instead of being fetched, and every workgroup of a grid can poll it without a relay.
+    unsigned *req_dev = nullptr;
+    unsigned *req(int s) const { return (req_dev ? req_dev : reinterpret_cast<unsigned *>(pinned)) + (size_t)s * 16; }
+    void flush_lines() const
+    {
+#if defined(__x86_64__)
+        if (req_dev) _mm_sfence();
+#endif
+    }
     unsigned *resp(int s) const { return reinterpret_cast<unsigned *>(pinned + o_resp) + (size_t)s * 16; }
     unsigned long long *exit_gen() const { return reinterpret_cast<unsigned long long *>(pinned + o_exit); }
     char *extra() const { return pinned + o_extra; }
@@ -257,6 +267,7 @@ struct SrvHost {
         for (int d = 0; d < 16; d++) line[d] = (tag << 16) | (pay[d] & 0xffffu);
         __atomic_thread_fence(__ATOMIC_RELEASE); // the bulk data is written before the line that announces it
         srv_store_line(req(slot), line);
+        flush_lines();
         requests.fetch_add(1, std::memory_order_relaxed);
     }
     // A message of n_lines consecutive lines starting at line `slot` (the scheduling grid: header + state), every dword under
@@ -268,6 +279,7 @@ struct SrvHost {
         for (int d = 0; d < 16 * n_lines; d++) msg[d] = (tag << 16) | (pay[d] & 0xffffu);
         __atomic_thread_fence(__ATOMIC_RELEASE);
         for (int l = n_lines - 1; l >= 0; l--) srv_store_line(req(slot + l), msg + 16 * l);
+        flush_lines();
         requests.fetch_add(1, std::memory_order_relaxed);
     }
     // QUIT to every reader (one per `lines_per_msg` lines), as a WHOLE message of that reader's size under one new tag
