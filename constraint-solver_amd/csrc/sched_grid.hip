@@ -216,14 +216,16 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
 #pragma unroll
         for (int j = 0; j < MAXC; j++) {
             const int k = k0 + j * (64 * NW);
-            int ty = -1, xa = 0, xb = 0;
-            if (j < cpw) { // block-uniform
+            ed[j].active = false; ed[j].swap = false; ed[j].p1 = ed[j].p2 = ed[j].ea = ed[j].eb = ed[j].new1 = ed[j].new2 = 0;
+            hbits[j] = 0;
+            if (j < cpw) { // block-uniform: the chunks beyond cpw of this instantiation cost nothing
+                int ty = -1, xa = 0, xb = 0;
                 if constexpr (GEN) sched_gen_exhaustive(e_lane, E, k, ty, xa, xb); // every lane takes part in the shuffle
                 else { ty = mtype[j]; xa = mma[j]; xb = mmb[j]; }
                 if (k >= nm) ty = -1;
+                ed[j] = sched_edit_of(e_lane, S, E, ty, xa, xb);
+                hbits[j] = sched_edit_hbits(in, ed[j]);
             }
-            ed[j] = sched_edit_of(e_lane, S, E, ty, xa, xb);
-            hbits[j] = sched_edit_hbits(in, ed[j]);
         }
 #if defined(LS_NQ_STAMPS) && !defined(SCG_FINE)
         { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); gst[1] = wall_clock64(); }
@@ -240,12 +242,15 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
 #pragma unroll
         for (int j = 0; j < MAXC; j++) {
             my_key[j] = SC_KEY_EMPTY;
-            if (ed[j].active) {
-                int hard, soft;
-                my_key[j] = sched_delta_key<M>(T, D, e_lane, ed[j], hbits[j], hard, soft, emp);
-                if (my_key[j] < best_key) { best_key = my_key[j]; best_rel = tid + j * (64 * NW); }
+            my_bal[j] = 0;
+            if (j < cpw) { // block-uniform
+                if (ed[j].active) {
+                    int hard, soft;
+                    my_key[j] = sched_delta_key<M>(T, D, e_lane, ed[j], hbits[j], hard, soft, emp);
+                    if (my_key[j] < best_key) { best_key = my_key[j]; best_rel = tid + j * (64 * NW); }
+                }
+                my_bal[j] = __ballot(ed[j].active);
             }
-            my_bal[j] = __ballot(ed[j].active);
             if (lane == 0) s_cntc[j][wib] = __popcll(my_bal[j]);
         }
         SCG_STAMP(3);
@@ -266,10 +271,12 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
             wg_key = wave_min_u64(k8);
             wg_rel = (unsigned)wave_min_u64(lane < NW && k8 == wg_key ? (u64)s_wrel[lane] : ~0ull);
         }
-        int total = 0;
-#pragma unroll
-        for (int j = 0; j < MAXC; j++)
-            for (int i = 0; i < NW; i++) total += s_cntc[j][i];
+        // real candidates per (chunk, wavefront) in candidate order, one per lane: the inclusive prefix gives the workgroup's total
+        // and, for the finisher, the rank of every wavefront's first candidate (one LDS read and six DPP adds instead of MAXC x NW reads)
+        static_assert(MAXC * NW <= 64, "one (chunk, wavefront) count per lane");
+        const int cnt_l = lane < MAXC * NW ? (&s_cntc[0][0])[lane] : 0;
+        const int cnt_incl = wave_prefix_sum_i32(cnt_l);
+        const int total = __builtin_amdgcn_readlane(cnt_incl, 63);
         SCG_FSTAMP(5);
         // ---- this workgroup's record: four tagged dwords (count | key in 24 + 24 + 16 bits | position in 8 + 4 bits), ONE store by
         // four lanes, no acknowledgement wait and no ticket: the request's finisher polls the records until all carry the tag
@@ -286,15 +293,10 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         if (c == fin) { // ---- the finish step: prefix over the counts, minima of the workgroups inside the window, the cut workgroup up to the window
             int my_rank[MAXC]; // 1-based among the workgroup's real candidates, in candidate order (chunk, wavefront, lane): for a cut through THIS workgroup
             {
-                int run0 = 0;
+                const int cnt_excl = cnt_incl - cnt_l;
 #pragma unroll
-                for (int j = 0; j < MAXC; j++) {
-                    my_rank[j] = run0 + __popcll(my_bal[j] & ((2ull << lane) - 1));
-                    for (int i = 0; i < NW; i++) {
-                        if (i < wib) my_rank[j] += s_cntc[j][i];
-                        run0 += s_cntc[j][i];
-                    }
-                }
+                for (int j = 0; j < MAXC; j++)
+                    my_rank[j] = __builtin_amdgcn_readlane(cnt_excl, j * NW + wib) + __popcll(my_bal[j] & ((2ull << lane) - 1));
             }
             // the records of THIS request: one 16-byte read per lane and pass (two 8-byte loads that go to the coherence point,
             // past the L2), by as many wavefronts as there are 64 records; no barrier inside the poll
@@ -455,7 +457,7 @@ template <int MAXC> static const void *grid_fn_c(bool m32, bool gen)
 }
 static const void *grid_fn(bool m32, bool gen, int maxc)
 {
-    return maxc <= 1 ? grid_fn_c<1>(m32, gen) : (maxc <= 2 ? grid_fn_c<2>(m32, gen) : (maxc <= 4 ? grid_fn_c<4>(m32, gen) : grid_fn_c<SCG_MAXC>(m32, gen)));
+    return maxc <= 1 ? grid_fn_c<1>(m32, gen) : (maxc <= 2 ? grid_fn_c<2>(m32, gen) : (maxc <= 4 ? grid_fn_c<4>(m32, gen) : (maxc <= 6 ? grid_fn_c<6>(m32, gen) : grid_fn_c<SCG_MAXC>(m32, gen))));
 }
 
 // Geometry of a grid of n_sub sub-grids for lists of `total` candidates: as few chunks per workgroup as leave every workgroup
@@ -525,7 +527,7 @@ int sched_grid_create(ls_ctx *ctx, int n_sub, bool gen, long long capacity, Sche
     SchedGrid *s = new (std::nothrow) SchedGrid();
     if (!s) return set_err(ctx, LS_ERR_NOMEM, "out of host memory");
     s->owner = ctx; s->gen = gen; s->n_sub = n_sub; s->G = G; s->cpw = cpw;
-    s->maxc = cpw <= 1 ? 1 : (cpw <= 2 ? 2 : (cpw <= 4 ? 4 : SCG_MAXC));
+    s->maxc = cpw <= 1 ? 1 : (cpw <= 2 ? 2 : (cpw <= 4 ? 4 : (cpw <= 6 ? 6 : SCG_MAXC)));
     s->stream_cap = (long long)G * cpw * SCS_CHUNK;
     s->subs.resize((size_t)n_sub);
     int rc = s->h.init(ctx, "scheduling grid server", 4 * n_sub, gen ? 0 : (size_t)n_sub * (size_t)s->stream_cap * sizeof(ls_sched_move));

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "constraint-solver_amd"))
 import numpy as np  # noqa: E402
 
 # the LAUNCHED kernels are what per-dispatch counters can describe: one-restart host calls take the launch-per-call route here
-# (the resident servers are one long dispatch each; their service timeline comes from tools/step_server_trace.py)
+# (the resident servers are one long dispatch each; their service timelines come from tools/resident_timelines.py)
 os.environ.setdefault("LS_NQ_STEP", "3")
 os.environ.setdefault("LS_SCHED_SERVER", "0")
 
@@ -29,7 +29,7 @@ def main():
         _, cur = ctx.nqueens_col_scores(boards)
         cols = np.tile(np.arange(n, dtype=np.int32), (R, 1))
         ncols = np.full(R, n, dtype=np.int32)
-        for algo, kernel in (("scan", "nq_scan_regs_kernel"), ("table", "nq_table_pairs_kernel")):
+        for algo, kernel in (("scan", "nq_scan_regs_kernel"), ("table", "nq_table_quads_kernel")):
             ctx.set_algo(algo)
             for _ in range(reps):
                 out, _ = ctx.nqueens_eval_batch(boards, cur, cols, ncols, n * (n - 1))
@@ -42,10 +42,10 @@ def main():
         ctx.set_algo("table")
         for _ in range(reps):
             out, _ = ctx.nqueens_eval_batch(b64, cur64, np.tile(np.arange(n, dtype=np.int32), (R64, 1)), np.full(R64, n, np.int32), n * (n - 1))
-        meta["nq_table_pairs_kernel_r64"] = dict(candidates_per_launch=int(sum(o["n_scored"] for o in out)), restarts=R64, n=n,
+        meta["nq_table_quads_kernel_r64"] = dict(candidates_per_launch=int(sum(o["n_scored"] for o in out)), restarts=R64, n=n,
                                                  workload="64 restarts x full n x n neighbourhood (same grid as the 8-restart launch: the second group of dispatches)",
-                                                 match="nq_table_pairs_kernel", dispatch_slice=[reps, 2 * reps], shares_group_with="nq_table_pairs_kernel")
-        meta["nq_table_pairs_kernel"]["dispatch_slice"] = [0, reps]
+                                                 match="nq_table_quads_kernel", dispatch_slice=[reps, 2 * reps], shares_group_with="nq_table_quads_kernel")
+        meta["nq_table_quads_kernel"]["dispatch_slice"] = [0, reps]
         # n = 1024 scan: 32 restarts x 1024 columns
         n2, R2 = 1024, 32
         b2 = np.stack([np.random.default_rng(100 + r).integers(0, n2, size=n2) for r in range(R2)]).astype(np.int32)
