@@ -329,6 +329,10 @@ def run_rank(args, rank, world, device, sync, launcher):
                              "sched_exhaustive_cpu_per_s": (legs.get("sched10k_exhaustive_320k") or {}).get("one_core_per_s"),
                              "sched_exhaustive_gpu_per_s": (ex.get("sched10k_exhaustive_320k") or {}).get("neighbours_per_s"),
                              "sched_example_x64_gpu_per_s": (ex.get("sched_example_window100_x64_restarts") or {}).get("neighbours_per_s")})
+                for tagk, key in (("nq_srv", "fused_ls_step_host_round_trip_1_restarts"), ("c3_srv", "config3_end_to_end_sched_example_seed42"),
+                                  ("c5_grid", "config5_end_to_end_sched10k_window65536_seed42"), ("xgrid", "sched10k_exhaustive_320k_host_round_trip_generated_on_device")):
+                    rr = (ex.get(key) or {}).get("resident") or {}
+                    flat.update({f"{tagk}_service_us": rr.get("service_us"), f"{tagk}_frac": rr.get("frac"), f"{tagk}_mailbox_us": rr.get("mailbox_us")})
                 ms = ex.get("config3_multi_restart_end_to_end") or {}
                 flat.update({"c3_x64_e2e_per_s": ms.get("neighbours_per_s"), "c3_x64_e2e_equal": ms.get("equal_single_solver_runs")})
                 m5 = ex.get("config5_multi_restart_end_to_end") or {}
@@ -382,7 +386,7 @@ def build_report(args, world, R, n, info, value, elapsed, avg_launch_s, neighbou
     counters = load_counters()
     traffic = counters.get("hbm_traffic", {}).get(f"nq_{args.algo}_n{n}_r{R}", {}).get("bytes_per_launch")
     kernel = ("nq_scan_regs_kernel<BoardF32<64>, false>" if (args.algo == "scan" and 2048 < n <= 4096)
-              else ("nq_table_pairs_kernel" if args.algo == "table" else "nq_scan_*"))
+              else ("nq_table_quads_kernel" if args.algo == "table" else "nq_scan_*"))
     # VALU-issue roofline of the scan kernel: per neighbour every lane runs 4 full-rate fp32
     # instructions (sub, sub, mul+clamp, add) for each of its ceil64(n)/64 columns; achieved counts ONLY those
     # algorithmic instructions (measured SQ_INSTS_VALU per neighbour is in counters.*), peak is the spec issue rate.
@@ -463,11 +467,27 @@ def build_report(args, world, R, n, info, value, elapsed, avg_launch_s, neighbou
 def load_counters():
     """Committed rocprofv3 summaries (profiles/): HBM traffic per launch and per-kernel SQ instruction counts."""
     out = {}
-    for key, name in (("hbm_traffic", "hbm_traffic.json"), ("kernels", "kernel_counters.json")):
+    for key, name in (("hbm_traffic", "hbm_traffic.json"), ("kernels", "kernel_counters.json"), ("resident", "resident_timelines.json")):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
                 out[key] = json.load(f)
+    return out
+
+
+def resident_route(route, live_us=None):
+    """{service_us, bound_us, frac, mailbox_us} of a RESIDENT route (no launch per request) from the committed stamps-build
+    timelines (profiles/resident_timelines.json, tools/resident_timelines.py): service = request seen -> answer written inside
+    the workgroup, bound = the VALU-issue bound of the same work from the launched twin kernel's counters, mailbox = the answer
+    wait minus the service (two PCIe crossings + poll delays).  live_us: what this run measured for the whole call / iteration."""
+    r = (load_counters().get("resident") or {}).get("routes", {}).get(route)
+    if not r or "service_us" not in r:
+        return None
+    out = {k: r.get(k) for k in ("service_us", "bound_us", "frac", "mailbox_us", "bound", "answer_wait_us", "bound_from")}
+    out["route"] = route
+    out["timelines"] = "profiles/resident_timelines.json (in-kernel stamps, -DLS_NQ_STAMPS build)"
+    if live_us:
+        out["service_share_of_live_call"] = r["service_us"] / live_us
     return out
 
 
@@ -632,7 +652,8 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True, sc
                                                      ncols_full.data_ptr(), n, n * (n - 1), res_d.data_ptr()),
                   5 if algo == "scan" else 50)
         out[f"{algo}_full_neighbourhood"] = {"neighbours_per_s": R * n * (n - 1) / s, "ms_per_launch": s * 1e3,
-                                             "roofline": issue_roofline("nq_scan_regs_kernel" if algo == "scan" else "nq_table_pairs_kernel", s)}
+                                             "roofline": issue_roofline("nq_scan_regs_kernel" if algo == "scan" else
+                                                                        ("nq_table_quads_kernel" if "nq_table_quads_kernel" in kc else "nq_table_pairs_kernel"), s)}
         w = 5 * n
         s = timed(lambda: ctx.nqueens_eval_batch_dev(R, n, rows_d.data_ptr(), cur_d.data_ptr(), cols_ref.data_ptr(),
                                                      ncols_ref.data_ptr(), mc, w, res_d.data_ptr()), 200)
@@ -652,7 +673,7 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True, sc
         s = timed(lambda: ctx.nqueens_eval_batch_dev(R64, n, rows64.data_ptr(), cur64_d.data_ptr(), cols64.data_ptr(), nc64.data_ptr(), n,
                                                      n * (n - 1), res64.data_ptr()), 30)
         out["table_full_neighbourhood_64_restarts"] = {"neighbours_per_s": R64 * n * (n - 1) / s, "us_per_launch": s * 1e6,
-                                                       "roofline": issue_roofline("nq_table_pairs_kernel_r64", s)}
+                                                       "roofline": issue_roofline("nq_table_quads_kernel_r64" if "nq_table_quads_kernel_r64" in kc else "nq_table_pairs_kernel_r64", s)}
         del rows64, cur64_d, cols64, nc64, res64
     except Exception as e:  # noqa: BLE001 - a secondary line must not take the bench down
         out["table_full_neighbourhood_64_restarts"] = {"error": repr(e)}
@@ -751,6 +772,7 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True, sc
                 raw_step()
             raw_us = (time.perf_counter() - t0) / (5000 // RR) * 1e6
         out[f"fused_ls_step_host_round_trip_{RR}_restarts"] = {
+            "resident": resident_route("nq_server_kernel", raw_us) if on_server else None,
             "us_per_call": s * 1e6, "candidates_per_call": RR * min(5 * n, mc * (n - 1)),
             "us_per_call_bare_c_entry": raw_us,
             "note": "us_per_call includes ctypes/numpy marshalling of the Python wrapper (about 8 us); us_per_call_bare_c_entry calls the C entry "
@@ -765,6 +787,16 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True, sc
         out["config4_end_to_end_64_restarts_one_gpu"] = config4_end_to_end(ctx, n)
         out.update(single_restart_end_to_end(ctx))
         out.update(multi_restart_sched_end_to_end(ctx, out))
+        for key, route in (("config4_end_to_end_64_restarts_one_gpu", "nq_server_kernel"), ("config2_end_to_end_nq1024_seed42", "nq_server_kernel"),
+                           ("config3_end_to_end_sched_example_seed42", "sched_server_kernel"), ("config3_multi_restart_end_to_end", "sched_server_kernel"),
+                           ("config5_end_to_end_sched10k_window65536_seed42", "sched_grid_server_kernel"),
+                           ("config5_multi_restart_end_to_end", "sched_grid_server_kernel")):
+            if isinstance(out.get(key), dict) and "error" not in out[key]:
+                out[key]["resident"] = resident_route(route, out[key].get("us_per_ls_iteration"))
+                if key == "config2_end_to_end_nq1024_seed42" and out[key]["resident"]:
+                    out[key]["resident"]["note"] = "timeline measured at n = 4096 (config 4's board size); the same kernel serves n = 1024"
+                if key == "config5_multi_restart_end_to_end" and out[key]["resident"]:
+                    out[key]["resident"]["note"] = "timeline of the one-sub-grid launch (one chunk per workgroup); with 8 sub-grids a workgroup scores six chunks per request"
     ctx.set_algo("scan")
     out.update(sched_measurements(ctx, torch, dev, timed, issue_roofline, cpu_seconds=max(sched_cpu_seconds, 0.05)))
     # the HBM figure the rooflines divide by is the vendor's 8 TB/s; this is what a plain device-to-device
@@ -1187,6 +1219,7 @@ def sched_measurements(ctx, torch, dev, timed, issue_roofline, cpu_seconds=0.4):
     got_rt = (r0["n_scored"], r0["best_index"], r0["best_hard"], r0["best_soft"])
     verified["sched10k_exhaustive_320k_host_round_trip"] = {"ok": got_rt == want, "records_checked": 1}
     out["sched10k_exhaustive_320k_host_round_trip_generated_on_device"] = {
+        "resident": resident_route("sched_grid_server_kernel_gen", s * 1e6) if on_grid else None,
         "neighbours_per_s": r0["n_scored"] / s, "us_per_call": s * 1e6, "candidates_per_call": r0["n_scored"],
         "route": "resident grid (no launch per call; candidates generated in the kernel, one workgroup per three 512-candidate chunks)" if on_grid
                  else "two launches per call (sched_eval_all_kernel + sched_finish_kernel)",
