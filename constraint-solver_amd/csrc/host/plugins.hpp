@@ -502,6 +502,10 @@ struct SchedProblem {
     size_t resident = 0; // entries of `stream` already on the device (ls_sched_moves_upload)
 
     SchedProblem(ls_ctx *c, int32_t d, int32_t s, int32_t e) : ctx(c), n_days_scored(d), n_days_stored(s), n_employees(e) {}
+    // how many moves of the stream an LS iteration asks the GPU to consider for a window (no-ops do not consume window: an eighth
+    // of slack -- the example's seven employees make one move in seven a no-op, ten thousand employees almost none --; a call that
+    // still cannot fill the window doubles it: the result is that of the reference's lazy take(window) either way)
+    static long long list_prefix(uint64_t window) { return (long long)window + (long long)(window / 8) + 16; }
 
     // ScheduleInitialSolutionGenerator (lib.rs:400-420): pushes D + 1 entries
     template <class R> Solution generate_initial_solution(R &rng) const
@@ -521,13 +525,29 @@ struct SchedProblem {
     void extend_stream(const ChaCha20Rng &ls_rng, size_t want)
     {
         if (!stream_started) { stream_rng = ls_rng; stream_started = true; }
+        if (stream.size() >= want) return;
+        stream.reserve(want);
+        // The draws of lib.rs:459-478, move by move, without the per-move allocations of the generic helpers (a window of 65 536
+        // asks for > 80 000 moves before the first LS iteration): the same values in the same order --
+        //   choose_weighted(ChangeDay: 1, SwapDays: 4) = WeightedIndex<u64>: Uniform<u64>(0, 5) against the cumulative weights [1]
+        //   days.choose / employees.choose           = gen_index (choose_index)
+        //   days.choose_multiple(rng, 2)              = index::sample(len, 2): Floyd's, amount < 50 (index_sample; checked against it
+        //                                              by tests/test_host_rng.py through the solver trajectories and the oracle driver)
+        const bool floyd2 = n_days_scored >= 2 && index_sample_uses_floyd((uint32_t)n_days_scored, 2);
         while (stream.size() < want) {
-            const size_t t = choose_weighted_index(stream_rng, {1, 4}, /*wide=*/true); // ChangeDay:1, SwapDays:4 (:435)
+            const size_t t = uniform_u64_below(stream_rng, 5) < 1 ? 0 : 1; // ChangeDay:1, SwapDays:4 (:435)
             ls_sched_move m;
             if (t == 0) {
                 m.type = 0;
                 m.a = (int32_t)choose_index(stream_rng, (size_t)n_days_scored); // days_to_employees.choose (:467)
                 m.b = (int32_t)choose_index(stream_rng, (size_t)n_employees);   // employees.choose (:468)
+            } else if (floyd2) {
+                const uint32_t len = (uint32_t)n_days_scored;
+                const uint32_t t0 = gen_range_u32_incl(stream_rng, 0, len - 2);
+                const uint32_t t1 = gen_range_u32_incl(stream_rng, 0, len - 1);
+                m.type = 1;
+                if (t1 == t0) { m.a = (int32_t)(len - 1); m.b = (int32_t)t0; } // "insert j before t"
+                else { m.a = (int32_t)t0; m.b = (int32_t)t1; }
             } else {
                 const std::vector<uint32_t> xs = index_sample(stream_rng, (uint32_t)n_days_scored, 2); // :473
                 m.type = 1;
@@ -581,11 +601,11 @@ struct SchedProblem {
     {
         if (window == 0) return false;
         if (tabu.tabu_size() != 1) return best_of_neighbourhood_general(current, rng, window, out, tabu);
-        size_t want = window + window / 4 + 16;
+        size_t want = (size_t)list_prefix(window);
         for (;;) {
             extend_stream(rng, want);
-            if (resident < want) { // the stream is the same for the whole run: keep it on the device
-                extend_stream(rng, want + want / 2);
+            if (resident < want) { // the stream is the same for the whole run: hand it over once (a little beyond what this call asks for)
+                extend_stream(rng, want + want / 16);
                 check_rc(ctx, ls_sched_moves_upload(ctx, stream.data(), (int64_t)stream.size()), "ls_sched_moves_upload");
                 resident = stream.size();
             }

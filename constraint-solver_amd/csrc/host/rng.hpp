@@ -374,6 +374,17 @@ template <class R> inline size_t choose_weighted_index(R &rng, const std::vector
     return idx;
 }
 
+// which of index::sample's three algorithms rand 0.8.5 picks (the selection at the end of index_sample, restated for callers
+// that inline the Floyd path for small amounts)
+inline bool index_sample_uses_floyd(uint32_t length, uint32_t amount)
+{
+    if (amount > length || amount >= 163) return false;
+    const int j = length < 500000 ? 0 : 1;
+    static const float C[2][2] = {{1.6f, 8.0f / 45.0f}, {10.0f, 70.0f / 9.0f}};
+    const float amount_fp = (float)amount;
+    return !(amount > 11 && (float)length < (C[1][j] + C[0][j] * amount_fp) * amount_fp);
+}
+
 // seq::index::sample(rng, length, amount) — indices in the order the reference yields them
 template <class R> inline std::vector<uint32_t> index_sample(R &rng, uint32_t length, uint32_t amount)
 {

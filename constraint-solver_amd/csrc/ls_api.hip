@@ -218,6 +218,23 @@ static int sched_ctx_grid(ls_ctx *ctx, bool gen, long long n_list, SchedGrid **o
     return LS_OK;
 }
 
+// ls_solver_create_sched: start the resident launch this solver's LS iterations will use (lists of `want` moves) before the first
+// round, like nq_ctx_prepare_server -- pinned blocks, a stream on its own hardware queue and the first launch are set-up, not
+// part of a round.  Failure to do so is not an error: the calls create what they need on demand.
+int sched_ctx_prepare(ls_ctx *ctx, long long want)
+{
+    if (!sched_resident_ok(ctx) || want <= 0) return LS_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return LS_OK;
+    if (want <= 512) {
+        SchedStepServer *sv = nullptr;
+        (void)sched_ctx_step(ctx, &sv);
+    } else {
+        SchedGrid *g = nullptr;
+        (void)sched_ctx_grid(ctx, false, want, &g);
+    }
+    return LS_OK;
+}
+
 // the device copy of the resident list, for the launched pipelines (made when one first needs the current list)
 static int sched_resident_dev(ls_ctx *ctx)
 {
@@ -1057,16 +1074,12 @@ int ls_sched_score(ls_ctx *ctx, int32_t n_states, const int32_t *states, int64_t
     if (!ctx) return LS_ERR_INVALID;
     if (!ctx->sched.valid) return set_err(ctx, LS_ERR_STATE, "ls_sched_instance_upload has not been called");
     LS_REQUIRE(ctx, n_states >= 1 && states && hard && soft, "bad arguments");
-    if (n_states == 1 && !terms && sched_resident_ok(ctx)) { // no launch: the slot's workgroup, or the master of the attached sub-grid
-        if (ctx->sched_grid && !ctx->sched_step && !ctx->sched_grid_unavailable) {
+    if (n_states == 1 && !terms && sched_resident_ok(ctx)) { // no launch when a resident launch is there: the slot's workgroup, or the sub-grid's master
+        if (ctx->sched_step) return sched_step_score(ctx, ctx->sched_step, ctx->sched_step_slot, states, hard, soft);
+        if (ctx->sched_grid && !ctx->sched_grid_unavailable) {
             const int rc_g = sched_grid_score(ctx, ctx->sched_grid, ctx->sched_grid_sub, states, hard, soft);
             if (rc_g != SRV_RC_GIVE_UP) return rc_g;
             ctx->sched_grid_unavailable = true;
-        } else {
-            SchedStepServer *sv = nullptr;
-            const int rc_s = sched_ctx_step(ctx, &sv);
-            if (rc_s == LS_OK) return sched_step_score(ctx, sv, ctx->sched_step_slot, states, hard, soft);
-            if (rc_s != LS_ERR_UNSUPPORTED) return rc_s;
         }
     }
     LS_BIND(ctx);

@@ -256,6 +256,7 @@ int nq_server_post(ls_ctx *ctx, NqServer *s, int slot, const int32_t *rows, cons
                    bool has_next_col_scores);
 int nq_server_finish(ls_ctx *ctx, NqServer *s, int slot, int64_t cur_score, const int32_t *cols, ls_nq_result *res, int64_t *next_col_scores);
 int nq_ctx_prepare_server(ls_ctx *ctx, int n);
+int sched_ctx_prepare(ls_ctx *ctx, long long want);
 
 #define LS_HIP(ctx, call)                                                                   \
     do {                                                                                    \

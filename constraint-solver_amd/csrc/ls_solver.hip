@@ -194,6 +194,14 @@ int ls_solver_create_sched(ls_ctx *ctx, int32_t n_days_scored, int32_t start_wee
         s->sc.reset(new SchedProblem(ctx, n_days_scored, n_days_scored + 1, n_employees));
         const ChaCha20Rng solver_rng = ChaCha20Rng::from_seed_string(seed); // lib.rs:58-62
         const ChaCha20Rng ils_rng = ChaCha20Rng::from_seed_string(seed);    // lib.rs:94
+        {   // set-up, not part of a round: the proposer's stream (a clone of the LocalSearch generator that nothing ever advances,
+            // lib.rs:488 -- the same list whenever it is drawn) and the resident launch the LS iterations will ask
+            const long long want = SchedProblem::list_prefix(params->window_size);
+            if (params->all_solution_iteration_expiry >= 1 && want > 0 && want < (1ll << 24)) {
+                s->sc->extend_stream(solver_rng, (size_t)(want + want / 16));
+                (void)lsamd::sched_ctx_prepare(ctx, want);
+            }
+        }
         LocalSearch<SchedProblem> ls(s->sc.get(), params->local_search_max_iterations, (size_t)params->window_size,
                                      (size_t)params->best_solutions_capacity, (size_t)params->all_solutions_capacity,
                                      params->all_solution_iteration_expiry, solver_rng);
@@ -414,6 +422,10 @@ int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, dou
                     ~Attach() { if (on) { c->server = s0; c->server_slot = slot0; c->server_owned = owned0; } }
                 } attach{ctx, ctx->server, ctx->server_slot, ctx->server_owned, shared.s != nullptr};
                 if (shared.s) { ctx->server = shared.s; ctx->server_slot = t; ctx->server_owned = false; }
+                // no shared launch (more slots than the device holds resident, or a board the server does not take): the slots launch
+                // per call -- they must not start a resident server EACH (that many launches could not all be resident either)
+                struct StepMode { ls_ctx *c; int m0; ~StepMode() { c->nq_step_mode = m0; } } step_mode{ctx, ctx->nq_step_mode};
+                if (!shared.s && !lockstep && ctx->nq_step_mode >= 4) ctx->nq_step_mode = 3;
                 const uint64_t fb0 = ctx->n_done_fallbacks, ru0 = ctx->n_resident_uploads;
                 struct Count { ls_ctx *c; uint64_t *fb, *ru; uint64_t fb0, ru0; ~Count() { *fb = c->n_done_fallbacks - fb0; *ru = c->n_resident_uploads - ru0; } }
                     count{ctx, &fallbacks[(size_t)t], &reuploads[(size_t)t], fb0, ru0};
@@ -642,7 +654,7 @@ static int multi_run_sched(ls_multi_solver *m, uint64_t max_rounds_per_restart, 
         ~Phase() { if (on) fprintf(stderr, "multi-restart scheduling run: set-up %.2f ms, restarts %.2f ms, tear-down %.2f ms\n", setup * 1e3, run * 1e3,
                                    (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - setup - run) * 1e3); }
     } phase{T_begin, trace};
-    const long long want = (long long)p.window_size + (long long)p.window_size / 4 + 16; // the list prefix an LS iteration asks for (SchedProblem::best_of_neighbourhood)
+    const long long want = SchedProblem::list_prefix(p.window_size); // the list prefix an LS iteration asks for (SchedProblem::best_of_neighbourhood)
     const bool resident = base->sched_server_on && base->sched_delta && m->sc_employees <= 32768 && p.all_solution_iteration_expiry >= 1;
     if (resident && want <= 512) {
         const int cap = lsamd::sched_step_max_slots(base);

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
     __shared__ int s_ctl[2]; // [0] leave, [1] the request's tag
     __shared__ int s_cut;
     __shared__ int s_before;
+    __shared__ __align__(16) unsigned s_mv[3 * 64 * NW]; // staging of a chunk of the sub-grid's stream when it is fetched (once per restart)
     // Which scored days an employee works in the current state, for every employee: the table's day-equality rows and the day
     // set of a ChangeDay's new employee are one LDS read each instead of a 64-step compare loop (a third of the scorer's
     // instructions).  Zero between requests: the <= 64 entries a state touches are set before and cleared after its scoring.
@@ -201,11 +202,14 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         const int hol_base = wib == 0 ? sched_holiday_bit(in, e_lane, lane) : 0;
         if constexpr (!GEN) {
             if (stream_id != my_stream) { // block-uniform: a new restart on this sub-grid (or a relaunch): this lane's moves, once
+                static_assert(NW == 8, "srv_fetch_moves_512 moves one 512-move chunk");
 #pragma unroll
                 for (int j = 0; j < MAXC; j++) {
-                    const int k = k0 + j * (64 * NW);
                     mtype[j] = -1;
-                    if (j < cpw && k < nm) { mtype[j] = srv_sys_load(&stream[k].type); mma[j] = srv_sys_load(&stream[k].a); mmb[j] = srv_sys_load(&stream[k].b); }
+                    if (j < cpw) { // (the whole chunk, whatever this request's n_moves: a later request may ask for more of the same list)
+                        srv_fetch_moves_512(stream + (size_t)(c * cpw + j) * (64 * NW), s_mv, tid);
+                        mtype[j] = (int)s_mv[3 * tid]; mma[j] = (int)s_mv[3 * tid + 1]; mmb[j] = (int)s_mv[3 * tid + 2];
+                    }
                 }
                 my_stream = stream_id;
             }

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
     __shared__ int s_state[64];
     __shared__ int s_leave;
     __shared__ int s_win[3]; // the winner's move, for the state update
+    __shared__ __align__(16) unsigned s_mv[3 * 64 * NW]; // staging of the slot's stream when it is fetched (once per restart)
     // employee -> scored days of the current state (sched_device.hpp): zero between requests
     extern __shared__ __align__(16) unsigned char s_dyn[];
     M *const emp = a.emp_entries > 0 ? reinterpret_cast<M *>(s_dyn) : nullptr;
@@ -86,7 +87,9 @@ __global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
         const bool eval = (s_req[0] & SCS_F_EVAL) != 0;
         bool fresh = false;
         if (eval && stream_id != my_stream) { // block-uniform: a new restart on this slot (or a relaunch): this lane's move, once
-            mtype = srv_sys_load(&stream[tid].type); mma = srv_sys_load(&stream[tid].a); mmb = srv_sys_load(&stream[tid].b);
+            static_assert(NW == 8, "srv_fetch_moves_512 moves one 512-move chunk");
+            srv_fetch_moves_512(stream, s_mv, tid);
+            mtype = (int)s_mv[3 * tid]; mma = (int)s_mv[3 * tid + 1]; mmb = (int)s_mv[3 * tid + 2];
             my_stream = stream_id;
         }
         if (state_id != lds_state) { // block-uniform: not the state this workgroup holds
@@ -183,8 +186,8 @@ struct SchedStepServer {
         bool valid = false;
         const ls_ctx *stream_ctx = nullptr;   // whose list, and which generation of it, the slot's pinned block holds
         unsigned long long stream_gen = 0;
-        double t_wait = 0, t_call = 0;        // LS_AMD_TRACE
-        unsigned long long calls = 0, dev_ticks[5] = {0, 0, 0, 0, 0};
+        double t_wait = 0, t_call = 0, t_score = 0; // LS_AMD_TRACE
+        unsigned long long calls = 0, score_calls = 0, dev_ticks[5] = {0, 0, 0, 0, 0};
     };
     std::vector<Slot> slots;
     int *shadow(int s) const { return reinterpret_cast<int *>(h.extra()) + (size_t)s * 64; }
@@ -248,12 +251,13 @@ void sched_step_destroy(SchedStepServer *s)
 {
     if (!s) return;
     if (getenv("LS_AMD_TRACE")) {
-        double wait = 0, call = 0;
-        unsigned long long calls = 0, ticks[5] = {0, 0, 0, 0, 0};
+        double wait = 0, call = 0, score = 0;
+        unsigned long long calls = 0, scores = 0, ticks[5] = {0, 0, 0, 0, 0};
         for (const auto &sl : s->slots) {
-            wait += sl.t_wait; call += sl.t_call; calls += sl.calls;
+            wait += sl.t_wait; call += sl.t_call; calls += sl.calls; score += sl.t_score; scores += sl.score_calls;
             for (int d = 0; d < 5; d++) ticks[d] += sl.dev_ticks[d];
         }
+        if (scores) fprintf(stderr, "scheduling step server (%d slots): %llu single-state scores, %.2f us per call\n", s->n_slots, scores, score / scores * 1e6);
         if (calls) {
             fprintf(stderr, "scheduling step server (%d slots): %llu steps, answer wait %.2f us per step (whole call %.2f us), %llu launches\n",
                     s->n_slots, calls, wait / calls * 1e6, call / calls * 1e6, s->h.relaunches.load());
@@ -300,6 +304,8 @@ static int step_check_slot(ls_ctx *ctx, const SchedStepServer *s, int slot)
 // ls_sched_score for one state through the slot's workgroup (the LS walk that follows then starts from a state it holds)
 int sched_step_score(ls_ctx *ctx, SchedStepServer *s, int slot, const int32_t *state, int64_t *hard, int64_t *soft)
 {
+    static const bool trace = getenv("LS_AMD_TRACE") != nullptr;
+    const auto T0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     int rc = step_check_slot(ctx, s, slot);
     if (rc != LS_OK) return rc;
     rc = step_sync_state(ctx, s, slot, state);
@@ -316,6 +322,10 @@ int sched_step_score(ls_ctx *ctx, SchedStepServer *s, int slot, const int32_t *s
     if (rc != LS_OK) { s->slots[(size_t)slot].valid = false; return rc; }
     *hard = r[3];
     *soft = r[4];
+    if (trace) {
+        s->slots[(size_t)slot].t_score += std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count();
+        s->slots[(size_t)slot].score_calls++;
+    }
     return LS_OK;
 }
 

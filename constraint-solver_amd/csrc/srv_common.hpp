@@ -59,6 +59,24 @@ struct SrvLink {                      // kernel argument: the lines of slot 0 (s
 #if defined(__HIPCC__)
 template <class T> __device__ __forceinline__ T srv_sys_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// 16 bytes from host (or fine-grained device) memory past every cache: bulk data a workgroup fetches once (a slot's move stream)
+typedef unsigned srv_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ srv_u32x4 srv_sys_load_b128(const void *p)
+{
+    srv_u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// A workgroup of 512 threads fetches one 512-move chunk (12 bytes a move: 384 16-byte reads instead of 1536 4-byte ones over PCIe)
+// through `buf` (1536 dwords of LDS); afterwards thread t finds its move in buf[3 t .. 3 t + 2].  Block-uniform call.
+__device__ __forceinline__ void srv_fetch_moves_512(const void *chunk, unsigned *buf, int tid)
+{
+    __syncthreads(); // nobody still reads the previous chunk
+    if (tid < 384) reinterpret_cast<srv_u32x4 *>(buf)[tid] = srv_sys_load_b128(static_cast<const char *>(chunk) + (size_t)tid * 16);
+    __syncthreads();
+}
+
 struct SrvPoll { // wave 0's poll state
     unsigned last_tag;
     unsigned long long t_start, t_served;

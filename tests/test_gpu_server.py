@@ -773,3 +773,29 @@ def test_sched_exhaustive_grid_many_chunks_per_workgroup_day_by_day():
             assert (r["n_scored"], r["best_index"], r["best_hard"], r["best_soft"]) == \
                    (exp["n_scored"], exp["best_index"], exp["best_hard"], exp["best_soft"]), w
         assert c.counters()["server_requests"] >= 4
+
+
+def test_more_slots_than_resident_workgroups_fall_back_to_launches(monkeypatch):
+    # every workgroup of the N-queens server must be resident for the life of the launch (1024 threads, 147 KB of LDS at
+    # n = 8192: one per CU), so its slot count is bounded by what the CUs hold (nq_server_max_slots: 240 of 256).  256 slots do not
+    # fit: the run takes one fused launch per LS iteration instead (no starved slot, no 10 s error), with the same results.
+    import ls_amd
+    n, rounds = 8192, 1
+    seeds = [str(900 + r) for r in range(256)]
+    p = dict(local_search_max_iterations=10_000, window_size=5 * n, best_solutions_capacity=32, all_solutions_capacity=100_000,
+             all_solution_iteration_expiry=10_000, iterated_local_search_max_iterations=10_000, max_allow_no_improvement_for=5)
+    with ls_amd.Context(0) as c:
+        if c.device_info()["n_cus"] > 272:
+            pytest.skip("this device holds 256 resident workgroups of the server")
+        m = ls_amd.MultiSolver(c, n, seeds, p, n_slots=256, mode="free")
+        m.run(max_rounds_per_restart=rounds)
+        cnt = m.counters()
+        assert cnt["server_requests"] == 0 and cnt["completion_word_fallbacks"] == 0
+        got = {r: (m.best(r), m.restart_stats(r)["ls_iterations"]) for r in (0, 100, 255)}
+        m.close()
+        for r, g in got.items():
+            s = ls_amd.Solver.nqueens(c, n, seeds[r], p)
+            for _ in range(rounds):
+                s.execute_round()
+            assert (s.best(), s.stats()["ls_iterations"]) == g, seeds[r]
+            s.close()
