@@ -502,10 +502,14 @@ struct SchedProblem {
     size_t resident = 0; // entries of `stream` already on the device (ls_sched_moves_upload)
 
     SchedProblem(ls_ctx *c, int32_t d, int32_t s, int32_t e) : ctx(c), n_days_scored(d), n_days_stored(s), n_employees(e) {}
-    // how many moves of the stream an LS iteration asks the GPU to consider for a window (no-ops do not consume window: an eighth
-    // of slack -- the example's seven employees make one move in seven a no-op, ten thousand employees almost none --; a call that
-    // still cannot fill the window doubles it: the result is that of the reference's lazy take(window) either way)
-    static long long list_prefix(uint64_t window) { return (long long)window + (long long)(window / 8) + 16; }
+    // How many moves of the stream an LS iteration asks the GPU to consider for a window.  No-ops do not consume window and about
+    // one move in `n_employees` is one (the example's seven employees: 14 %, and a restart whose FIXED stream starts badly fails
+    // again and again), so: a quarter of slack for small rosters, an eighth from 64 employees on; a call that still cannot fill
+    // the window doubles the prefix -- the result is that of the reference's lazy take(window) either way.
+    static long long list_prefix(uint64_t window, int32_t n_employees)
+    {
+        return (long long)window + (long long)(window / (n_employees < 64 ? 4 : 8)) + 16;
+    }
 
     // ScheduleInitialSolutionGenerator (lib.rs:400-420): pushes D + 1 entries
     template <class R> Solution generate_initial_solution(R &rng) const
@@ -601,7 +605,7 @@ struct SchedProblem {
     {
         if (window == 0) return false;
         if (tabu.tabu_size() != 1) return best_of_neighbourhood_general(current, rng, window, out, tabu);
-        size_t want = (size_t)list_prefix(window);
+        size_t want = (size_t)list_prefix(window, n_employees);
         for (;;) {
             extend_stream(rng, want);
             if (resident < want) { // the stream is the same for the whole run: hand it over once (a little beyond what this call asks for)

@@ -196,7 +196,7 @@ int ls_solver_create_sched(ls_ctx *ctx, int32_t n_days_scored, int32_t start_wee
         const ChaCha20Rng ils_rng = ChaCha20Rng::from_seed_string(seed);    // lib.rs:94
         {   // set-up, not part of a round: the proposer's stream (a clone of the LocalSearch generator that nothing ever advances,
             // lib.rs:488 -- the same list whenever it is drawn) and the resident launch the LS iterations will ask
-            const long long want = SchedProblem::list_prefix(params->window_size);
+            const long long want = SchedProblem::list_prefix(params->window_size, n_employees);
             if (params->all_solution_iteration_expiry >= 1 && want > 0 && want < (1ll << 24)) {
                 s->sc->extend_stream(solver_rng, (size_t)(want + want / 16));
                 (void)lsamd::sched_ctx_prepare(ctx, want);
@@ -654,7 +654,7 @@ static int multi_run_sched(ls_multi_solver *m, uint64_t max_rounds_per_restart, 
         ~Phase() { if (on) fprintf(stderr, "multi-restart scheduling run: set-up %.2f ms, restarts %.2f ms, tear-down %.2f ms\n", setup * 1e3, run * 1e3,
                                    (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - setup - run) * 1e3); }
     } phase{T_begin, trace};
-    const long long want = SchedProblem::list_prefix(p.window_size); // the list prefix an LS iteration asks for (SchedProblem::best_of_neighbourhood)
+    const long long want = SchedProblem::list_prefix(p.window_size, m->sc_employees); // the list prefix an LS iteration asks for (SchedProblem::best_of_neighbourhood)
     const bool resident = base->sched_server_on && base->sched_delta && m->sc_employees <= 32768 && p.all_solution_iteration_expiry >= 1;
     if (resident && want <= 512) {
         const int cap = lsamd::sched_step_max_slots(base);
