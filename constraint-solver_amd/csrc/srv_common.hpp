@@ -191,7 +191,10 @@ struct SrvHost {
 
     // Request lines: pinned host memory, polled by the device over PCIe -- or, when the owner sets req_dev, fine-grained DEVICE
     // memory the host writes through the PCIe BAR (write-combined: 64-byte stores, then sfence): a poll is then a local read, a
-    // request crosses PCIe once instead of being fetched, and every workgroup of a grid can poll it without a relay.
+    // request crosses PCIe once instead of being fetched, and every workgroup of a grid can poll it without a relay.  (Used by the
+    // scheduling grid.  For the one-line mailboxes of the step servers it was measured twice, rounds 3 and 4: no gain -- config 3
+    // 5.8-6.2 against 5.4 us per LS iteration, N-queens n = 4096 within the noise -- the write-combined store + sfence costs the
+    // host what the local poll saves.)
     unsigned *req_dev = nullptr;
     unsigned *req(int s) const { return (req_dev ? req_dev : reinterpret_cast<unsigned *>(pinned)) + (size_t)s * 16; }
     void flush_lines() const
@@ -244,6 +247,7 @@ struct SrvHost {
     }
     void release()
     {
+        req_dev = nullptr; // (owned by whoever set it)
         if (stream) (void)hipStreamDestroy(stream);
         if (pinned) (void)hipHostFree(pinned);
         if (ctl) (void)hipFree(ctl);
