@@ -662,6 +662,10 @@ static int multi_run_sched(ls_multi_solver *m, uint64_t max_rounds_per_restart, 
     } else if (resident) {
         while (T > 1 && !lsamd::sched_grid_fits(base, T, false, want)) T--; // as many sub-grids as the device holds side by side
     }
+    // the caller's own resident launches (earlier single-solver calls on this context) leave now instead of 2 ms from now: the
+    // shared launch may need every CU
+    if (base->sched_step && base->sched_step_owned) lsamd::sched_step_pause(base->sched_step);
+    if (base->sched_grid && base->sched_grid_owned) lsamd::sched_grid_pause(base->sched_grid);
     if (m->sc_slots_made != T) { // (first run, or another slot count: the shared launch is sized by it)
         m->sc_release();
         if (resident && want <= 512) check_rc(base, lsamd::sched_step_create(base, T, &m->sc_step), "scheduling LS-step server");

@@ -171,6 +171,34 @@ def server_walk(ctx):
     stats["server_steps"] = stats.get("server_steps", 0) + 12
 
 
+def multi_sched_case(ctx):
+    """Many scheduling restarts on one GPU (ls_multi_solver_create_sched): the slots of one shared resident launch -- step-server
+    workgroups (small windows) or sub-grids (windows beyond 512 moves) -- against each restart's own ls_solver run."""
+    E = int(rng.choice([3, 7, 40, 600]))
+    D = int(rng.choice([14, 31, 45]))
+    window = int(rng.choice([20, 100, 700, 1500]))
+    bits = np.zeros(E, dtype=np.uint64)
+    for e in range(min(E, 20)):
+        for d in rng.choice(D, size=int(rng.integers(0, 3)), replace=False):
+            bits[e] |= np.uint64(1) << np.uint64(int(d))
+    p = dict(local_search_max_iterations=200, window_size=window, best_solutions_capacity=8, all_solutions_capacity=1000,
+             all_solution_iteration_expiry=100, iterated_local_search_max_iterations=3, max_allow_no_improvement_for=5)
+    seeds = [str(int(rng.integers(0, 10 ** 6))) for _ in range(int(rng.integers(2, 7)))]
+    m = ls_amd.MultiSolver.scheduling(ctx, D, int(rng.integers(0, 7)) if False else 0, E, seeds, p, holiday_bits=bits, n_slots=int(rng.integers(1, len(seeds) + 1)))
+    m.run(max_rounds_per_restart=3)
+    got = [(m.best(r), m.restart_stats(r)["ls_iterations"]) for r in range(len(seeds))]
+    m.close()
+    for r, sd in enumerate(seeds):
+        s1 = ls_amd.Solver.scheduling(ctx, D, 0, E, sd, p, holiday_bits=bits)
+        while not s1.is_finished():
+            s1.execute_round()
+        one = (s1.best(), s1.stats()["ls_iterations"])
+        s1.close()
+        if one != got[r]:
+            fail("multi-restart scheduling run differs from the single run", E=E, D=D, window=window, seed=sd, got=got[r], exp=one)
+    stats["multi_sched_restarts"] = stats.get("multi_sched_restarts", 0) + len(seeds)
+
+
 os.environ["LS_NQ_STEP"] = "3"          # a second context on the launch-per-call routes (the knob is read when a context is created)
 ctx3 = ls_amd.Context(0)
 os.environ.pop("LS_NQ_STEP")
@@ -181,6 +209,8 @@ with ls_amd.Context(0) as ctx:
         nq_case(ctx if turn % 2 == 0 else ctx3)   # batched LS steps: resident server slots | fused launches
         sched_case(ctx)
         server_walk(ctx)
+        if turn % 8 == 0:
+            multi_sched_case(ctx)
         turn += 1
         if time.time() - last > 30:
             print("progress", stats, flush=True)
