@@ -556,6 +556,22 @@ __device__ __forceinline__ int sched_edit_hbits(const SchedInst &in, const Sched
     return sched_holiday_bit(in, ed.new1, ed.p1) | (sched_holiday_bit(in, ed.new2, ed.p2) << 1);
 }
 
+// The same in two steps, for kernels that have several candidates per lane in flight: the holiday WORDS of the two new employees
+// are fetched first (the loads of all candidates are issued before anything waits for one), the bits are taken when they are
+// needed.  M = unsigned (<= 32 days): the low half of the 64-bit word is all there is to read.
+template <typename M> __device__ __forceinline__ M sched_hol_word(const SchedInst &in, int employee)
+{
+    if ((unsigned)employee >= (unsigned)in.n_employees) return 0;
+    return reinterpret_cast<const M *>(in.holiday_bits + employee)[0];
+}
+template <typename M> __device__ __forceinline__ int sched_hbits_of(const SchedInst &in, const SchedEdit &ed, M w1, M w2)
+{
+    if (!ed.active) return 0;
+    const int b1 = (unsigned)ed.p1 < (unsigned)in.D ? (int)((w1 >> ed.p1) & 1) : 0;
+    const int b2 = (unsigned)ed.p2 < (unsigned)in.D ? (int)((w2 >> ed.p2) & 1) : 0;
+    return b1 | (b2 << 1);
+}
+
 // the argmin key of an active candidate (and its scores)
 template <typename M>
 __device__ __forceinline__ u64 sched_delta_key(const SchedBaseTab<M> &T, int D, int e_lane, const SchedEdit &ed, int hbits, int &hard,

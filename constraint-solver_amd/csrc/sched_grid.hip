@@ -216,19 +216,19 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         }
         // ---- this workgroup's chunks: the delta scorer, one candidate per lane and chunk
         SchedEdit ed[MAXC];
-        int hbits[MAXC];
+        M hw1[MAXC], hw2[MAXC]; // the holiday words of the candidates' new employees: all fetched before anything waits for one
 #pragma unroll
         for (int j = 0; j < MAXC; j++) {
             const int k = k0 + j * (64 * NW);
             ed[j].active = false; ed[j].swap = false; ed[j].p1 = ed[j].p2 = ed[j].ea = ed[j].eb = ed[j].new1 = ed[j].new2 = 0;
-            hbits[j] = 0;
+            hw1[j] = hw2[j] = 0;
             if (j < cpw) { // block-uniform: the chunks beyond cpw of this instantiation cost nothing
                 int ty = -1, xa = 0, xb = 0;
                 if constexpr (GEN) sched_gen_exhaustive(e_lane, E, k, ty, xa, xb); // every lane takes part in the shuffle
                 else { ty = mtype[j]; xa = mma[j]; xb = mmb[j]; }
                 if (k >= nm) ty = -1;
                 ed[j] = sched_edit_of(e_lane, S, E, ty, xa, xb);
-                hbits[j] = sched_edit_hbits(in, ed[j]);
+                if (ed[j].active) { hw1[j] = sched_hol_word<M>(in, ed[j].new1); hw2[j] = sched_hol_word<M>(in, ed[j].new2); }
             }
         }
 #if defined(LS_NQ_STAMPS) && !defined(SCG_FINE)
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
             if (j < cpw) { // block-uniform
                 if (ed[j].active) {
                     int hard, soft;
-                    my_key[j] = sched_delta_key<M>(T, D, e_lane, ed[j], hbits[j], hard, soft, emp);
+                    my_key[j] = sched_delta_key<M>(T, D, e_lane, ed[j], sched_hbits_of<M>(in, ed[j], hw1[j], hw2[j]), hard, soft, emp);
                     if (my_key[j] < best_key) { best_key = my_key[j]; best_rel = tid + j * (64 * NW); }
                 }
                 my_bal[j] = __ballot(ed[j].active);

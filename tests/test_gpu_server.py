@@ -799,3 +799,36 @@ def test_more_slots_than_resident_workgroups_fall_back_to_launches(monkeypatch):
                 s.execute_round()
             assert (s.best(), s.stats()["ls_iterations"]) == g, seeds[r]
             s.close()
+
+
+def test_multi_sched_config5_size_sub_grids_equal_single_runs(monkeypatch):
+    # BASELINE config 5 at its real size on ONE GPU: 10 000 employees x 31 days, holidays U{0..3}, window 65 536 (a stream prefix of
+    # 73 744 moves = 145 chunks), all 8 restarts side by side as the sub-grids of one resident launch (8 x 29 workgroups x 5 chunks).
+    # Every restart's best solution, LS-iteration and candidate counts equal its single ls_solver run on the launched pipeline.
+    import ls_amd
+    rng = np.random.default_rng(5)
+    E = 10_000
+    bits = np.zeros(E, dtype=np.uint64)
+    for e in range(E):
+        for d in rng.choice(31, size=int(rng.integers(0, 4)), replace=False):
+            bits[e] |= np.uint64(1) << np.uint64(int(d))
+    p = dict(SCHED_EXAMPLE, window_size=65_536)
+    rounds = 12
+    seeds = [str(42 + r) for r in range(8)]
+    monkeypatch.setenv("LS_SCHED_SERVER", "0")
+    with ls_amd.Context(0) as c0:
+        single = [_single_sched_run(c0, 31, 0, E, sd, p, bits, rounds) for sd in seeds]
+        assert c0.counters()["server_requests"] == 0
+    monkeypatch.setenv("LS_SCHED_SERVER", "1")
+    with ls_amd.Context(0) as c:
+        m = ls_amd.MultiSolver.scheduling(c, 31, 0, E, seeds, p, holiday_bits=bits, n_slots=8)
+        m.run(max_rounds_per_restart=rounds)
+        cnt = m.counters()
+        for r in range(8):
+            st = m.restart_stats(r)
+            assert (m.best(r), st["ls_iterations"], st["neighbours_scored"], st["rounds"]) == single[r], seeds[r]
+        assert cnt["server_requests"] >= m.stats()["ls_iterations"] and cnt["completion_word_fallbacks"] == 0
+        # a second run of the same object reuses the launch object and the slot contexts
+        m.run(max_rounds_per_restart=rounds)
+        assert all((m.best(r), m.restart_stats(r)["ls_iterations"]) == (single[r][0], single[r][1]) for r in range(8))
+        m.close()
