@@ -103,6 +103,8 @@ def parse(route, err):
                     out["service_shader_cycles"], out["shader_clock_GHz"] = int(m2.group(1)), float(m2.group(2))
         if route == "sched_server_kernel" and ln.startswith("scheduling step server"):
             m = re.search(r"answer wait ([\d.]+) us per step \(whole call ([\d.]+) us\)", ln)
+            if not m:
+                continue  # (the line of the single-state scores)
             out.update(answer_wait_us=float(m.group(1)), call_us=float(m.group(2)))
             if "workgroup, after the request was seen" in nxt:
                 f = floats_after(nxt)
@@ -111,6 +113,8 @@ def parse(route, err):
                 out["service_us"] = f[4]
         if route.startswith("sched_grid") and ln.startswith("scheduling grid"):
             m = re.search(r"(\d+) workgroups x (\d+) chunks\): (\d+) requests, answer wait ([\d.]+) us per request \(whole call ([\d.]+) us\)", ln)
+            if not m:
+                continue
             out.update(workgroups=int(m.group(1)), chunks_per_workgroup=int(m.group(2)), requests=int(m.group(3)),
                        answer_wait_us=float(m.group(4)), call_us=float(m.group(5)))
             if "the finisher, after it saw the request" in nxt:
