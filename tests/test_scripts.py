@@ -18,7 +18,7 @@ def test_script_compiles(path, tmp_path):
     py_compile.compile(path, cfile=str(tmp_path / "x.pyc"), doraise=True)
 
 
-@pytest.mark.parametrize("rel", ["bench.py", "tools/run_config4.py", "tools/run_config5.py", "tools/step_latency.py",
+@pytest.mark.parametrize("rel", ["bench.py", "tools/run_config4.py", "tools/run_config5.py", "tools/multi_sched_trace.py",
                                  "examples/nqueens.py", "examples/employee_scheduling.py"])
 def test_help_needs_no_gpu(rel):
     r = subprocess.run([sys.executable, os.path.join(ROOT, rel), "--help"], capture_output=True, text=True, timeout=300)
