@@ -40,6 +40,11 @@ struct ls_multi_solver {
     int32_t sc_days_scored = 0, sc_start_weekday = 0, sc_employees = 0;
     std::vector<uint64_t> sc_holidays;
     std::vector<ScoredSolution<SchedProblem>> sc_best;
+    // every restart's proposer stream, drawn at creation like ls_solver_create_sched's (set-up, not part of a run: the stream is a
+    // clone of the restart's LocalSearch generator in its seed state, lib.rs:488 -- the same list whenever it is drawn), and the
+    // generator behind it, should a run ask for a longer prefix.  Empty: the restart draws its own when it starts.
+    std::vector<std::vector<ls_sched_move>> sc_streams;
+    std::vector<ChaCha20Rng> sc_stream_rng;
     // the resident launch the slots share and the slots' contexts: made by the first run, kept for later runs (pinned memory, a
     // stream on its own hardware queue), released by ls_multi_solver_free; the launch itself leaves at the end of every run
     lsamd::SchedStepServer *sc_step = nullptr;
@@ -353,10 +358,37 @@ int ls_multi_solver_create_sched(ls_ctx *ctx, int32_t n_days_scored, int32_t sta
         // 64 seeds: 16 / 32 / 64 / 128 slots on 16 cores -> 1.7 / 3.0 / 2.5 / 3.0-3.6 x 10^8 neighbours/s, the last with 256 seeds)
         const unsigned hw = usable_cores();
         m->n_slots = (int)(2 * hw > 256 ? 256 : (2 * hw < 1 ? 1 : 2 * hw));
+        {   // the restarts' streams (at most 256 MiB of them), by as many threads as there are cores
+            const long long want = SchedProblem::list_prefix(params->window_size, n_employees);
+            const long long each = want + want / 16;
+            if (params->all_solution_iteration_expiry >= 1 && want > 0 && want < (1ll << 24) &&
+                each * (long long)sizeof(ls_sched_move) * n_restarts <= (256ll << 20)) {
+                m->sc_streams.resize((size_t)n_restarts);
+                m->sc_stream_rng.resize((size_t)n_restarts);
+                std::atomic<int> next{0};
+                auto draw = [&]() {
+                    for (int r = next.fetch_add(1); r < n_restarts; r = next.fetch_add(1)) {
+                        SchedProblem pr(ctx, n_days_scored, n_days_scored + 1, n_employees);
+                        pr.extend_stream(ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]), (size_t)each);
+                        m->sc_streams[(size_t)r] = std::move(pr.stream);
+                        m->sc_stream_rng[(size_t)r] = pr.stream_rng;
+                    }
+                };
+                const int n_thr = (int)(hw < (unsigned)n_restarts ? hw : (unsigned)n_restarts);
+                if (n_thr <= 1 || each < 4096) draw();
+                else {
+                    std::vector<std::thread> th;
+                    for (int i = 0; i < n_thr; i++) th.emplace_back(draw);
+                    for (auto &t : th) t.join();
+                }
+            }
+        }
         *out = m.release();
         return LS_OK;
     });
 }
+
+static int multi_sched_setup(ls_multi_solver *m);
 
 int ls_multi_solver_configure(ls_multi_solver *m, int32_t n_slots, int32_t mode)
 {
@@ -370,6 +402,7 @@ int ls_multi_solver_configure(ls_multi_solver *m, int32_t n_slots, int32_t mode)
     }
     m->n_slots = n_slots;
     m->mode = mode;
+    if (m->kind == 1) return guarded(m->ctx, [&]() { (void)multi_sched_setup(m); return LS_OK; }); // set-up, not part of a run
     return LS_OK;
 }
 
@@ -641,10 +674,38 @@ int ls_host_rng_script(const uint8_t seed32[32], const int64_t *ops, int64_t n_o
 // reference example's window 100), or sub-grid t of the grid (sched_grid.hip: longer lists, config 5's window 65 536) -- so no
 // slot ever waits for another and nothing is launched per LS iteration.  When neither fits (too many slots for the device, a
 // window between the two) every slot's context takes its own routes.
-static int multi_run_sched(ls_multi_solver *m, uint64_t max_rounds_per_restart, double max_seconds)
+// The slots of a scheduling run and what they share: how many restarts are in flight (the device may hold fewer workgroups / sub-grids
+// side by side than n_slots asks for), the resident launch's host object, one light context per slot.  Made once per slot count --
+// by ls_multi_solver_configure, or by the first run -- and kept; the launch itself starts with a run's first request.
+static int multi_sched_setup(ls_multi_solver *m)
 {
     const int R = (int)m->seeds.size();
     int T = m->n_slots < R ? m->n_slots : R;
+    const ls_solver_params &p = m->params;
+    ls_ctx *base = m->ctx;
+    const long long want = SchedProblem::list_prefix(p.window_size, m->sc_employees); // the list prefix an LS iteration asks for (SchedProblem::best_of_neighbourhood)
+    const bool resident = base->sched_server_on && base->sched_delta && m->sc_employees <= 32768 && p.all_solution_iteration_expiry >= 1;
+    if (resident && want <= 512) {
+        const int cap = lsamd::sched_step_max_slots(base);
+        if (T > cap) T = cap;
+    } else if (resident) {
+        while (T > 1 && !lsamd::sched_grid_fits(base, T, false, want)) T--; // as many sub-grids as the device holds side by side
+    }
+    if (m->sc_slots_made != T) { // (first time, or another slot count: the shared launch is sized by it)
+        m->sc_release();
+        if (resident && want <= 512) check_rc(base, lsamd::sched_step_create(base, T, &m->sc_step), "scheduling LS-step server");
+        else if (resident && lsamd::sched_grid_fits(base, T, false, want)) check_rc(base, lsamd::sched_grid_create(base, T, false, want, &m->sc_grid), "scheduling grid");
+        m->sc_slot_ctx.assign((size_t)T, nullptr);
+        for (int t = 1; t < T; t++) check_rc(base, lsamd::ctx_clone_light(base, &m->sc_slot_ctx[(size_t)t]), "context for a slot"); // (the instance is base's: create_sched uploaded it)
+        m->sc_slots_made = T;
+    }
+    return T;
+}
+
+static int multi_run_sched(ls_multi_solver *m, uint64_t max_rounds_per_restart, double max_seconds)
+{
+    const int R = (int)m->seeds.size();
+    int T = 0;
     const ls_solver_params &p = m->params;
     ls_ctx *base = m->ctx;
     static const bool trace = getenv("LS_AMD_TRACE") != nullptr;
@@ -654,26 +715,11 @@ static int multi_run_sched(ls_multi_solver *m, uint64_t max_rounds_per_restart, 
         ~Phase() { if (on) fprintf(stderr, "multi-restart scheduling run: set-up %.2f ms, restarts %.2f ms, tear-down %.2f ms\n", setup * 1e3, run * 1e3,
                                    (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - setup - run) * 1e3); }
     } phase{T_begin, trace};
-    const long long want = SchedProblem::list_prefix(p.window_size, m->sc_employees); // the list prefix an LS iteration asks for (SchedProblem::best_of_neighbourhood)
-    const bool resident = base->sched_server_on && base->sched_delta && m->sc_employees <= 32768 && p.all_solution_iteration_expiry >= 1;
-    if (resident && want <= 512) {
-        const int cap = lsamd::sched_step_max_slots(base);
-        if (T > cap) T = cap;
-    } else if (resident) {
-        while (T > 1 && !lsamd::sched_grid_fits(base, T, false, want)) T--; // as many sub-grids as the device holds side by side
-    }
     // the caller's own resident launches (earlier single-solver calls on this context) leave now instead of 2 ms from now: the
     // shared launch may need every CU
     if (base->sched_step && base->sched_step_owned) lsamd::sched_step_pause(base->sched_step);
     if (base->sched_grid && base->sched_grid_owned) lsamd::sched_grid_pause(base->sched_grid);
-    if (m->sc_slots_made != T) { // (first run, or another slot count: the shared launch is sized by it)
-        m->sc_release();
-        if (resident && want <= 512) check_rc(base, lsamd::sched_step_create(base, T, &m->sc_step), "scheduling LS-step server");
-        else if (resident && lsamd::sched_grid_fits(base, T, false, want)) check_rc(base, lsamd::sched_grid_create(base, T, false, want, &m->sc_grid), "scheduling grid");
-        m->sc_slot_ctx.assign((size_t)T, nullptr);
-        for (int t = 1; t < T; t++) check_rc(base, lsamd::ctx_clone_light(base, &m->sc_slot_ctx[(size_t)t]), "context for a slot"); // (the instance is base's: create_sched uploaded it)
-        m->sc_slots_made = T;
-    }
+    T = multi_sched_setup(m); // (made by ls_multi_solver_configure already, or by an earlier run: then this is a comparison)
     struct Shared { lsamd::SchedStepServer *step; lsamd::SchedGrid *grid; } shared{m->sc_step, m->sc_grid};
     struct LeaveAtEnd { // the resident launch leaves with the run (it would idle out by itself 2 ms later)
         Shared &s;
@@ -704,6 +750,11 @@ static int multi_run_sched(ls_multi_solver *m, uint64_t max_rounds_per_restart, 
                 if (r >= R || stop.load()) break;
                 ctx->steps_done = 0; // the new restart's scheduling priority starts over
                 SchedProblem problem(ctx, m->sc_days_scored, m->sc_days_scored + 1, m->sc_employees);
+                if ((size_t)r < m->sc_streams.size() && !m->sc_streams[(size_t)r].empty()) { // drawn at creation (a copy: the solver may run again)
+                    problem.stream = m->sc_streams[(size_t)r];
+                    problem.stream_rng = m->sc_stream_rng[(size_t)r];
+                    problem.stream_started = true;
+                }
                 const ChaCha20Rng solver_rng = ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]); // lib.rs:58-62
                 const ChaCha20Rng ils_rng = ChaCha20Rng::from_seed_string(m->seeds[(size_t)r]);    // lib.rs:94
                 LocalSearch<SchedProblem> ls(&problem, p.local_search_max_iterations, (size_t)p.window_size, (size_t)p.best_solutions_capacity,

@@ -268,23 +268,52 @@ template <> struct SchedMaskOps<u64> {
     static __device__ __forceinline__ int msb(u64 x) { return 63 - __clzll((long long)x); }
 };
 
-// the base state of one restart, tabulated in LDS
+// the base state of one restart, tabulated in LDS.  One ROW per stored day -- everything the scorer needs of an edited day in two
+// (three: 64-day masks) 16-byte reads whose addresses follow from the edit alone, so a candidate issues all its reads but one
+// (the H4 | S1 values of an arbitrary employee's first day) before it waits for any.
+template <typename M> struct SchedDayRow;
+template <> struct alignas(16) SchedDayRow<unsigned> {
+    unsigned eq;   // scored days worked by the employee of day d
+    unsigned adj;  // scored days paired with day d by H2 / H3 (0 for an unscored day)
+    unsigned wd;   // scored days on the weekday of day d (0: weekend or unscored)
+    unsigned gh;   // F14 | F7 << 8 of eq | holiday bit of (employee of day d, day d) << 16
+    unsigned gb[3]; // the weekday group of day d: bit i: i + 1 of its days held by at least 1 / 2 / 3 employees
+    unsigned gsv;  // days of the group | its S2 value in the base state << 16
+};
+template <> struct alignas(16) SchedDayRow<u64> {
+    u64 eq, adj;
+    u64 wd;
+    unsigned gh, pad;
+    unsigned gb[3];
+    unsigned gsv;
+};
 template <typename M> struct SchedBaseTab {
-    int e[64];             // employee of stored day d (a distinct negative id beyond the stored days)
-    M eq[64];              // scored days worked by the employee of day d
-    M adj[64];             // scored days paired with day d by H2 / H3 (0 for an unscored day)
-    M wd[64];              // scored days on the weekday of day d (0: weekend or unscored)
-    unsigned short g[64];  // F14 | F7 << 8 of eq[d]
-    unsigned char hol[64]; // holiday bit of (employee of day d, day d)
-    // the three range terms: which values are held by at least 1 / 2 / 3 employees
+    SchedDayRow<M> row[64];
+    // the two range terms over all employees: which values are held by at least 1 / 2 / 3 employees
     u64 tot_b[3];          // bit i: scored-day count i + 1
     unsigned wk_b[3];      // bit i: i weekend days (among the employees present)
-    unsigned grp_b[7][3];  // weekday residue r, bit i: i + 1 of its days
-    int grp_size[7];       // days of the weekday group (0: weekend residue)
-    int grp_v[7];          // S2 value of the group in the base state
     M valid7, valid14, weekend;
     int hard, soft_s1, soft_s2; // base hard score; S1 and S2 of the base state
 };
+// the table's wavefront-uniform part, in scalar registers: read once per request, not once per candidate
+template <typename M> struct SchedBaseUni {
+    u64 tot_b[3];
+    unsigned wk_b[3];
+    M valid7, valid14, weekend;
+    int hard, soft12;
+};
+__device__ __forceinline__ unsigned sc_uniform(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ u64 sc_uniform(u64 x) { return ((u64)sc_uniform((unsigned)(x >> 32)) << 32) | sc_uniform((unsigned)x); }
+template <typename M> __device__ __forceinline__ SchedBaseUni<M> sched_base_uniforms(const SchedBaseTab<M> &T)
+{
+    SchedBaseUni<M> U;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { U.tot_b[i] = sc_uniform(T.tot_b[i]); U.wk_b[i] = sc_uniform(T.wk_b[i]); }
+    U.valid7 = sc_uniform(T.valid7); U.valid14 = sc_uniform(T.valid14); U.weekend = sc_uniform(T.weekend);
+    U.hard = (int)sc_uniform((unsigned)T.hard);
+    U.soft12 = (int)sc_uniform((unsigned)(T.soft_s1 + T.soft_s2));
+    return U;
+}
 
 // number of 7-day / 14-day windows (starting at the bits of valid7 / valid14) in which mask m holds more than
 // 2 / more than 3 days: bit-sliced sliding sums 1 -> 2 -> 4, 3 -> 7 -> 14
@@ -382,12 +411,10 @@ __device__ __forceinline__ void sched_build_base_tab(const SchedInst &in, int pa
         const M valid7 = D >= 7 ? (M)(L.scored_mask >> 6) : 0, valid14 = D >= 14 ? (M)(L.scored_mask >> 13) : 0;
         int f7, f14;
         sched_window_counts<M>(eq, valid7, valid14, f7, f14);
-        T.e[lane] = e;
-        T.eq[lane] = eq;
-        T.adj[lane] = (M)L.adj;
-        T.wd[lane] = wdm;
-        T.g[lane] = (unsigned short)(f14 | (f7 << 8));
-        T.hol[lane] = (unsigned char)hol;
+        T.row[lane].eq = eq;
+        T.row[lane].adj = (M)L.adj;
+        T.row[lane].wd = wdm;
+        T.row[lane].gh = (unsigned)(f14 | (f7 << 8) | (hol << 16)); // F14 <= 51, F7 <= 58
         int hard_l = 0, soft_l = 0;
         if (scored) hard_l = hol + O::popc(eq & (M)(L.mask2 | L.h3mask));
         if (rep) { hard_l += f14; soft_l = f7; }
@@ -422,22 +449,23 @@ __device__ __forceinline__ void sched_build_base_tab(const SchedInst &in, int pa
         wave_value_sets_u32(gr < 3 ? g_onehot : 0, g0[0], g0[1], g0[2]);
         wave_value_sets_u32(gr >= 3 && gr < 6 ? g_onehot : 0, g1[0], g1[1], g1[2]);
         wave_value_sets_u32(gr == 6 ? g_onehot : 0, g2[0], g2[1], g2[2]);
+        // every lane writes the group of ITS day's weekday into its row (lanes 0..6 are the first days of their residues: the S2 sum is theirs)
         int v = 0;
-        if (lane < 7) {
-            const int sh = 10 * (lane % 3);
+        {
+            const int sh = 10 * (gr % 3);
             unsigned gb[3];
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                gb[i] = ((lane < 3 ? g0[i] : (lane < 6 ? g1[i] : g2[i])) >> sh) & 0x3ffu;
-                T.grp_b[lane][i] = gb[i];
+                gb[i] = ((gr < 3 ? g0[i] : (gr < 6 ? g1[i] : g2[i])) >> sh) & 0x3ffu;
+                T.row[lane].gb[i] = gb[i];
             }
-            const int gsize = (L.flags & 2) ? L.gsize : 0; // lanes 0..6 are the first days of their residues
+            const int gsize = L.gsize; // popcount of the lane's weekday mask: 0 on weekend and unscored lanes
             if (gsize > 0) {
                 const int mn = __ffs((int)gb[0]); // smallest per-employee count on this weekday
                 if (mn < gsize) v = mn;
             }
-            T.grp_size[lane] = gsize;
-            T.grp_v[lane] = v;
+            T.row[lane].gsv = (unsigned)gsize | ((unsigned)v << 16);
+            if (lane >= 7) v = 0;
         }
         const int s2 = wave_sum_i32(v);
         if (lane == 0) T.soft_s2 = s2;
@@ -461,67 +489,67 @@ __device__ __forceinline__ B sched_replace_values(const B *b, bool hXo, int vXo,
 }
 
 // (hard, soft) of one candidate; o1 / o2 = base employees of p1 / p2, n1 = new employee of p1, hbits = holiday bits
-// of (n1, p1) | (n2, p2) << 1.  Only called for well-formed, non-tabu candidates.
+// of (n1, p1) | (n2, p2) << 1.  Only called for well-formed, non-tabu candidates (p2 == p1 for a ChangeDay).
 template <typename M>
-__device__ __forceinline__ void sched_delta_score(const SchedBaseTab<M> &T, int e_lane, int D, bool swap, int p1, int p2, int n1,
-                                                  int hbits, int &hard_out, int &soft_out, const M *emp = nullptr)
+__device__ __forceinline__ void sched_delta_score(const SchedBaseTab<M> &T, const SchedBaseUni<M> &U, int e_lane, int D, bool swap, int p1, int p2,
+                                                  int n1, int hbits, int &hard_out, int &soft_out, const M *emp = nullptr)
 {
     typedef SchedMaskOps<M> O;
-    const M bit1 = p1 < D ? (M)1 << p1 : 0, bit2 = (swap && p2 < D) ? (M)1 << p2 : 0;
-    const M mX = T.eq[p1];
-    const int gX = T.g[p1];
-    M mY;
-    int gY;
-    if (swap) {
-        mY = T.eq[p2];
-        gY = T.g[p2];
-    } else if (emp) {
-        mY = emp[n1]; // the day set of an arbitrary employee, from the block's employee -> scored-days table
-        gY = mY ? T.g[O::lsb(mY)] : 0;
-    } else {
-        mY = 0; // ... or by comparing with every scored day (e_lane: lane d holds day d)
+    // every read whose address the edit gives, before anything waits
+    const SchedDayRow<M> r1 = T.row[p1];
+    const SchedDayRow<M> r2 = T.row[p2];
+    M mYe = 0;
+    if (emp) mYe = emp[n1]; // the day set of an arbitrary employee, from the block's employee -> scored-days table
+    else {                  // ... or by comparing with every scored day (e_lane: lane d holds day d)
 #pragma unroll
         for (int d = 0; d < (int)sizeof(M) * 8; d++)
-            if (d < D && __builtin_amdgcn_readlane(e_lane, d) == n1) mY |= (M)1 << d;
-        gY = mY ? T.g[O::lsb(mY)] : 0;
+            if (d < D && __builtin_amdgcn_readlane(e_lane, d) == n1) mYe |= (M)1 << d;
     }
+    const M bit1 = p1 < D ? (M)1 << p1 : 0, bit2 = (swap && p2 < D) ? (M)1 << p2 : 0;
+    const M mX = r1.eq;
+    const M mY = swap ? r2.eq : mYe;
+    // the one dependent read: H4 | S1 of Y's day set, kept with its first day
+    const int iy = swap ? p2 : (mY ? O::lsb(mY) : 0);
+    const unsigned ghY = T.row[iy].gh;
+    const int gX = (int)(r1.gh & 0xffffu);
     const M mXn = (mX & ~bit1) | bit2, mYn = (mY & ~bit2) | bit1;
-    const M A1 = T.adj[p1], A2 = swap ? T.adj[p2] : 0;
+    const M A1 = r1.adj, A2 = swap ? r2.adj : 0;
     int f7X, f14X, f7Y, f14Y;
-    sched_window_counts<M>(mXn, T.valid7, T.valid14, f7X, f14X);
-    sched_window_counts<M>(mYn, T.valid7, T.valid14, f7Y, f14Y);
-    int hard = T.hard + (hbits & 1) - T.hol[p1];
-    if (swap) hard += ((hbits >> 1) & 1) - T.hol[p2];
+    sched_window_counts<M>(mXn, U.valid7, U.valid14, f7X, f14X);
+    sched_window_counts<M>(mYn, U.valid7, U.valid14, f7Y, f14Y);
+    int hard = U.hard + (hbits & 1) - (int)((r1.gh >> 16) & 1u);
+    if (swap) hard += ((hbits >> 1) & 1) - (int)((r2.gh >> 16) & 1u);
     hard += O::popc(A1 & mYn) - O::popc(A1 & mX) + O::popc(A2 & mXn) - O::popc(A2 & mY);
-    hard += f14X + f14Y - (gX & 0xff) - (gY & 0xff);
-    int soft = T.soft_s1 + T.soft_s2 + f7X + f7Y - (gX >> 8) - (gY >> 8);
+    int soft = U.soft12 + f7X + f7Y - (gX >> 8);
+    hard += f14X + f14Y - (gX & 0xff);
     const int cX = O::popc(mX), cY = O::popc(mY), cXn = O::popc(mXn), cYn = O::popc(mYn);
     const bool hXo = cX > 0, hYo = cY > 0, hXn = cXn > 0, hYn = cYn > 0;
     {   // S3: day counts (value index = count - 1)
-        const u64 b = sched_replace_values<u64>(T.tot_b, hXo, cX - 1, hYo, cY - 1, hXn, cXn - 1, hYn, cYn - 1);
+        const u64 b = sched_replace_values<u64>(U.tot_b, hXo, cX - 1, hYo, cY - 1, hXn, cXn - 1, hYn, cYn - 1);
         soft += (63 - __clzll((long long)b)) - (__ffsll((long long)b) - 1);
     }
     {   // S4: weekend-day counts of the employees present
-        const M wk = T.weekend;
-        const unsigned b = sched_replace_values<unsigned>(T.wk_b, hXo, O::popc(mX & wk), hYo, O::popc(mY & wk), hXn,
+        const M wk = U.weekend;
+        const unsigned b = sched_replace_values<unsigned>(U.wk_b, hXo, O::popc(mX & wk), hYo, O::popc(mY & wk), hXn,
                                                           O::popc(mXn & wk), hYn, O::popc(mYn & wk));
         soft += (31 - __clz((int)b)) - (__ffs((int)b) - 1);
     }
     // S2: the weekday groups of the edited days
-    const M G1 = T.wd[p1], G2 = swap ? T.wd[p2] : 0;
+    const M G1 = r1.wd, G2 = swap ? r2.wd : 0;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const M G = i == 0 ? G1 : G2;
         if (G == 0 || (i == 1 && G == G1)) continue;
-        const int r = (i == 0 ? p1 : p2) % 7;
+        const SchedDayRow<M> &r = i == 0 ? r1 : r2;
         const int a = O::popc(mX & G), b = O::popc(mY & G), an = O::popc(mXn & G), bn = O::popc(mYn & G);
-        const unsigned bits = sched_replace_values<unsigned>(T.grp_b[r], a > 0, a - 1, b > 0, b - 1, an > 0, an - 1,
-                                                             bn > 0, bn - 1);
+        const unsigned bits = sched_replace_values<unsigned>(r.gb, a > 0, a - 1, b > 0, b - 1, an > 0, an - 1, bn > 0, bn - 1);
         const int mn = __ffs((int)bits);
-        soft += (mn < T.grp_size[r] ? mn : 0) - T.grp_v[r];
+        soft += (mn < (int)(r.gsv & 0xffffu) ? mn : 0) - (int)(r.gsv >> 16);
     }
-    hard_out = hard;
-    soft_out = soft;
+    // (the late read last)
+    const int gY = (swap || mY) ? (int)(ghY & 0xffffu) : 0;
+    hard_out = hard - (gY & 0xff);
+    soft_out = soft - (gY >> 8);
 }
 
 // one candidate of a delta kernel: its edit, and whether it is a real (well-formed, non-tabu) candidate.
@@ -574,8 +602,8 @@ template <typename M> __device__ __forceinline__ int sched_hbits_of(const SchedI
 
 // the argmin key of an active candidate (and its scores)
 template <typename M>
-__device__ __forceinline__ u64 sched_delta_key(const SchedBaseTab<M> &T, int D, int e_lane, const SchedEdit &ed, int hbits, int &hard,
-                                               int &soft, const M *emp = nullptr)
+__device__ __forceinline__ u64 sched_delta_key(const SchedBaseTab<M> &T, const SchedBaseUni<M> &U, int D, int e_lane, const SchedEdit &ed, int hbits,
+                                               int &hard, int &soft, const M *emp = nullptr)
 {
     u64 e1, e2 = (u64)1 << 21; // "no second edit" sorts between lowering and raising edits
     if (!ed.swap) e1 = sc_edit_key(ed.p1, ed.new1, ed.ea);
@@ -584,8 +612,16 @@ __device__ __forceinline__ u64 sched_delta_key(const SchedBaseTab<M> &T, int D, 
         e1 = a_first ? sc_edit_key(ed.p1, ed.new1, ed.ea) : sc_edit_key(ed.p2, ed.new2, ed.eb);
         e2 = a_first ? sc_edit_key(ed.p2, ed.new2, ed.eb) : sc_edit_key(ed.p1, ed.new1, ed.ea);
     }
-    sched_delta_score<M>(T, e_lane, D, ed.swap, ed.p1, ed.p2, ed.new1, hbits, hard, soft, emp);
+    sched_delta_score<M>(T, U, e_lane, D, ed.swap, ed.p1, ed.p2, ed.new1, hbits, hard, soft, emp);
     return ((u64)(unsigned)hard << 54) | ((u64)(unsigned)soft << 46) | (e1 << 23) | e2;
+}
+// (one candidate per lane and request: the uniforms are read on the way)
+template <typename M>
+__device__ __forceinline__ u64 sched_delta_key(const SchedBaseTab<M> &T, int D, int e_lane, const SchedEdit &ed, int hbits, int &hard, int &soft,
+                                               const M *emp = nullptr)
+{
+    const SchedBaseUni<M> U = sched_base_uniforms<M>(T);
+    return sched_delta_key<M>(T, U, D, e_lane, ed, hbits, hard, soft, emp);
 }
 
 // candidate k of the exhaustive ScheduleMoveProposer (lib.rs:493-559), generated in place: day d = k / E,

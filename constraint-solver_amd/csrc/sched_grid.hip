@@ -240,6 +240,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
 #ifndef SCG_FINE
         SCG_STAMP(2);
 #endif
+        const SchedBaseUni<M> U = sched_base_uniforms<M>(T); // the table's uniform part, once per request
         u64 best_key = SC_KEY_EMPTY;
         int best_rel = 0; // position of the lane's best candidate, relative to the workgroup's first
         u64 my_key[MAXC], my_bal[MAXC]; // this lane's own candidates: what the finisher needs if the window cuts ITS chunks
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
             if (j < cpw) { // block-uniform
                 if (ed[j].active) {
                     int hard, soft;
-                    my_key[j] = sched_delta_key<M>(T, D, e_lane, ed[j], sched_hbits_of<M>(in, ed[j], hw1[j], hw2[j]), hard, soft, emp);
+                    my_key[j] = sched_delta_key<M>(T, U, D, e_lane, ed[j], sched_hbits_of<M>(in, ed[j], hw1[j], hw2[j]), hard, soft, emp);
                     if (my_key[j] < best_key) { best_key = my_key[j]; best_rel = tid + j * (64 * NW); }
                 }
                 my_bal[j] = __ballot(ed[j].active);
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                     const int rank = before + __popcll(bal & ((2ull << lane) - 1)); // 1-based among the workgroup's real candidates
                     if (e2.active && rank <= need) {
                         int hard, soft;
-                        const u64 key2 = sched_delta_key<M>(T, D, e_lane, e2, hb2, hard, soft, emp);
+                        const u64 key2 = sched_delta_key<M>(T, U, D, e_lane, e2, hb2, hard, soft, emp);
                         if (key2 < fkey || (key2 == fkey && kk < fidx)) { fkey = key2; fidx = kk; }
                     }
                 }

@@ -362,7 +362,7 @@ class MultiSolver:
             ctx._check(self._l.ls_multi_solver_create_sched(ctx._h, int(n_days_scored), int(start_weekday), int(n_employees), _vp(hb),
                                                             len(self.seeds), C.cast(arr, C.c_void_p), C.byref(p), C.byref(h)))
         self._h = h
-        if n_slots is not None or mode is not None:
+        if _sched is not None or n_slots is not None or mode is not None:  # (scheduling: configure also makes the slots' shared launch object)
             ctx._check(self._l.ls_multi_solver_configure(h, int(n_slots or 0), self.MODES[mode or "free"]))
 
     @classmethod

@@ -369,7 +369,9 @@ int ls_multi_solver_create_sched(ls_ctx *ctx, int32_t n_days_scored, int32_t sta
                                  const ls_solver_params *params, ls_multi_solver **out);
 /* n_slots in [1, 256], or 0 for the mode's default (default: four per core the process may use; free-running slots beyond the cores share host
  * threads as cooperative fibres: a slot whose launch is in flight lends its thread to a slot with host work to do;
- * lockstep slots are one host thread each), mode as above; call before ls_multi_solver_run. */
+ * lockstep slots are one host thread each), mode as above; call before ls_multi_solver_run.  For a scheduling solver the call also
+ * makes what the slots share -- the resident launch's host object, a light context per slot -- which the first run would make otherwise
+ * (set-up, like ls_solver_create_sched's, not part of a run). */
 int ls_multi_solver_configure(ls_multi_solver *m, int32_t n_slots, int32_t mode);
 int ls_multi_solver_run(ls_multi_solver *m, uint64_t max_rounds_per_restart, double max_seconds);
 int ls_multi_solver_get_best(const ls_multi_solver *m, int32_t restart, int64_t score[2], int64_t *solution,
