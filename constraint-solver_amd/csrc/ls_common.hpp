@@ -340,6 +340,25 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x)
     return ((unsigned long long)mh << 32) | ml;
 }
 
+// The same over lanes 0..7 only (one value per wavefront of a 512-thread block, the other lanes hold the identity): three steps;
+// returned wave-uniform from lane 0.
+__device__ __forceinline__ unsigned wave_min8_u32(unsigned x)
+{
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0"
+                 : "+v"(x));
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 0);
+}
+__device__ __forceinline__ unsigned long long wave_min8_u64(unsigned long long x)
+{
+    const unsigned hi = (unsigned)(x >> 32);
+    const unsigned mh = wave_min8_u32(hi);
+    const unsigned ml = wave_min8_u32(hi == mh ? (unsigned)x : 0xffffffffu);
+    return ((unsigned long long)mh << 32) | ml;
+}
+
 #endif // __HIPCC__
 
 } // namespace lsamd

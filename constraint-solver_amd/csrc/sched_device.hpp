@@ -587,10 +587,16 @@ __device__ __forceinline__ int sched_edit_hbits(const SchedInst &in, const Sched
 // The same in two steps, for kernels that have several candidates per lane in flight: the holiday WORDS of the two new employees
 // are fetched first (the loads of all candidates are issued before anything waits for one), the bits are taken when they are
 // needed.  M = unsigned (<= 32 days): the low half of the 64-bit word is all there is to read.
-template <typename M> __device__ __forceinline__ M sched_hol_word(const SchedInst &in, int employee)
+// (hol: a resident workgroup's copy of the words in LDS, or nullptr -- the gather then goes to global memory)
+template <typename M> __device__ __forceinline__ M sched_hol_word(const SchedInst &in, int employee, const M *hol = nullptr)
 {
     if ((unsigned)employee >= (unsigned)in.n_employees) return 0;
-    return reinterpret_cast<const M *>(in.holiday_bits + employee)[0];
+    return hol ? hol[employee] : reinterpret_cast<const M *>(in.holiday_bits + employee)[0];
+}
+template <typename M> __device__ __forceinline__ int sched_holiday_bit_of(const SchedInst &in, int employee, int day, const M *hol)
+{
+    if ((unsigned)day >= (unsigned)in.D) return 0;
+    return (int)((sched_hol_word<M>(in, employee, hol) >> day) & 1);
 }
 template <typename M> __device__ __forceinline__ int sched_hbits_of(const SchedInst &in, const SchedEdit &ed, M w1, M w2)
 {
@@ -684,7 +690,23 @@ constexpr int SCS_CHUNK = 64 * SCS_NW;
 
 // Dynamic LDS for a resident workgroup's employee -> scored-days table (one mask per employee), or 0 when it does not fit
 // beside the static LDS of the kernel (160 KB per CU on gfx950): the scorers then compare day by day.
-static inline size_t sched_emp_table_bytes(const ls_ctx *ctx, const void *fn, bool m32, size_t cap = (size_t)96 << 10)
+// The same with a copy of the instance's holiday words behind it (one M per employee: the gathers of a request's holiday bits
+// become LDS reads), when both fit under `cap`: *hol_entries = n_employees then, else 0 and the table alone as below.
+static inline size_t sched_emp_table_bytes(const ls_ctx *ctx, const void *fn, bool m32, size_t cap = (size_t)96 << 10);
+static inline size_t sched_lds_tables_bytes(const ls_ctx *ctx, const void *fn, bool m32, size_t cap_both, size_t cap_emp, int *hol_entries)
+{
+    *hol_entries = 0;
+    const size_t one = (size_t)ctx->sched.n_employees * (m32 ? 4 : 8);
+    if (one != 0 && 2 * one <= cap_both) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * one)) == hipSuccess) {
+            *hol_entries = ctx->sched.n_employees;
+            return 2 * one;
+        }
+        (void)hipGetLastError();
+    }
+    return sched_emp_table_bytes(ctx, fn, m32, cap_emp);
+}
+static inline size_t sched_emp_table_bytes(const ls_ctx *ctx, const void *fn, bool m32, size_t cap)
 {
     const size_t dyn = (size_t)ctx->sched.n_employees * (m32 ? 4 : 8);
     if (dyn == 0 || dyn > cap) return 0;

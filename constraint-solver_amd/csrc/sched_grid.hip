@@ -54,6 +54,7 @@ struct SchedGridArgs {
     int G;                       // workgroups per sub-grid
     int cpw;                     // chunks per workgroup (consecutive ones)
     int emp_entries;             // entries of the workgroup's employee -> scored-days table in dynamic LDS (0: the scorers compare day by day)
+    int hol_entries;             // entries of the workgroup's copy of the holiday words behind it (0: the holiday bits are gathered from global memory)
 };
 
 __device__ __forceinline__ unsigned scg_tag8(unsigned tag16) { return tag16 % 255u + 1u; } // 1..255: never the 0 of a cleared record
@@ -91,6 +92,10 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
     extern __shared__ __align__(16) unsigned char s_dyn[];
     M *const emp = a.emp_entries > 0 ? reinterpret_cast<M *>(s_dyn) : nullptr;
     for (int i = tid; i < a.emp_entries; i += 64 * NW) emp[i] = 0;
+    // ... and the instance's holiday words (the low 32 days of each when M is 32 bits wide): a request's gathers of holiday bits --
+    // the state's own, every candidate's two -- are LDS reads instead of global loads the table build and the scorers wait for
+    M *const hol = a.hol_entries > 0 ? reinterpret_cast<M *>(s_dyn) + a.emp_entries : nullptr;
+    for (int i = tid; i < a.hol_entries; i += 64 * NW) hol[i] = (M)a.in.holiday_bits[i];
     if (tid == 0) s_quit = 0;
     SchedLaneConst L{};
     if (wib < 3) L = a.in.lane_tab[lane];
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                     // get_scored_solution of the message's state, by the wavefront-per-state scorer (sched_wave.hip's sched_score_kernel)
                     const int e1 = lane < S ? (int)s_req[SCG_STATE_AT + lane] : -1 - lane;
                     const u64 eq = sched_build_eq(D, e1) & L.scored_mask;
-                    const SchedScore r = sched_terms<false>(D, L, lane, eq, sched_holiday_bit(in, e1, lane));
+                    const SchedScore r = sched_terms<false>(D, L, lane, eq, sched_holiday_bit(in, e1, lane)); // (before the first barrier: not from the LDS copy)
                     unsigned pay = 0;
                     if (lane == 5) pay = (unsigned)r.hard;
                     else if (lane == 6) pay = (unsigned)r.soft;
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         const int fin = (int)s_req[5] < G ? (int)s_req[5] : 0; // the finisher of THIS request: the workgroup the host expects the window to cut
         const unsigned stream_id = s_req[6];
         const int e_lane = lane < S ? (int)s_req[SCG_STATE_AT + lane] : -1 - lane;
-        const int hol_base = wib == 0 ? sched_holiday_bit(in, e_lane, lane) : 0;
+        const int hol_base = wib == 0 ? sched_holiday_bit_of<M>(in, e_lane, lane, hol) : 0;
         if constexpr (!GEN) {
             if (stream_id != my_stream) { // block-uniform: a new restart on this sub-grid (or a relaunch): this lane's moves, once
                 static_assert(NW == 8, "srv_fetch_moves_512 moves one 512-move chunk");
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                 else { ty = mtype[j]; xa = mma[j]; xb = mmb[j]; }
                 if (k >= nm) ty = -1;
                 ed[j] = sched_edit_of(e_lane, S, E, ty, xa, xb);
-                if (ed[j].active) { hw1[j] = sched_hol_word<M>(in, ed[j].new1); hw2[j] = sched_hol_word<M>(in, ed[j].new2); }
+                if (ed[j].active) { hw1[j] = sched_hol_word<M>(in, ed[j].new1, hol); hw2[j] = sched_hol_word<M>(in, ed[j].new2, hol); }
             }
         }
 #if defined(LS_NQ_STAMPS) && !defined(SCG_FINE)
@@ -263,8 +268,8 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         // reduces the NW pairs itself (no second barrier, no serial walk)
         {
             const u64 wk = wave_min_u64(best_key);
-            const u64 wr = wave_min_u64(best_key == wk && wk != SC_KEY_EMPTY ? (u64)(unsigned)best_rel : ~0ull);
-            if (lane == 0) { s_wkey[wib] = wk; s_wrel[wib] = (unsigned)wr; }
+            const unsigned wr = wave_min_u32(best_key == wk && wk != SC_KEY_EMPTY ? (unsigned)best_rel : ~0u);
+            if (lane == 0) { s_wkey[wib] = wk; s_wrel[wib] = wr; }
         }
         SCG_FSTAMP(1);
         __syncthreads(); // the wavefronts' minima and the per-chunk counts are in LDS
@@ -273,8 +278,9 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         unsigned wg_rel;
         {
             const u64 k8 = lane < NW ? s_wkey[lane] : SC_KEY_EMPTY;
-            wg_key = wave_min_u64(k8);
-            wg_rel = (unsigned)wave_min_u64(lane < NW && k8 == wg_key ? (u64)s_wrel[lane] : ~0ull);
+            static_assert(NW == 8, "wave_min8: one value per wavefront in lanes 0..7");
+            wg_key = wave_min8_u64(k8);
+            wg_rel = wave_min8_u32(lane < NW && k8 == wg_key ? s_wrel[lane] : ~0u);
         }
         // real candidates per (chunk, wavefront) in candidate order, one per lane: the inclusive prefix gives the workgroup's total
         // and, for the finisher, the rank of every wavefront's first candidate (one LDS read and six DPP adds instead of MAXC x NW reads)
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                     else if (kk < nm) { ty = srv_sys_load(&stream[kk].type); xa = srv_sys_load(&stream[kk].a); xb = srv_sys_load(&stream[kk].b); }
                     if (kk >= nm) ty = -1;
                     const SchedEdit e2 = sched_edit_of(e_lane, S, E, ty, xa, xb);
-                    const int hb2 = sched_edit_hbits(in, e2);
+                    const int hb2 = sched_hbits_of<M>(in, e2, sched_hol_word<M>(in, e2.new1, hol), sched_hol_word<M>(in, e2.new2, hol));
                     const u64 bal = __ballot(e2.active);
                     __syncthreads(); // s_cnt is reused
                     if (lane == 0) s_cnt[wib] = __popcll(bal);
@@ -394,15 +400,15 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
             // the minimum (key, first position) over the lanes' candidates: the wavefronts' pairs through LDS, one barrier
             {
                 const u64 wk = wave_min_u64(fkey);
-                const u64 wr = wave_min_u64(fkey == wk && wk != SC_KEY_EMPTY ? (u64)(unsigned)fidx : ~0ull);
-                if (lane == 0) { s_wkey[wib] = wk; s_wrel[wib] = (unsigned)wr; }
+                const unsigned wr = wave_min_u32(fkey == wk && wk != SC_KEY_EMPTY ? (unsigned)fidx : ~0u);
+                if (lane == 0) { s_wkey[wib] = wk; s_wrel[wib] = wr; }
             }
             __syncthreads();
             SCG_STAMP(6);
             if (wib == 0) { // the answer: d0 has-move, d1-2 n_scored, d3-4 best_index, d5 hard, d6 soft, d7 the cut workgroup + 1 (0: none)
                 const u64 k8 = lane < NW ? s_wkey[lane] : SC_KEY_EMPTY;
-                const u64 akey = wave_min_u64(k8);
-                const unsigned aidx = (unsigned)wave_min_u64(lane < NW && k8 == akey ? (u64)s_wrel[lane] : ~0ull);
+                const u64 akey = wave_min8_u64(k8);
+                const unsigned aidx = wave_min8_u32(lane < NW && k8 == akey ? s_wrel[lane] : ~0u);
                 const bool has = akey != SC_KEY_EMPTY;
                 unsigned pay = 0;
                 if (lane == 0) pay = has ? 1u : 0u;
@@ -590,7 +596,8 @@ int sched_grid_create(ls_ctx *ctx, int n_sub, bool gen, long long capacity, Sche
         a.G = s->G; a.cpw = s->cpw;
         const bool m32 = sched_m32(ctx);
         const void *fn = grid_fn(m32, s->gen, s->maxc);
-        const size_t dyn = sched_emp_table_bytes(ctx, fn, m32); // the employee -> scored-days table (one workgroup per CU: it has the LDS to itself)
+        // the employee -> scored-days table and the holiday words (one workgroup per CU: it has the LDS to itself)
+        const size_t dyn = sched_lds_tables_bytes(ctx, fn, m32, (size_t)144 << 10, (size_t)96 << 10, &a.hol_entries);
         a.emp_entries = dyn ? ctx->sched.n_employees : 0;
         void *args[] = {&a};
         return hipLaunchKernel(fn, dim3((unsigned)(s->n_sub * s->G)), dim3(64 * SCS_NW), args, dyn, s->h.stream);

@@ -34,6 +34,7 @@ struct SchedSrvArgs {
     const ls_sched_move *streams; // pinned host: [n_slots][SCS_CHUNK] the slots' move streams
     const int *shadow;            // pinned host: [n_slots][64] the state of each slot's current request
     int emp_entries;              // entries of the employee -> scored-days table in dynamic LDS (0: none)
+    int hol_entries;              // entries of the copy of the holiday words behind it (0: gathered from global memory)
 };
 
 template <typename M, int NW>
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
     const ls_sched_move *stream = a.streams + (size_t)slot * (64 * NW);
     __shared__ SchedBaseTab<M> T;
     __shared__ u64 s_key[NW];
-    __shared__ long long s_idx[NW];
+    __shared__ unsigned s_idx[NW];
     __shared__ int s_wcnt[NW];
     __shared__ unsigned s_req[16];
     __shared__ int s_state[64];
@@ -60,6 +61,9 @@ __global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
     extern __shared__ __align__(16) unsigned char s_dyn[];
     M *const emp = a.emp_entries > 0 ? reinterpret_cast<M *>(s_dyn) : nullptr;
     for (int i = tid; i < a.emp_entries; i += 64 * NW) emp[i] = 0;
+    M *const hol = a.hol_entries > 0 ? reinterpret_cast<M *>(s_dyn) + a.emp_entries : nullptr; // (sched_grid.hip: the holiday words beside it)
+    for (int i = tid; i < a.hol_entries; i += 64 * NW) hol[i] = (M)a.in.holiday_bits[i];
+    if (a.hol_entries > 0) __syncthreads(); // (a request's first use may come before any other barrier)
     SchedLaneConst L{};
     if (wib < 3) L = a.in.lane_tab[lane];
     int mtype = -1, mma = 0, mmb = 0; // this lane's move of the slot's stream
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
         }
         if (fresh) __syncthreads();
         const int e_lane = lane < S ? s_state[lane] : -1 - lane;
-        const int hol_base = wib == 0 ? sched_holiday_bit(a.in, e_lane, lane) : 0;
+        const int hol_base = wib == 0 ? sched_holiday_bit_of<M>(a.in, e_lane, lane, hol) : 0;
         if (!eval) { // block-uniform: the state's own score, by the wavefront-per-state scorer (sched_score_kernel, sched_wave.hip)
             if (wib == 0) {
                 const u64 eq = sched_build_eq(D, e_lane) & L.scored_mask;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
         const SchedEdit ed = sched_edit_of(e_lane, S, E, k < nm ? mtype : -1, mma, mmb);
         const u64 bal = __ballot(ed.active);
         if (lane == 0) s_wcnt[wib] = __popcll(bal);
-        const int hbits = sched_edit_hbits(a.in, ed);
+        const int hbits = sched_hbits_of<M>(a.in, ed, sched_hol_word<M>(a.in, ed.new1, hol), sched_hol_word<M>(a.in, ed.new2, hol));
         if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T, emp);
         __syncthreads();
         SCS_STAMP(2);
@@ -129,24 +133,28 @@ __global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
         }
         const long long rank = before + __popcll(bal & ((2ull << lane) - 1)); // 1-based among the real candidates
         u64 best_key = SC_KEY_EMPTY;
-        long long best_idx = -1;
+        unsigned best_idx = ~0u; // position in the list (< 512)
         if (ed.active && rank <= window) {
             int hard, soft;
             best_key = sched_delta_key<M>(T, D, e_lane, ed, hbits, hard, soft, emp);
-            best_idx = k;
+            best_idx = (unsigned)k;
         }
         SCS_STAMP(3);
-        // block minimum; the winner's lane leaves its move where wavefront 0 finds it
-        sched_wave_min_key(best_key, best_idx);
-        if (lane == 0) { s_key[wib] = best_key; s_idx[wib] = best_idx; }
+        // block minimum (key, first position): the wavefronts' pairs through LDS, one barrier, then EVERY wavefront reduces the NW
+        // pairs itself; the winner's lane leaves its move where wavefront 0 finds it
+        {
+            const u64 wk = wave_min_u64(best_key);
+            const unsigned wi = wave_min_u32(best_key == wk && wk != SC_KEY_EMPTY ? best_idx : ~0u);
+            if (lane == 0) { s_key[wib] = wk; s_idx[wib] = wi; }
+        }
         __syncthreads();
         {
-            u64 bk = lane < NW ? s_key[lane] : SC_KEY_EMPTY;
-            long long bi = lane < NW ? s_idx[lane] : -1;
-            sched_wave_min_key(bk, bi); // every wavefront: the block's winner
-            best_key = bk; best_idx = bi;
+            static_assert(NW == 8, "wave_min8: one value per wavefront in lanes 0..7");
+            const u64 k8 = lane < NW ? s_key[lane] : SC_KEY_EMPTY;
+            best_key = wave_min8_u64(k8);
+            best_idx = wave_min8_u32(lane < NW && k8 == best_key ? s_idx[lane] : ~0u);
         }
-        if (best_idx == k && best_key != SC_KEY_EMPTY) { s_win[0] = mtype; s_win[1] = mma; s_win[2] = mmb; }
+        if (best_idx == (unsigned)k && best_key != SC_KEY_EMPTY) { s_win[0] = mtype; s_win[1] = mma; s_win[2] = mmb; }
         SCS_STAMP(4);
         if (wib == 0) {
             if (emp && lane < D && e_lane >= 0) emp[e_lane] = 0; // every scorer is past the barrier above: the table is all zero again
@@ -205,7 +213,8 @@ static const void *step_fn(bool m32)
 int sched_step_max_slots(ls_ctx *ctx)
 {
     const bool m32 = sched_m32(ctx);
-    const size_t dyn = sched_emp_table_bytes(ctx, step_fn(m32), m32, (size_t)40 << 10);
+    int hol_entries = 0;
+    const size_t dyn = sched_lds_tables_bytes(ctx, step_fn(m32), m32, (size_t)40 << 10, (size_t)40 << 10, &hol_entries);
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_fn(m32), 64 * SCS_NW, dyn) != hipSuccess) {
         (void)hipGetLastError();
@@ -238,7 +247,7 @@ int sched_step_create(ls_ctx *ctx, int n_slots, SchedStepServer **out)
         a.streams = s->stream(0);
         a.shadow = s->shadow(0);
         const bool m32 = sched_m32(ctx);
-        const size_t dyn = sched_emp_table_bytes(ctx, step_fn(m32), m32, (size_t)40 << 10);
+        const size_t dyn = sched_lds_tables_bytes(ctx, step_fn(m32), m32, (size_t)40 << 10, (size_t)40 << 10, &a.hol_entries);
         a.emp_entries = dyn ? ctx->sched.n_employees : 0;
         void *args[] = {&a};
         return hipLaunchKernel(step_fn(m32), dim3((unsigned)s->n_slots), dim3(64 * SCS_NW), args, dyn, s->h.stream);
