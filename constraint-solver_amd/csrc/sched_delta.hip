@@ -33,7 +33,8 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_delta_kernel(SchedEvalArgs
     __shared__ u64 s_key[NW];
     __shared__ long long s_idx[NW];
     SchedLaneConst L{};
-    if (wib < 3) L = a.in.lane_tab[lane];
+    static_assert(NW >= SCHED_TAB_PARTS, "the base table is built by SCHED_TAB_PARTS wavefronts side by side");
+    if (wib < SCHED_TAB_PARTS) L = a.in.lane_tab[lane];
     const long long k_end = a.k_end[r];
     const int e_lane = lane < S ? sched_state_at(a, r, lane) : -1 - lane;
     const int hol_base = wib == 0 ? sched_holiday_bit(a.in, e_lane, lane) : 0; // in flight until the table build needs it
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_delta_kernel(SchedEvalArgs
     }
     SchedEdit ed = sched_edit_of(e_lane, S, E, type, ma, mb);
     int hbits = sched_edit_hbits(a.in, ed);
-    if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T);
+    if (wib < SCHED_TAB_PARTS) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T);
     __syncthreads();
     u64 best_key = SC_KEY_EMPTY;
     long long best_idx = -1;
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_small_kernel(SchedEvalArgs
     __shared__ int s_wcnt[NW];
     LS_SC_STAMP(0);
     SchedLaneConst L{};
-    if (wib < 3) L = a.in.lane_tab[lane];
+    static_assert(NW >= SCHED_TAB_PARTS, "the base table is built by SCHED_TAB_PARTS wavefronts side by side");
+    if (wib < SCHED_TAB_PARTS) L = a.in.lane_tab[lane];
     const int e_lane = lane < S ? sched_state_at(a, r, lane) : -1 - lane;
     const int hol_base = wib == 0 ? sched_holiday_bit(a.in, e_lane, lane) : 0; // in flight until the table build needs it
     const long long nm = sched_nm(a, r);
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_small_kernel(SchedEvalArgs
     if (lane == 0) s_wcnt[wib] = __popcll(bal);
     const int hbits = sched_edit_hbits(a.in, ed);
     LS_SC_STAMP(2);
-    if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T);
+    if (wib < SCHED_TAB_PARTS) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T);
     LS_SC_STAMP(3);
     __syncthreads();
     LS_SC_STAMP(4);
@@ -169,7 +171,8 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_all_kernel(SchedEvalArgs a
     __shared__ int s_cnt[NW];
     LS_SC_STAMP(0);
     SchedLaneConst L{};
-    if (wib < 3) L = a.in.lane_tab[lane];
+    static_assert(NW >= SCHED_TAB_PARTS, "the base table is built by SCHED_TAB_PARTS wavefronts side by side");
+    if (wib < SCHED_TAB_PARTS) L = a.in.lane_tab[lane];
     const int e_lane = lane < S ? sched_state_at(a, r, lane) : -1 - lane;
     const int hol_base = wib == 0 ? sched_holiday_bit(a.in, e_lane, lane) : 0; // in flight until the table build needs it
     const long long nm = GEN ? a.max_moves : sched_nm(a, r);
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(64 * NW) void sched_eval_all_kernel(SchedEvalArgs a
         for (int i = (int)threadIdx.x; i < n16; i += 64 * NW) reinterpret_cast<uint4 *>(s_dyn)[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
     }
-    if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T, emp);
+    if (wib < SCHED_TAB_PARTS) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T, emp);
     LS_SC_STAMP(3);
     __syncthreads();
     LS_SC_STAMP(4);

@@ -293,7 +293,7 @@ template <typename M> struct SchedBaseTab {
     u64 tot_b[3];          // bit i: scored-day count i + 1
     unsigned wk_b[3];      // bit i: i weekend days (among the employees present)
     M valid7, valid14, weekend;
-    int hard, soft_s1, soft_s2; // base hard score; S1 and S2 of the base state
+    int hard, soft_s1, soft_s2[2]; // base hard score; S1 and S2 (weekday residues 0-2, 3-6) of the base state
 };
 // the table's wavefront-uniform part, in scalar registers: read once per request, not once per candidate
 template <typename M> struct SchedBaseUni {
@@ -311,7 +311,7 @@ template <typename M> __device__ __forceinline__ SchedBaseUni<M> sched_base_unif
     for (int i = 0; i < 3; i++) { U.tot_b[i] = sc_uniform(T.tot_b[i]); U.wk_b[i] = sc_uniform(T.wk_b[i]); }
     U.valid7 = sc_uniform(T.valid7); U.valid14 = sc_uniform(T.valid14); U.weekend = sc_uniform(T.weekend);
     U.hard = (int)sc_uniform((unsigned)T.hard);
-    U.soft12 = (int)sc_uniform((unsigned)(T.soft_s1 + T.soft_s2));
+    U.soft12 = (int)sc_uniform((unsigned)(T.soft_s1 + T.soft_s2[0] + T.soft_s2[1]));
     return U;
 }
 
@@ -380,11 +380,15 @@ __device__ __forceinline__ void wave_value_sets_u32(unsigned onehot, unsigned &b
     b3 = wave_or_u32(onehot & ex2);
 }
 
-// The table is filled by wavefronts 0, 1 and 2 of the block side by side (lane = day; each derives the day-equality
-// row of its lane first); the caller synchronises the block after.
-//   part 0: per-day rows (employee, day set, pair / weekday masks, H4 | S1 values, holiday bit), base hard score, S1
-//   part 1: S3 / S4 value sets (day counts, weekend-day counts)
-//   part 2: S2 value sets per weekday, group sizes and base values
+// The table is filled by the first SCHED_TAB_PARTS wavefronts of the block side by side -- one per SIMD: six wavefronts, two to a
+// SIMD, were measured slower in the grid (the LDS atomics of the day sets and the DPP chains queue behind each other) -- (lane = day;
+// each derives the day-equality row of its lane first), two DPP value-set chains per wavefront at most; the caller synchronises the
+// block after.
+//   part 0: per-day rows (day set, pair / weekday masks, H4 | S1 values, holiday bit), base hard score, S1
+//   part 1: S3 and S4 value sets (day counts, weekend-day counts)
+//   part 2: S2 value sets of the weekday residues 0-2, group sizes and base values into the rows of those days
+//   part 3: the same for residues 3-5 and 6
+constexpr int SCHED_TAB_PARTS = 4;
 template <typename M>
 __device__ __forceinline__ void sched_build_base_tab(const SchedInst &in, int part, int e /* employee of day `lane`; -1 - lane beyond S */,
                                                      int hol /* holiday bit of (e, lane), gathered by the caller (part 0) */,
@@ -441,22 +445,24 @@ __device__ __forceinline__ void sched_build_base_tab(const SchedInst &in, int pa
             T.wk_b[lane] = lane == 0 ? wk[0] : (lane == 1 ? wk[1] : wk[2]);
         }
     } else {
-        // weekday groups: residue r = lane % 7 occupies bits 10 * (r % 3) .. + 9 of word r / 3
+        // weekday groups: residue r = lane % 7 occupies bits 10 * (r % 3) .. + 9 of word r / 3; part 2 has word 0, part 3 words 1 and 2
         const int gr = lane % 7;
+        const bool mine = part == 2 ? gr < 3 : gr >= 3;
         unsigned g_onehot = 0;
-        if (wdm != 0 && (eq & wdm & low) == 0) g_onehot = 1u << (10 * (gr % 3) + O::popc(eq & wdm) - 1); // first day of its employee on this weekday
-        unsigned g0[3], g1[3], g2[3];
-        wave_value_sets_u32(gr < 3 ? g_onehot : 0, g0[0], g0[1], g0[2]);
-        wave_value_sets_u32(gr >= 3 && gr < 6 ? g_onehot : 0, g1[0], g1[1], g1[2]);
-        wave_value_sets_u32(gr == 6 ? g_onehot : 0, g2[0], g2[1], g2[2]);
-        // every lane writes the group of ITS day's weekday into its row (lanes 0..6 are the first days of their residues: the S2 sum is theirs)
+        if (mine && wdm != 0 && (eq & wdm & low) == 0) g_onehot = 1u << (10 * (gr % 3) + O::popc(eq & wdm) - 1); // first day of its employee on this weekday
+        unsigned g[3], g6[3] = {0, 0, 0};
+        wave_value_sets_u32(gr < 6 ? g_onehot : 0, g[0], g[1], g[2]);
+        if (part == 3 && __builtin_amdgcn_ballot_w64(gr == 6 && g_onehot != 0) != 0) // (residue 6 is a weekend day for four start weekdays of seven: no chain then)
+            wave_value_sets_u32(gr == 6 ? g_onehot : 0, g6[0], g6[1], g6[2]);
+        // every lane of these residues writes the group of ITS day's weekday into its row (lanes 0..6 are the first days of their residues:
+        // the S2 sum is theirs)
         int v = 0;
-        {
+        if (mine) {
             const int sh = 10 * (gr % 3);
             unsigned gb[3];
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                gb[i] = ((gr < 3 ? g0[i] : (gr < 6 ? g1[i] : g2[i])) >> sh) & 0x3ffu;
+                gb[i] = ((gr == 6 ? g6[i] : g[i]) >> sh) & 0x3ffu;
                 T.row[lane].gb[i] = gb[i];
             }
             const int gsize = L.gsize; // popcount of the lane's weekday mask: 0 on weekend and unscored lanes
@@ -468,7 +474,7 @@ __device__ __forceinline__ void sched_build_base_tab(const SchedInst &in, int pa
             if (lane >= 7) v = 0;
         }
         const int s2 = wave_sum_i32(v);
-        if (lane == 0) T.soft_s2 = s2;
+        if (lane == 0) T.soft_s2[part - 2] = s2;
     }
     LS_SC_STAMP(11);
 }
@@ -574,6 +580,31 @@ __device__ __forceinline__ SchedEdit sched_edit_of(int e_lane, int S, int E, int
     ed.new2 = type == 0 ? mb : ed.ea;
     ed.active = ok && !(ed.new1 == ed.ea && ed.new2 == ed.eb); // candidate != current (tabu, local_search.rs:319)
     return ed;
+}
+
+// The same with the state read from LDS (e[d] = employee of stored day d, d < S) instead of exchanged between the lanes: a
+// ds_bpermute costs the LDS crossbar a whole pass per wavefront -- two per candidate were 0.3 us per 512-candidate chunk in a
+// resident workgroup -- a ds_read_b32 of at most S consecutive dwords is conflict-free and ten times cheaper.
+template <typename T> __device__ __forceinline__ SchedEdit sched_edit_of_lds(const T *e, int S, int E, int type, int ma, int mb)
+{
+    SchedEdit ed;
+    const bool ok = sched_move_ok(type, ma, mb, S, E);
+    ed.swap = type == 1;
+    ed.p1 = ok ? ma : 0;
+    ed.p2 = (ok && type == 1) ? mb : ed.p1;
+    ed.ea = (int)e[ed.p1];
+    ed.eb = (int)e[ed.p2];
+    ed.new1 = type == 0 ? mb : ed.eb;
+    ed.new2 = type == 0 ? mb : ed.ea;
+    ed.active = ok && !(ed.new1 == ed.ea && ed.new2 == ed.eb);
+    return ed;
+}
+template <typename T> __device__ __forceinline__ void sched_gen_exhaustive_lds(const T *e, int S, int E, long long k, int &type, int &ma, int &mb)
+{
+    const unsigned d = (unsigned)k / (unsigned)E, i = (unsigned)k - d * (unsigned)E;
+    type = 0;
+    ma = (int)d;
+    mb = (int)(((unsigned)(d < (unsigned)S ? e[d] : 0) + 1u + i) % (unsigned)E);
 }
 
 // holiday bits of the edited days under their new employees: a gather from global memory that depends on the move

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
     for (int i = tid; i < a.hol_entries; i += 64 * NW) hol[i] = (M)a.in.holiday_bits[i];
     if (tid == 0) s_quit = 0;
     SchedLaneConst L{};
-    if (wib < 3) L = a.in.lane_tab[lane];
+    static_assert(NW >= SCHED_TAB_PARTS, "the base table is built by SCHED_TAB_PARTS wavefronts side by side");
+    if (wib < SCHED_TAB_PARTS) L = a.in.lane_tab[lane];
     const SchedInst &in = a.in;
     const int cpw = a.cpw;
     const int k0 = c * cpw * (64 * NW) + tid; // this lane's candidates: k0 + 512 j, j < cpw
@@ -222,25 +223,28 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
         // ---- this workgroup's chunks: the delta scorer, one candidate per lane and chunk
         SchedEdit ed[MAXC];
         M hw1[MAXC], hw2[MAXC]; // the holiday words of the candidates' new employees: all fetched before anything waits for one
+        // Straight-line over all MAXC chunks of the instantiation (a chunk beyond cpw has no moves: type -1, an inactive edit of day 0):
+        // with a branch per chunk every chunk's two lane exchanges and two holiday reads were a round trip of their own -- 0.4 us per
+        // chunk; now the exchanges of all chunks are in flight together, then the reads.
 #pragma unroll
         for (int j = 0; j < MAXC; j++) {
             const int k = k0 + j * (64 * NW);
-            ed[j].active = false; ed[j].swap = false; ed[j].p1 = ed[j].p2 = ed[j].ea = ed[j].eb = ed[j].new1 = ed[j].new2 = 0;
-            hw1[j] = hw2[j] = 0;
-            if (j < cpw) { // block-uniform: the chunks beyond cpw of this instantiation cost nothing
-                int ty = -1, xa = 0, xb = 0;
-                if constexpr (GEN) sched_gen_exhaustive(e_lane, E, k, ty, xa, xb); // every lane takes part in the shuffle
-                else { ty = mtype[j]; xa = mma[j]; xb = mmb[j]; }
-                if (k >= nm) ty = -1;
-                ed[j] = sched_edit_of(e_lane, S, E, ty, xa, xb);
-                if (ed[j].active) { hw1[j] = sched_hol_word<M>(in, ed[j].new1, hol); hw2[j] = sched_hol_word<M>(in, ed[j].new2, hol); }
-            }
+            int ty = -1, xa = 0, xb = 0;
+            if constexpr (GEN) sched_gen_exhaustive_lds(s_req + SCG_STATE_AT, S, E, k, ty, xa, xb);
+            else { ty = mtype[j]; xa = mma[j]; xb = mmb[j]; }
+            if (k >= nm || j >= cpw) ty = -1;
+            ed[j] = sched_edit_of_lds(s_req + SCG_STATE_AT, S, E, ty, xa, xb); // (the request's state, as every wavefront reads it for e_lane)
+        }
+#pragma unroll
+        for (int j = 0; j < MAXC; j++) {
+            hw1[j] = sched_hol_word<M>(in, ed[j].new1, hol);
+            hw2[j] = sched_hol_word<M>(in, ed[j].new2, hol);
         }
 #if defined(LS_NQ_STAMPS) && !defined(SCG_FINE)
         { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); gst[1] = wall_clock64(); }
 #endif
         if (tid == 0) { s_cut = -1; s_before = 0; }
-        if (wib < 3) sched_build_base_tab<M>(in, wib, e_lane, hol_base, L, lane, T, emp);
+        if (wib < SCHED_TAB_PARTS) sched_build_base_tab<M>(in, wib, e_lane, hol_base, L, lane, T, emp);
         __syncthreads();
 #ifndef SCG_FINE
         SCG_STAMP(2);
@@ -375,10 +379,10 @@ __global__ __launch_bounds__(64 * NW) void sched_grid_server_kernel(SchedGridArg
                 for (int j = 0; j < cpw && done < need; j++) { // block-uniform
                     const int kk = (cut * cpw + j) * (64 * NW) + tid;
                     int ty = -1, xa = 0, xb = 0;
-                    if constexpr (GEN) sched_gen_exhaustive(e_lane, E, kk, ty, xa, xb);
+                    if constexpr (GEN) sched_gen_exhaustive_lds(s_req + SCG_STATE_AT, S, E, kk, ty, xa, xb);
                     else if (kk < nm) { ty = srv_sys_load(&stream[kk].type); xa = srv_sys_load(&stream[kk].a); xb = srv_sys_load(&stream[kk].b); }
                     if (kk >= nm) ty = -1;
-                    const SchedEdit e2 = sched_edit_of(e_lane, S, E, ty, xa, xb);
+                    const SchedEdit e2 = sched_edit_of_lds(s_req + SCG_STATE_AT, S, E, ty, xa, xb);
                     const int hb2 = sched_hbits_of<M>(in, e2, sched_hol_word<M>(in, e2.new1, hol), sched_hol_word<M>(in, e2.new2, hol));
                     const u64 bal = __ballot(e2.active);
                     __syncthreads(); // s_cnt is reused

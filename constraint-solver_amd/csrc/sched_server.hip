@@ -65,7 +65,8 @@ __global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
     for (int i = tid; i < a.hol_entries; i += 64 * NW) hol[i] = (M)a.in.holiday_bits[i];
     if (a.hol_entries > 0) __syncthreads(); // (a request's first use may come before any other barrier)
     SchedLaneConst L{};
-    if (wib < 3) L = a.in.lane_tab[lane];
+    static_assert(NW >= SCHED_TAB_PARTS, "the base table is built by SCHED_TAB_PARTS wavefronts side by side");
+    if (wib < SCHED_TAB_PARTS) L = a.in.lane_tab[lane];
     int mtype = -1, mma = 0, mmb = 0; // this lane's move of the slot's stream
     unsigned lds_state = 0, my_stream = 0; // ids of the state in s_state / of the stream in the lanes (0: none); block-uniform
     SrvPoll poll{0, 0, 0};
@@ -118,11 +119,11 @@ __global__ __launch_bounds__(64 * NW) void sched_server_kernel(SchedSrvArgs a)
         }
         SCS_STAMP(1);
         const long long k = tid;
-        const SchedEdit ed = sched_edit_of(e_lane, S, E, k < nm ? mtype : -1, mma, mmb);
+        const SchedEdit ed = sched_edit_of_lds(s_state, S, E, k < nm ? mtype : -1, mma, mmb);
         const u64 bal = __ballot(ed.active);
         if (lane == 0) s_wcnt[wib] = __popcll(bal);
         const int hbits = sched_hbits_of<M>(a.in, ed, sched_hol_word<M>(a.in, ed.new1, hol), sched_hol_word<M>(a.in, ed.new2, hol));
-        if (wib < 3) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T, emp);
+        if (wib < SCHED_TAB_PARTS) sched_build_base_tab<M>(a.in, wib, e_lane, hol_base, L, lane, T, emp);
         __syncthreads();
         SCS_STAMP(2);
         int before = 0, total = 0;
