@@ -353,11 +353,13 @@ int ls_multi_solver_create_sched(ls_ctx *ctx, int32_t n_days_scored, int32_t sta
         }
         m->sc_best.resize((size_t)n_restarts);
         m->have.assign((size_t)n_restarts, 0);
-        // two restarts in flight per usable core: a scheduling LS iteration is ~1.5 us of host work around a ~4.5 us round trip, and
-        // more fibres per core than it takes to hide that only add switches and cache misses (measured on the example instance with
-        // 64 seeds: 16 / 32 / 64 / 128 slots on 16 cores -> 1.7 / 3.0 / 2.5 / 3.0-3.6 x 10^8 neighbours/s, the last with 256 seeds)
+        // eight restarts in flight per usable core (at most what one resident launch holds, multi_sched_setup): a scheduling LS iteration
+        // is ~1 us of host work around a ~4.5 us round trip, and the fibres of a core hide the one behind the other.  Measured on the
+        // example instance, 16 cores, 256 seeds: 64 / 96 / 128 / 256 slots -> 0.93 / 1.19 / 1.45 / 1.45 x 10^9 neighbours/s (64 seeds
+        // in 64 slots: 9.2 x 10^8).  (Before every slot's tag and request count had a cache line of their own -- srv_common.hpp --
+        // the same sweep peaked at 32 slots and 3.9 x 10^8.)
         const unsigned hw = usable_cores();
-        m->n_slots = (int)(2 * hw > 256 ? 256 : (2 * hw < 1 ? 1 : 2 * hw));
+        m->n_slots = (int)(8 * hw > 256 ? 256 : (8 * hw < 1 ? 1 : 8 * hw));
         {   // the restarts' streams (at most 256 MiB of them), by as many threads as there are cores
             const long long want = SchedProblem::list_prefix(params->window_size, n_employees);
             const long long each = want + want / 16;
@@ -397,7 +399,7 @@ int ls_multi_solver_configure(ls_multi_solver *m, int32_t n_slots, int32_t mode)
         return lsamd::set_err(m->ctx, LS_ERR_INVALID, "ls_multi_solver_configure: n_slots %d (0..256), mode %d", n_slots, mode);
     if (n_slots == 0) { // the mode's default: lockstep slots are host threads, free-running slots may share them
         const unsigned hw = usable_cores();
-        const unsigned want = mode == LS_MULTI_LOCKSTEP ? hw : (m->kind == 1 ? 2 * hw : 4 * hw);
+        const unsigned want = mode == LS_MULTI_LOCKSTEP ? hw : (m->kind == 1 ? 8 * hw : 4 * hw);
         n_slots = (int)(want > 256 ? 256 : (want < 1 ? 1 : want));
     }
     m->n_slots = n_slots;

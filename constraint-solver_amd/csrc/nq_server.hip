@@ -314,7 +314,7 @@ struct NqServer {
     size_t o_cols = 0, o_shadow = 0, o_cs = 0; // in h.extra(): cols_ext | shadow | cs16
     size_t lds = 0;
     std::atomic<unsigned long long> fresh_boards{0};
-    struct Slot {
+    struct alignas(64) Slot { // (a slot is one host thread's: no line shared with a neighbour)
         double t_pre = 0, t_wait = 0, t_post = 0; // LS_AMD_TRACE: where a call spends its time (host before / answer wait / host after)
         unsigned long long calls = 0, dev_ticks[6] = {0, 0, 0, 0, 0, 0}; // stamps builds: phase ends of the workgroup's service, shader cycles / 4
         unsigned board_id = 0;
@@ -338,7 +338,7 @@ int nq_server_slots(const NqServer *s) { return s->n_slots; }
 
 void nq_server_counters(const NqServer *s, unsigned long long out[4])
 {
-    out[0] = s->h.requests.load(); out[1] = s->h.relaunches.load(); out[2] = s->h.slow_waits.load(); out[3] = s->fresh_boards.load();
+    out[0] = s->h.requests_total(); out[1] = s->h.relaunches.load(); out[2] = s->h.slow_waits.load(); out[3] = s->fresh_boards.load();
 }
 
 static const void *server_fn(bool pairs)
@@ -561,7 +561,7 @@ int nq_server_finish(ls_ctx *ctx, NqServer *s, int slot, int64_t cur_score, cons
         sl.t_wait += sec(T1, T2); sl.t_post += sec(T2, T3);
         sl.calls++;
         const volatile unsigned *rl = s->h.resp(slot);
-        for (int d = 0; d < 6; d++) sl.dev_ticks[d] += (rl[7 + d] >> 16) == s->h.tags[(size_t)slot] ? rl[7 + d] & 0xffffu : 0u;
+        for (int d = 0; d < 6; d++) sl.dev_ticks[d] += (rl[7 + d] >> 16) == s->h.per[(size_t)slot].tag ? rl[7 + d] & 0xffffu : 0u;
     }
     return LS_OK;
 }

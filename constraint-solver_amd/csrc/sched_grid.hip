@@ -450,7 +450,7 @@ struct SchedGrid {
     bool go_direct = false;
     DevBuf rec;
     unsigned long long ready_total = 0;
-    struct Sub {
+    struct alignas(64) Sub { // (a sub-grid is one host thread's: no line shared with a neighbour)
         unsigned stream_id = 0;
         const ls_ctx *stream_ctx = nullptr;
         unsigned long long stream_gen = 0;
@@ -616,7 +616,7 @@ long long sched_grid_capacity(const SchedGrid *s) { return s->gen ? 0 : s->strea
 void sched_grid_pause(SchedGrid *s) { s->h.pause(); }
 void sched_grid_counters(const SchedGrid *s, unsigned long long out[3])
 {
-    out[0] = s->h.requests.load(); out[1] = s->h.relaunches.load(); out[2] = s->h.slow_waits.load();
+    out[0] = s->h.requests_total(); out[1] = s->h.relaunches.load(); out[2] = s->h.slow_waits.load();
 }
 
 static int grid_check_state(ls_ctx *ctx, const int32_t *state)
@@ -694,7 +694,7 @@ int sched_grid_eval(ls_ctx *ctx, SchedGrid *s, int sub, const int32_t *state, lo
         b.t_wait += std::chrono::duration<double>(T2 - T1).count();
         b.t_call += std::chrono::duration<double>(T2 - T0).count();
         const volatile unsigned *rl = s->h.resp(4 * sub);
-        for (int d = 0; d < 7; d++) b.dev_ticks[d] += (rl[8 + d] >> 16) == s->h.tags[(size_t)(4 * sub)] ? rl[8 + d] & 0xffffu : 0u;
+        for (int d = 0; d < 7; d++) b.dev_ticks[d] += (rl[8 + d] >> 16) == s->h.per[(size_t)(4 * sub)].tag ? rl[8 + d] & 0xffffu : 0u;
     }
     if (r[7] != 0) {
         if ((int)r[7] - 1 == b.fin) b.fin_hits++;

@@ -190,7 +190,7 @@ struct SchedStepServer {
     SrvHost h;
     ls_ctx *owner = nullptr;      // the context whose instance (holiday words, lane table) the launch carries
     int n_slots = 0;
-    struct Slot {
+    struct alignas(64) Slot { // (a slot is one host thread's: no line shared with a neighbour)
         unsigned state_id = 0, stream_id = 0;
         bool valid = false;
         const ls_ctx *stream_ctx = nullptr;   // whose list, and which generation of it, the slot's pinned block holds
@@ -285,7 +285,7 @@ int sched_step_slots(const SchedStepServer *s) { return s->n_slots; }
 void sched_step_pause(SchedStepServer *s) { for (auto &sl : s->slots) sl.valid = false; s->h.pause(); }
 void sched_step_counters(const SchedStepServer *s, unsigned long long out[3])
 {
-    out[0] = s->h.requests.load(); out[1] = s->h.relaunches.load(); out[2] = s->h.slow_waits.load();
+    out[0] = s->h.requests_total(); out[1] = s->h.relaunches.load(); out[2] = s->h.slow_waits.load();
 }
 
 // the state of this request versus what the slot's workgroup holds: a new one is range-checked, copied to the pinned shadow, gets a new id
@@ -388,7 +388,7 @@ int sched_step_eval(ls_ctx *ctx, SchedStepServer *s, int slot, const int32_t *st
         sl.t_call += std::chrono::duration<double>(T2 - T0).count();
         sl.calls++;
         const volatile unsigned *rl = s->h.resp(slot);
-        for (int d = 0; d < 5; d++) sl.dev_ticks[d] += (rl[8 + d] >> 16) == s->h.tags[(size_t)slot] ? rl[8 + d] & 0xffffu : 0u;
+        for (int d = 0; d < 5; d++) sl.dev_ticks[d] += (rl[8 + d] >> 16) == s->h.per[(size_t)slot].tag ? rl[8 + d] & 0xffffu : 0u;
     }
     return LS_OK;
 }

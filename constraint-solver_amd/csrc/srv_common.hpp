@@ -181,12 +181,26 @@ struct SrvHost {
     SrvCtl *ctl = nullptr;
     unsigned long long idle_ticks = 200000, limit_ticks = 200000000ull; // 2 ms, 2 s (100 MHz)
     std::mutex launch_mu;
-    std::atomic<unsigned long long> launch_gen{0};
-    std::atomic<unsigned long long> relaunches{0}, slow_waits{0}, requests{0};
+    // Many host threads use one SrvHost at once, a slot each (ls_multi_solver): what a slot's thread writes on every request -- its tag,
+    // its request count -- has a cache line of its own, and the launch generation every wait() reads is on a line nobody writes in
+    // the steady state.  (Tags of 16 slots in one line and one shared request counter cost a 16-thread run 2.7 us per call.)
+    struct alignas(64) PerSlot {
+        unsigned tag = 0;                 // last tag posted
+        unsigned long long requests = 0;  // requests posted (relaxed atomic accesses)
+    };
+    std::vector<PerSlot> per;
+    alignas(64) std::atomic<unsigned long long> launch_gen{0};
+    alignas(64) std::atomic<unsigned long long> relaunches{0};
+    std::atomic<unsigned long long> slow_waits{0};
+    unsigned long long requests_total() const
+    {
+        unsigned long long n = 0;
+        for (const PerSlot &p : per) n += __atomic_load_n(&p.requests, __ATOMIC_RELAXED);
+        return n;
+    }
     bool failed = false;
     unsigned relaunch_limit = 0;  // wait(): give up (SRV_RC_GIVE_UP) after this many relaunches under one request; 0: never
     double no_answer_seconds = 10.0; // wait(): an error after this long without an answer from a launch that has not drained
-    std::vector<unsigned> tags;   // last tag posted per slot
     std::function<hipError_t(const SrvLink &)> launch; // set by the owner: starts the resident kernel on `stream`
 
     // Request lines: pinned host memory, polled by the device over PCIe -- or, when the owner sets req_dev, fine-grained DEVICE
@@ -242,7 +256,7 @@ struct SrvHost {
             release();
             return set_err(ctx, LS_ERR_HIP, "%s: control block set-up failed: %s", what, hipGetErrorString(e));
         }
-        tags.assign((size_t)slots, 0u);
+        per.assign((size_t)slots, PerSlot());
         return LS_OK;
     }
     void release()
@@ -278,9 +292,10 @@ struct SrvHost {
     }
     unsigned next_tag(int slot)
     {
-        unsigned &t = tags[(size_t)slot];
-        t = t >= 0xfffeu ? 1u : t + 1u;
-        return t;
+        PerSlot &p = per[(size_t)slot];
+        p.tag = p.tag >= 0xfffeu ? 1u : p.tag + 1u;
+        __atomic_store_n(&p.requests, p.requests + 1, __ATOMIC_RELAXED); // (one writer: the slot's thread)
+        return p.tag;
     }
     void post(int slot, const unsigned pay[16])
     {
@@ -290,7 +305,6 @@ struct SrvHost {
         __atomic_thread_fence(__ATOMIC_RELEASE); // the bulk data is written before the line that announces it
         srv_store_line(req(slot), line);
         flush_lines();
-        requests.fetch_add(1, std::memory_order_relaxed);
     }
     // A message of n_lines consecutive lines starting at line `slot` (the scheduling grid: header + state), every dword under
     // ONE new tag; the reader accepts a snapshot only when all tags agree, so the order of the line stores does not matter.
@@ -302,7 +316,6 @@ struct SrvHost {
         __atomic_thread_fence(__ATOMIC_RELEASE);
         for (int l = n_lines - 1; l >= 0; l--) srv_store_line(req(slot + l), msg + 16 * l);
         flush_lines();
-        requests.fetch_add(1, std::memory_order_relaxed);
     }
     // QUIT to every reader (one per `lines_per_msg` lines), as a WHOLE message of that reader's size under one new tag
     void post_quit_all()
@@ -312,8 +325,8 @@ struct SrvHost {
         for (int i = 0; i + lines_per_msg <= n_slots; i += lines_per_msg) {
             if (lines_per_msg == 1) post(i, pay);
             else post_lines(i, pay, lines_per_msg);
+            __atomic_store_n(&per[(size_t)i].requests, per[(size_t)i].requests - 1, __ATOMIC_RELAXED); // not a request of a caller
         }
-        requests.fetch_sub((unsigned long long)(n_slots / lines_per_msg), std::memory_order_relaxed); // not requests of a caller
     }
     // the launch leaves now (its arguments are about to change, or memory is about to be released) and comes back on demand
     void pause()
@@ -328,13 +341,13 @@ struct SrvHost {
         // and its slot would have nobody until the whole launch has drained.
         if (asked)
             for (int i = 0; i + lines_per_msg <= n_slots; i += lines_per_msg)
-                __atomic_store_n(resp(i), tags[(size_t)i] << 16, __ATOMIC_RELAXED);
+                __atomic_store_n(resp(i), per[(size_t)i].tag << 16, __ATOMIC_RELAXED);
     }
     // Poll the slot's answer line for the tag of the request just posted (the same hooks as the completion-word wait of a
     // launched step: the caller's idle work, another restart's fibre, sched_yield).
     int wait(ls_ctx *ctx, int slot, unsigned out[8])
     {
-        const unsigned tag = tags[(size_t)slot];
+        const unsigned tag = per[(size_t)slot].tag;
         const volatile unsigned *r = resp(slot);
         struct Announce { // what this wait waits for, for a scheduler behind wait_hook
             ls_ctx *c;

@@ -135,14 +135,14 @@ int main()
             CHECK(H.h.drained());
         }
         CHECK(H.h.relaunches.load() >= 4);
-        CHECK(H.h.requests.load() == 6 * 3000);
+        CHECK(H.h.requests_total() == 6 * 3000);
         H.h.shutdown();
     }
     {   // 2. the 16-bit tag wraps (tags run 1 .. 0xfffe): > 65 534 requests on ONE slot, then across a relaunch
         Harness H;
         H.start(1, 1, 2000);
         for (unsigned i = 0; i < 70000; i++) request(H, &H.ctx, 0, i);
-        CHECK(H.h.tags[0] >= 1 && H.h.tags[0] <= 0xfffeu && H.h.tags[0] == 70000u - 0xfffeu);
+        CHECK(H.h.per[0].tag >= 1 && H.h.per[0].tag <= 0xfffeu && H.h.per[0].tag == 70000u - 0xfffeu);
         H.h.pause(); // QUIT: the launch leaves at once, not after the idle time
         CHECK(H.h.drained());
         for (unsigned i = 0; i < 100; i++) request(H, &H.ctx, 0, i); // comes back; the last served tag is read back from the answer line
