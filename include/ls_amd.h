@@ -367,7 +367,7 @@ int ls_multi_solver_create_nqueens(ls_ctx *ctx, uint64_t board_size, int32_t n_r
 int ls_multi_solver_create_sched(ls_ctx *ctx, int32_t n_days_scored, int32_t start_weekday, int32_t n_employees,
                                  const uint64_t *holiday_bits, int32_t n_restarts, const char *const *seeds,
                                  const ls_solver_params *params, ls_multi_solver **out);
-/* n_slots in [1, 256], or 0 for the mode's default (default: four per core the process may use; free-running slots beyond the cores share host
+/* n_slots in [1, 256], or 0 for the mode's default (default: four per core the process may use -- eight for a scheduling solver --; free-running slots beyond the cores share host
  * threads as cooperative fibres: a slot whose launch is in flight lends its thread to a slot with host work to do;
  * lockstep slots are one host thread each), mode as above; call before ls_multi_solver_run.  For a scheduling solver the call also
  * makes what the slots share -- the resident launch's host object, a light context per slot -- which the first run would make otherwise
