@@ -386,6 +386,7 @@ def _random_moves(rng, n, D, E):
 @pytest.mark.parametrize("dates,E", [(((2022, 5, 9), (2022, 6, 8)), 7),        # the example instance: 31 scored / 32 stored days
                                      (((2022, 5, 9), (2022, 7, 10)), 40),       # 63 / 64 days: the 64-bit day sets
                                      (((2022, 5, 11), (2022, 5, 24)), 3),       # 14 / 15 days, starts on a Wednesday
+                                     (((2022, 5, 9), (2022, 6, 8)), 8_000),     # the day-set table fits the slot's LDS, the holiday words do not
                                      (((2022, 5, 9), (2022, 6, 8)), 12_000)])   # too many employees for the LDS look-up table: day-by-day scorers
 def test_sched_server_follows_any_call_sequence(monkeypatch, dates, E):
     # ls_sched_eval_resident / ls_sched_score through the resident scheduling workgroup (no launch per call): continue from
@@ -750,12 +751,13 @@ def test_multi_sched_sub_grids_equal_single_runs(monkeypatch):
             m.close()
 
 
-def test_sched_exhaustive_grid_many_chunks_per_workgroup_day_by_day():
+@pytest.mark.parametrize("E", [26_000, 20_000])
+def test_sched_exhaustive_grid_many_chunks_per_workgroup_day_by_day(E):
     # 26 000 employees: 832 000 exhaustive candidates = 1 625 chunks, seven per workgroup (the eight-chunk instantiation), and
     # too many employees for the LDS look-up table (the scorers compare day by day).  Windows inside the first workgroups.
+    # 20 000 employees: the day-set table fits the LDS, the copy of the holiday words behind it does not (global gathers).
     import ls_amd
     rng = np.random.default_rng(88)
-    E = 26_000
     hol = {int(e): [int(rng.integers(0, 31))] for e in rng.choice(E, size=3000, replace=False)}
     inst = orc.Sched((2022, 5, 9), (2022, 6, 8), hol)
     D, S = inst.n_scored_days, inst.n_scored_days + 1
