@@ -197,6 +197,11 @@ __device__ __forceinline__ bool sched_counts(const SchedEvalArgs &a, const ls_sc
     return m.type == 0 ? (s_state[m.a] != m.b) : (s_state[m.a] != s_state[m.b]);
 }
 
+__device__ __forceinline__ unsigned sc_edit_key32(int pos, int newv, int basev) // the same value (it has 23 bits)
+{
+    const bool up = newv > basev;
+    return (up ? 2u << 21 : 0u) | ((unsigned)(up ? 63 - pos : pos) << 15) | (unsigned)newv;
+}
 __device__ __forceinline__ u64 sc_edit_key(int pos, int newv, int basev)
 {
     const int up = newv > basev;
@@ -290,14 +295,14 @@ template <> struct alignas(16) SchedDayRow<u64> {
 template <typename M> struct SchedBaseTab {
     SchedDayRow<M> row[64];
     // the two range terms over all employees: which values are held by at least 1 / 2 / 3 employees
-    u64 tot_b[3];          // bit i: scored-day count i + 1
+    M tot_b[3];            // bit i: scored-day count i + 1 (a count is at most the number of scored days: it fits the day mask's type)
     unsigned wk_b[3];      // bit i: i weekend days (among the employees present)
     M valid7, valid14, weekend;
     int hard, soft_s1, soft_s2[2]; // base hard score; S1 and S2 (weekday residues 0-2, 3-6) of the base state
 };
 // the table's wavefront-uniform part, in scalar registers: read once per request, not once per candidate
 template <typename M> struct SchedBaseUni {
-    u64 tot_b[3];
+    M tot_b[3];
     unsigned wk_b[3];
     M valid7, valid14, weekend;
     int hard, soft12;
@@ -429,19 +434,19 @@ __device__ __forceinline__ void sched_build_base_tab(const SchedInst &in, int pa
             T.soft_s1 = hs >> 16;
         }
     } else if (part == 1) {
-        u64 tot_onehot = 0;
+        M tot_onehot = 0;
         unsigned wk_onehot = 0;
         if (rep) {
-            tot_onehot = 1ull << (O::popc(eq) - 1);
+            tot_onehot = (M)1 << (O::popc(eq) - 1);
             wk_onehot = 1u << O::popc(eq & weekend);
         }
         unsigned tl[3], th[3] = {0, 0, 0}, wk[3];
         wave_value_sets_u32((unsigned)tot_onehot, tl[0], tl[1], tl[2]);
-        if (sizeof(M) > 4) wave_value_sets_u32((unsigned)(tot_onehot >> 32), th[0], th[1], th[2]);
+        if (sizeof(M) > 4) wave_value_sets_u32((unsigned)((u64)tot_onehot >> 32), th[0], th[1], th[2]);
         wave_value_sets_u32(wk_onehot, wk[0], wk[1], wk[2]);
         if (lane < 3) {
             const unsigned lo = lane == 0 ? tl[0] : (lane == 1 ? tl[1] : tl[2]), hi = lane == 0 ? th[0] : (lane == 1 ? th[1] : th[2]);
-            T.tot_b[lane] = ((u64)hi << 32) | lo;
+            T.tot_b[lane] = (M)(((u64)hi << 32) | lo);
             T.wk_b[lane] = lane == 0 ? wk[0] : (lane == 1 ? wk[1] : wk[2]);
         }
     } else {
@@ -531,8 +536,8 @@ __device__ __forceinline__ void sched_delta_score(const SchedBaseTab<M> &T, cons
     const int cX = O::popc(mX), cY = O::popc(mY), cXn = O::popc(mXn), cYn = O::popc(mYn);
     const bool hXo = cX > 0, hYo = cY > 0, hXn = cXn > 0, hYn = cYn > 0;
     {   // S3: day counts (value index = count - 1)
-        const u64 b = sched_replace_values<u64>(U.tot_b, hXo, cX - 1, hYo, cY - 1, hXn, cXn - 1, hYn, cYn - 1);
-        soft += (63 - __clzll((long long)b)) - (__ffsll((long long)b) - 1);
+        const M b = sched_replace_values<M>(U.tot_b, hXo, cX - 1, hYo, cY - 1, hXn, cXn - 1, hYn, cYn - 1);
+        soft += O::msb(b) - O::lsb(b);
     }
     {   // S4: weekend-day counts of the employees present
         const M wk = U.weekend;
@@ -642,15 +647,14 @@ template <typename M>
 __device__ __forceinline__ u64 sched_delta_key(const SchedBaseTab<M> &T, const SchedBaseUni<M> &U, int D, int e_lane, const SchedEdit &ed, int hbits,
                                                int &hard, int &soft, const M *emp = nullptr)
 {
-    u64 e1, e2 = (u64)1 << 21; // "no second edit" sorts between lowering and raising edits
-    if (!ed.swap) e1 = sc_edit_key(ed.p1, ed.new1, ed.ea);
-    else {
-        const bool a_first = ed.p1 < ed.p2;
-        e1 = a_first ? sc_edit_key(ed.p1, ed.new1, ed.ea) : sc_edit_key(ed.p2, ed.new2, ed.eb);
-        e2 = a_first ? sc_edit_key(ed.p2, ed.new2, ed.eb) : sc_edit_key(ed.p1, ed.new1, ed.ea);
-    }
+    // the edits' keys (sc_edit_key: 23 bits each) and the whole key in 32-bit halves, by selects: no 64-bit shifts, no divergent branch
+    const unsigned k1 = sc_edit_key32(ed.p1, ed.new1, ed.ea), k2 = sc_edit_key32(ed.p2, ed.new2, ed.eb);
+    const bool a_first = ed.p1 < ed.p2;
+    const unsigned e1 = (!ed.swap || a_first) ? k1 : k2;
+    const unsigned e2 = !ed.swap ? 1u << 21 : (a_first ? k2 : k1); // "no second edit" sorts between lowering and raising edits
     sched_delta_score<M>(T, U, e_lane, D, ed.swap, ed.p1, ed.p2, ed.new1, hbits, hard, soft, emp);
-    return ((u64)(unsigned)hard << 54) | ((u64)(unsigned)soft << 46) | (e1 << 23) | e2;
+    const unsigned hi = ((unsigned)hard << 22) | ((unsigned)soft << 14) | (e1 >> 9), lo = (e1 << 23) | e2; // hard << 54 | soft << 46 | e1 << 23 | e2
+    return ((u64)hi << 32) | lo;
 }
 // (one candidate per lane and request: the uniforms are read on the way)
 template <typename M>
