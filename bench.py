@@ -336,7 +336,7 @@ def run_rank(args, rank, world, device, sync, launcher):
                 ms = ex.get("config3_multi_restart_end_to_end") or {}
                 flat.update({"c3_x64_e2e_per_s": ms.get("neighbours_per_s"), "c3_x64_e2e_equal": ms.get("equal_single_solver_runs")})
                 m5 = ex.get("config5_multi_restart_end_to_end") or {}
-                flat.update({"c5_x8_e2e_s": m5.get("seconds"), "c5_x8_over_single": m5.get("wall_over_single_restart"),
+                flat.update({"c5_x8_e2e_s": m5.get("seconds"), "c5_x8_e2e_per_s": m5.get("neighbours_per_s"), "c5_x8_over_single": m5.get("wall_over_single_restart"),
                              "c5_x8_e2e_equal": m5.get("equal_single_solver_runs")})
                 roof.update({k: v for k, v in flat.items() if v is not None})
                 if "cpu_baseline" in out and c5.get("one_core_per_s"):
