@@ -284,7 +284,9 @@ __global__ __launch_bounds__(1024) void nq_server_kernel(NqSrvArgs a)
             stamp[5] = wall_clock64();
             if (lane >= 7 && lane < 12) { const unsigned long long dt = stamp[lane - 6] - stamp[0]; pay = dt > 0xffffu ? 0xffffu : (unsigned)dt; } // d7..d11: phase ends, 10 ns ticks
             if (lane == 12) { const unsigned long long dc = (__builtin_amdgcn_s_memtime() - cyc0) >> 2; pay = dc > 0xffffu ? 0xffffu : (unsigned)dc; } // d12: shader cycles / 4 of the service
-            if (lane >= 8 && lane < 13) __hip_atomic_store(resp + lane, (poll.last_tag << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane == 13) pay = poll.n_polls > 0xffffu ? 0xffffu : poll.n_polls;                                                                   // d13: polls this request took
+            if (lane == 14) { const unsigned long long g = stamp[0] - poll.t_served; pay = g > 0xffffu ? 0xffffu : (unsigned)g; }                    // d14: idle gap before it, 10 ns ticks
+            if (lane >= 8 && lane < 15) __hip_atomic_store(resp + lane, (poll.last_tag << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
             if (lane < 8) __hip_atomic_store(resp + lane, (poll.last_tag << 16) | (pay & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             srv_served(poll, a.link, lane);
@@ -316,7 +318,7 @@ struct NqServer {
     std::atomic<unsigned long long> fresh_boards{0};
     struct alignas(64) Slot { // (a slot is one host thread's: no line shared with a neighbour)
         double t_pre = 0, t_wait = 0, t_post = 0; // LS_AMD_TRACE: where a call spends its time (host before / answer wait / host after)
-        unsigned long long calls = 0, dev_ticks[6] = {0, 0, 0, 0, 0, 0}; // stamps builds: phase ends of the workgroup's service, shader cycles / 4
+        unsigned long long calls = 0, dev_ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // stamps builds: phase ends of the workgroup's service, shader cycles / 4
         unsigned board_id = 0;
         bool valid = false, cs_valid = false;
         bool want_cs = false; // the request in flight asked the workgroup for the column scores (post -> finish)
@@ -424,10 +426,10 @@ void nq_server_destroy(NqServer *s)
     if (!s) return;
     if (getenv("LS_AMD_TRACE")) {
         double pre = 0, wait = 0, post = 0;
-        unsigned long long calls = 0, ticks[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long calls = 0, ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (const auto &sl : s->slots) {
             pre += sl.t_pre; wait += sl.t_wait; post += sl.t_post; calls += sl.calls;
-            for (int d = 0; d < 6; d++) ticks[d] += sl.dev_ticks[d];
+            for (int d = 0; d < 8; d++) ticks[d] += sl.dev_ticks[d];
         }
         if (calls) {
             fprintf(stderr, "ls step server (n = %d, %d slots): %llu steps, per step: host before %.2f us, answer wait %.2f us, host after %.2f us; %llu launches, "
@@ -436,6 +438,9 @@ void nq_server_destroy(NqServer *s)
                 fprintf(stderr, "  workgroup, after the request was seen: request published to the block %.2f us, slot records %.2f, candidates scored %.2f, "
                                 "block minimum %.2f, answer written %.2f; %.0f shader cycles (%.2f GHz)\n", ticks[0] * 0.01 / calls, ticks[1] * 0.01 / calls, ticks[2] * 0.01 / calls,
                         ticks[3] * 0.01 / calls, ticks[4] * 0.01 / calls, ticks[5] * 4.0 / calls, ticks[5] * 4.0 / (ticks[4] * 10.0));
+            if (ticks[6])
+                fprintf(stderr, "  the poll before a request: %.2f polls over an idle gap of %.2f us = one poll per %.2f us\n", (double)ticks[6] / calls, ticks[7] * 0.01 / calls,
+                        ticks[7] * 0.01 / (double)ticks[6]);
         }
     }
     s->h.shutdown();
@@ -561,7 +566,7 @@ int nq_server_finish(ls_ctx *ctx, NqServer *s, int slot, int64_t cur_score, cons
         sl.t_wait += sec(T1, T2); sl.t_post += sec(T2, T3);
         sl.calls++;
         const volatile unsigned *rl = s->h.resp(slot);
-        for (int d = 0; d < 6; d++) sl.dev_ticks[d] += (rl[7 + d] >> 16) == s->h.per[(size_t)slot].tag ? rl[7 + d] & 0xffffu : 0u;
+        for (int d = 0; d < 8; d++) sl.dev_ticks[d] += (rl[7 + d] >> 16) == s->h.per[(size_t)slot].tag ? rl[7 + d] & 0xffffu : 0u;
     }
     return LS_OK;
 }

@@ -77,9 +77,18 @@ __device__ __forceinline__ void srv_fetch_moves_512(const void *chunk, unsigned 
     __syncthreads();
 }
 
+__device__ __forceinline__ unsigned long long srv_uniform_u64(unsigned long long x) // a wave-uniform value, into scalar registers
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
+}
+
 struct SrvPoll { // wave 0's poll state
     unsigned last_tag;
     unsigned long long t_start, t_served;
+#ifdef LS_NQ_STAMPS
+    unsigned n_polls = 0; // polls the last accepted request took (stamps builds: the poll period = idle gap / polls)
+#endif
 };
 
 // wave 0, once per launch: the last request an earlier launch answered is read back from the answer line
@@ -98,22 +107,29 @@ __device__ __forceinline__ int srv_poll_wait(SrvPoll &p, const SrvLink &L, const
 {
     static_assert(ND == 16 || ND == 64, "one line or four");
     for (unsigned polls = 1;; polls++) {
-        unsigned v = 0;
+        // ONE load in flight per poll, issued without a branch around it (every lane reads a dword of the message: lanes beyond it
+        // read it again, the same line); the launch's quit word -- device memory, a round trip of its own -- only every fourth
+        // poll, issued beside the line's read
+        const unsigned v = srv_sys_load(req_line + (lane & (ND - 1)));
         unsigned long long q = 0;
-        if (lane < ND) v = srv_sys_load(req_line + lane);
-        if (lane == 0) q = __hip_atomic_load(&L.ctl->quit_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((polls & 3u) == 0) q = __hip_atomic_load(&L.ctl->quit_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (uniform address, uniform branch)
         const unsigned tag = v >> 16;
         const unsigned t0 = __builtin_amdgcn_readfirstlane(tag);
-        const bool whole = __builtin_amdgcn_ballot_w64(lane < ND && tag != t0) == 0;
+        const bool whole = __builtin_amdgcn_ballot_w64(tag != t0) == 0;
         if (whole && t0 != p.last_tag && t0 != 0) {
             if (lane < ND) s_req[lane] = v & 0xffffu;
             if (raw) *raw = v;
+#ifdef LS_NQ_STAMPS
+            p.n_polls = polls;
+#endif
             p.last_tag = t0;
             return (__builtin_amdgcn_readfirstlane(v) & SRV_F_QUIT) ? 1 : 0;
         }
-        const unsigned qlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)q);
-        const unsigned qhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(q >> 32));
-        if ((((unsigned long long)qhi << 32) | qlo) == L.gen) return 1;
+        if ((polls & 3u) == 0) {
+            const unsigned qlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)q);
+            const unsigned qhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(q >> 32));
+            if ((((unsigned long long)qhi << 32) | qlo) == L.gen) return 1;
+        }
         const unsigned long long now = wall_clock64();
         if ((polls & 15u) == 0) { // nobody served for idle_ticks, or the launch has reached its age limit: everybody leaves
             unsigned long long la = 0;
@@ -121,14 +137,19 @@ __device__ __forceinline__ int srv_poll_wait(SrvPoll &p, const SrvLink &L, const
             const unsigned llo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)la);
             const unsigned lhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(la >> 32));
             la = ((unsigned long long)lhi << 32) | llo;
-            if ((now > la && now - la > L.idle_ticks) || now - p.t_start > L.limit_ticks) {
+            if ((now > la && now - la > L.idle_ticks) || now - srv_uniform_u64(p.t_start) > L.limit_ticks) {
                 if (lane == 0) __hip_atomic_store(&L.ctl->quit_gen, L.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return 1;
             }
         }
-        // a slot in the middle of a walk is asked again within microseconds; one that has been quiet for longer polls less often
-        if (now - p.t_served > 20000) __builtin_amdgcn_s_sleep(64);      // > 200 us quiet: ~2 us between polls
-        else if (now - p.t_served > 2000) __builtin_amdgcn_s_sleep(8);   // > 20 us quiet
+        // a slot in the middle of a walk is asked again within microseconds; one that has been quiet for longer polls less often.
+        // The quiet time as a SCALAR: with the stamp in vector registers the compiler turned the three-way choice into three
+        // exec-masked regions without branches, and s_sleep ignores the exec mask -- every poll slept 1 + 8 + 64 units, 1.9 us
+        // (one poll per 2.7 us, measured by the stamps build's poll counter, where the PCIe read takes 1.15 us; now 1.5 us per poll:
+        // n = 4096 11.2 -> 10.3 us per LS iteration, n = 1024 6.7 -> 5.6, config 5 8.5 -> 8.0, same box).
+        const unsigned long long quiet = now - srv_uniform_u64(p.t_served);
+        if (quiet > 20000) __builtin_amdgcn_s_sleep(64);      // > 200 us quiet: ~2 us between polls
+        else if (quiet > 2000) __builtin_amdgcn_s_sleep(8);   // > 20 us quiet
         else __builtin_amdgcn_s_sleep(1);
     }
 }
