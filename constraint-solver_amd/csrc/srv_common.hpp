@@ -227,9 +227,11 @@ struct SrvHost {
     // Request lines: pinned host memory, polled by the device over PCIe -- or, when the owner sets req_dev, fine-grained DEVICE
     // memory the host writes through the PCIe BAR (write-combined: 64-byte stores, then sfence): a poll is then a local read, a
     // request crosses PCIe once instead of being fetched, and every workgroup of a grid can poll it without a relay.  (Used by the
-    // scheduling grid.  For the one-line mailboxes of the step servers it was measured twice, rounds 3 and 4: no gain -- config 3
-    // 5.8-6.2 against 5.4 us per LS iteration, N-queens n = 4096 within the noise -- the write-combined store + sfence costs the
-    // host what the local poll saves.)
+    // scheduling grid.  For the one-line mailboxes of the step servers it was measured three times, rounds 3 and 4 -- the last time
+    // after the poll loop's sleep bug was fixed, same box: config 3 5.0 against 4.6 us per LS iteration, N-queens n = 4096 10.15
+    // against 10.2-10.4, n = 1024 5.4-5.7 against 5.6-5.8, config 4 end to end 0.84 against 0.78 s -- no gain: the write-combined
+    // store + sfence costs the host what the local poll saves, and a request posted right after an answer is caught by the
+    // pinned line's first poll anyway.)
     unsigned *req_dev = nullptr;
     unsigned *req(int s) const { return (req_dev ? req_dev : reinterpret_cast<unsigned *>(pinned)) + (size_t)s * 16; }
     void flush_lines() const
