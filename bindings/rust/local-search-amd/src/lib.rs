@@ -256,7 +256,16 @@ impl MultiSchedSolver {
                                               holiday_bits.as_ptr(), ptrs.len() as i32, ptrs.as_ptr(), params, &mut raw)
         };
         ctx.check(rc)?;
-        Ok(MultiSchedSolver { raw, n_stored: n_days_scored + 1 })
+        let mut m = MultiSchedSolver { raw, n_stored: n_days_scored + 1 };
+        m.configure(ctx, 0)?; // the default slot count; makes what the slots share now rather than in the first run
+        Ok(m)
+    }
+
+    /// Restarts in flight at once (0: the library's default, eight per usable core, at most what one resident launch holds).
+    /// Also builds the slots' shared launch object and contexts (set-up, not part of a run).
+    pub fn configure(&mut self, ctx: &mut GpuContext, n_slots: usize) -> Result<(), LsError> {
+        let rc = unsafe { sys::ls_multi_solver_configure(self.raw, n_slots as i32, 1 /* LS_MULTI_FREE_RUNNING */) };
+        ctx.check(rc)
     }
 
     pub fn run(&mut self, max_rounds_per_restart: u64, max_seconds: f64) -> Result<(), LsError> {
