@@ -108,6 +108,8 @@ struct BoardPk16 {
     static constexpr int CAP = 128 * NRP;
     static constexpr int SELF = 1;
     static constexpr int WAVES = nq_waves_for(3 * NRP + 32);
+    static constexpr bool PAIR = false; // one column per pass
+    static constexpr int TILES = 1;
     us2 R[NRP], A[NRP], B[NRP];
     int n;
     __device__ __forceinline__ void load(const int *__restrict__ rows, int n_, int lane)
@@ -181,8 +183,13 @@ template <int NR>
 struct BoardF32 {
     static constexpr int CAP = 64 * NR;
     static constexpr int SELF = 1;
-    static constexpr int WAVES = nq_waves_for(2 * NR + 40);
-    float R[NR], E[NR];
+    // NR == 64 (2048 < n <= 4096): TWO list columns per pass (lanes4x2).  d = rows[j] - v does not depend on the
+    // candidate's column, so two columns that walk the same values share it: 3.5 instructions per (candidate, column)
+    // instead of 4.  A third register array holds the second column's |j - c|; 2 waves per SIMD either way.
+    static constexpr bool PAIR = NR == 64;
+    static constexpr int TILES = PAIR ? 2 : 1;
+    static constexpr int WAVES = nq_waves_for((PAIR ? 3 : 2) * NR + 40);
+    float R[NR], E[NR], E2[PAIR ? NR : 1];
     __device__ __forceinline__ void load(const int *__restrict__ rows, int n, int lane)
     {
 #pragma unroll
@@ -196,6 +203,13 @@ struct BoardF32 {
     {
 #pragma unroll
         for (int i = 0; i < NR; i++) E[i] = __builtin_fabsf((float)(lane + 64 * i - c));
+    }
+    __device__ __forceinline__ void prepare2(int c2, int lane)
+    {
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int i = 0; i < NR; i++) E2[i] = __builtin_fabsf((float)(lane + 64 * i - c2));
+        }
     }
     static constexpr bool MISMATCH = true; // lanes4 counts mismatching columns (<= NR <= 64)
     static constexpr int READ_UNROLL = 4;
@@ -240,6 +254,39 @@ struct BoardF32 {
         }
 #undef LS_F32_COL
         return (unsigned)(int)m0 | ((unsigned)(int)m1 << 8) | ((unsigned)(int)m2 << 16) | ((unsigned)(int)m3 << 24);
+    }
+    // Values v .. v+3 of the column of prepare() (-> wa) and of the column of prepare2() (-> wb): per board column the
+    // four differences once, then sub / mul+abs+clamp / add per candidate: 28 instructions for 8 candidates.
+    __device__ __forceinline__ void lanes4x2(int v, unsigned &wa, unsigned &wb) const
+    {
+        const float f0 = (float)v, f1 = (float)(v + 1), f2 = (float)(v + 2), f3 = (float)(v + 3);
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#define LS_F32_COL_E(e, a0, a1, a2, a3)                                                             \
+    "v_sub_f32_e64 %12, |%8|, " e "\n\tv_sub_f32_e64 %13, |%9|, " e "\n\t"                          \
+    "v_sub_f32_e64 %14, |%10|, " e "\n\tv_sub_f32_e64 %15, |%11|, " e "\n\t"                        \
+    "v_mul_f32_e64 %12, |%8|, |%12| clamp\n\tv_mul_f32_e64 %13, |%9|, |%13| clamp\n\t"              \
+    "v_mul_f32_e64 %14, |%10|, |%14| clamp\n\tv_mul_f32_e64 %15, |%11|, |%15| clamp\n\t"            \
+    "v_add_f32_e32 " a0 ", " a0 ", %12\n\tv_add_f32_e32 " a1 ", " a1 ", %13\n\t"                    \
+    "v_add_f32_e32 " a2 ", " a2 ", %14\n\tv_add_f32_e32 " a3 ", " a3 ", %15\n\t"
+#define LS_F32_COL2(r, ea, eb)                                                                      \
+    "v_sub_f32_e32 %8, " r ", %22\n\tv_sub_f32_e32 %9, " r ", %23\n\t"                              \
+    "v_sub_f32_e32 %10, " r ", %24\n\tv_sub_f32_e32 %11, " r ", %25\n\t"                            \
+    LS_F32_COL_E(ea, "%0", "%1", "%2", "%3") LS_F32_COL_E(eb, "%4", "%5", "%6", "%7")
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int i = 0; i < NR; i += 2) {
+                float d0, d1, d2, d3, u0, u1, u2, u3;
+                asm(LS_F32_COL2("%16", "%18", "%20") LS_F32_COL2("%17", "%19", "%21")
+                    : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "=&v"(d0), "=&v"(d1),
+                      "=&v"(d2), "=&v"(d3), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
+                    : "v"(R[i]), "v"(R[i + 1]), "v"(E[i]), "v"(E[i + 1]), "v"(E2[i]), "v"(E2[i + 1]), "v"(f0), "v"(f1), "v"(f2),
+                      "v"(f3));
+            }
+        }
+#undef LS_F32_COL2
+#undef LS_F32_COL_E
+        wa = (unsigned)(int)m0 | ((unsigned)(int)m1 << 8) | ((unsigned)(int)m2 << 16) | ((unsigned)(int)m3 << 24);
+        wb = (unsigned)(int)p0 | ((unsigned)(int)p1 << 8) | ((unsigned)(int)p2 << 16) | ((unsigned)(int)p3 << 24);
     }
 };
 
@@ -314,11 +361,97 @@ __device__ __forceinline__ void nq_scan_column_regs(const Board &bd, unsigned *t
         best = u64min(best, nq_key((int)(mu >> 15) - conf_old, nq_key_hi(1, c, n, slot), (int)(mu & 0x7fffu)));
 }
 
+// lane q's candidate of a 64-candidate pass: byte (q & 3) of row (q >> 2), summed over the 64 lanes' words
+template <class Board>
+__device__ __forceinline__ int nq_tile_count(const unsigned *tile, int lane)
+{
+    const unsigned *row = tile + (lane >> 2) * NQ_TILE_STRIDE;
+    const int sh = (lane & 3) * 8;
+    int sum = 0;
+#pragma clang loop unroll_count(Board::READ_UNROLL)
+    for (int l4 = 0; l4 < 16; l4++) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(row + 4 * l4);
+        sum += (int)((x.x >> sh) & 0xffu) + (int)((x.y >> sh) & 0xffu) + (int)((x.z >> sh) & 0xffu) + (int)((x.w >> sh) & 0xffu);
+    }
+    return Board::MISMATCH ? 64 * Board::LANE_TOTAL - sum : sum;
+}
+
+// TWO list columns (slots `slot` and `slot + 1`: columns ca, cb with queens on rows ra, rb) whose n - 1 candidates are all
+// inside the wavefront's share and inside the window: both walk v = 0 .. n-1, so one pass of Board::lanes4x2 serves both
+// (two tiles).  Same minima, same keys as two calls of nq_scan_column_regs; the own squares' counts (conf_old + SELF) come
+// out of the walk, or, when the parity-mode score store needs them up front, out of a one-step pass per column.
+template <bool WANT_SCORES, class Board>
+__device__ __forceinline__ void nq_scan_column_pair_regs(const Board &bd, unsigned *tile, int ra, int rb, int ca, int cb, int n,
+                                                         int slot, unsigned long long &best, long long *srow_a, long long *srow_b,
+                                                         long long cur, int lane)
+{
+    unsigned *tile_b = tile + NQ_TILE_DWORDS;
+    int conf_a = 0, conf_b = 0, own_a = 0, own_b = 0;
+    unsigned mda = NQ_KEY32_EMPTY, mua = NQ_KEY32_EMPTY, mdb = NQ_KEY32_EMPTY, mub = NQ_KEY32_EMPTY;
+    if (WANT_SCORES) {
+        unsigned wa, wb, skip;
+        __builtin_amdgcn_wave_barrier();
+        bd.lanes4x2(ra, wa, skip);
+        bd.lanes4x2(rb, skip, wb);
+        tile[lane] = wa;
+        tile_b[lane] = wb;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        conf_a = __builtin_amdgcn_readfirstlane(nq_tile_count<Board>(tile, lane)) - Board::SELF;
+        conf_b = __builtin_amdgcn_readfirstlane(nq_tile_count<Board>(tile_b, lane)) - Board::SELF;
+    }
+#pragma unroll 1
+    for (int vb = 0; vb < n; vb += 64) {
+        const int left = n - vb;
+        const int steps = left >= 64 ? 16 : (left + 3) >> 2;
+        __builtin_amdgcn_wave_barrier(); // the previous pass's reads are program-ordered before these writes
+#pragma unroll 1 // one copy of the (fully unrolled) two-column scan
+        for (int st = 0; st < steps; st++) {
+            unsigned wa, wb;
+            bd.lanes4x2(vb + 4 * st, wa, wb);
+            tile[st * NQ_TILE_STRIDE + lane] = wa;
+            tile_b[st * NQ_TILE_STRIDE + lane] = wb;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int cnt_a = nq_tile_count<Board>(tile, lane);
+        const int cnt_b = nq_tile_count<Board>(tile_b, lane);
+        const int v = vb + lane;
+        if (v < n) {
+            const unsigned ka = ((unsigned)cnt_a << 15) | (unsigned)v, kb = ((unsigned)cnt_b << 15) | (unsigned)v;
+            if (v < ra) mda = ka < mda ? ka : mda;
+            else if (v > ra) mua = ka < mua ? ka : mua;
+            else own_a = cnt_a;
+            if (v < rb) mdb = kb < mdb ? kb : mdb;
+            else if (v > rb) mub = kb < mub ? kb : mub;
+            else own_b = cnt_b;
+            if (WANT_SCORES) {
+                if (v != ra) srow_a[v] = cur + 2ll * (cnt_a - conf_a);
+                if (v != rb) srow_b[v] = cur + 2ll * (cnt_b - conf_b);
+            }
+        }
+    }
+    if (!WANT_SCORES) {
+        conf_a = __builtin_amdgcn_readlane(own_a, ra & 63) - Board::SELF;
+        conf_b = __builtin_amdgcn_readlane(own_b, rb & 63) - Board::SELF;
+    }
+    if (mda != NQ_KEY32_EMPTY)
+        best = u64min(best, nq_key((int)(mda >> 15) - conf_a, nq_key_hi(0, ca, n, slot), (int)(mda & 0x7fffu)));
+    if (mua != NQ_KEY32_EMPTY)
+        best = u64min(best, nq_key((int)(mua >> 15) - conf_a, nq_key_hi(1, ca, n, slot), (int)(mua & 0x7fffu)));
+    if (mdb != NQ_KEY32_EMPTY)
+        best = u64min(best, nq_key((int)(mdb >> 15) - conf_b, nq_key_hi(0, cb, n, slot + 1), (int)(mdb & 0x7fffu)));
+    if (mub != NQ_KEY32_EMPTY)
+        best = u64min(best, nq_key((int)(mub >> 15) - conf_b, nq_key_hi(1, cb, n, slot + 1), (int)(mub & 0x7fffu)));
+}
+
 template <class Board, bool WANT_SCORES>
 __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs a)
 {
     __shared__ unsigned long long s_best[4];
-    __shared__ __attribute__((aligned(16))) unsigned s_tile[4 * NQ_TILE_DWORDS];
+    __shared__ __attribute__((aligned(16))) unsigned s_tile[4 * Board::TILES * NQ_TILE_DWORDS];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int restart = blockIdx.x % a.n_restarts;
@@ -333,7 +466,7 @@ __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs 
     const long long k0 = K * wchunk / n_wchunks;
     const long long k1 = K * (wchunk + 1) / n_wchunks;
     unsigned long long best = NQ_KEY_EMPTY; // per-lane running minimum
-    unsigned *tile = s_tile + wib * NQ_TILE_DWORDS;
+    unsigned *tile = s_tile + wib * Board::TILES * NQ_TILE_DWORDS;
 
     if (k0 < k1) {
         Board bd;
@@ -347,6 +480,24 @@ __global__ __launch_bounds__(256, Board::WAVES) void nq_scan_regs_kernel(NqArgs 
             const int ve = (left < (long long)(n - v0)) ? (int)(v0 + left) : n;
             const int c = cols[slot];
             const int rc = (unsigned)c < (unsigned)n ? rows[c] : -1;
+            if constexpr (Board::PAIR) {
+                // this column and the next one whole, both inside the share and the window: one two-column walk
+                if (v0 == 0 && left >= 2ll * n && (unsigned)rc < (unsigned)n &&
+                    a.window - (long long)slot * (n - 1) >= 2ll * (n - 1)) {
+                    const int c2 = cols[slot + 1];
+                    const int rc2 = (unsigned)c2 < (unsigned)n ? rows[c2] : -1;
+                    if ((unsigned)rc2 < (unsigned)n) {
+                        bd.prepare(c, lane);
+                        bd.prepare2(c2, lane);
+                        long long *srow = WANT_SCORES ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
+                        nq_scan_column_pair_regs<WANT_SCORES>(bd, tile, rc, rc2, c, c2, n, slot, best, srow,
+                                                              WANT_SCORES ? srow + n : nullptr, cur, lane);
+                        k += 2ll * n;
+                        slot += 2;
+                        continue;
+                    }
+                }
+            }
             if ((unsigned)rc < (unsigned)n) { // device-pointer callers are not validated: such a slot is skipped (nq_slot_scored)
                 const long long base = (long long)slot * (n - 1);
                 const NqRanges rg = nq_ranges(v0, ve, rc, base, a.window);
@@ -1726,7 +1877,7 @@ static int launch_scan_board(ls_ctx *ctx, const NqArgs &a, long long bpr_cap)
     // Exactly Board::WAVES 256-thread blocks per CU: the register budget alone may admit an odd
     // number of waves per SIMD, so a dynamic-LDS reservation (never touched) caps residency.
     constexpr int bpc = Board::WAVES;
-    constexpr size_t lds_cap = bpc >= 8 ? 0 : (size_t)(160 * 1024 / bpc - 2048 - 4 * NQ_TILE_DWORDS * 4);
+    constexpr size_t lds_cap = bpc >= 8 ? 0 : (size_t)(160 * 1024 / bpc - 2048 - 4 * Board::TILES * NQ_TILE_DWORDS * 4);
     // per device: function attributes belong to the device's code object.  Contexts may run on different threads:
     // the flag is atomic and setting the (same) attribute twice is harmless.
     static std::atomic<bool> attr_done_dev[64];

@@ -555,6 +555,43 @@ def test_scan_production_path_own_square_at_share_boundaries(ctx, algo):
         _check_batch_noscores(ctx, algo, rows[None], cols[None, :n_cols], np.array([n_cols]), window)
 
 
+@pytest.mark.parametrize("want_scores", [False, True])
+@pytest.mark.parametrize("n,R,n_cols,window", [
+    (2049, 128, 100, 10 ** 12),          # 16 wavefronts per restart, 6.25 columns each: a cut column, pairs, an odd one left
+    (2049, 128, 100, 61 * 2048 + 17),    # the window ends inside a column in the middle of a wavefront's share
+    (2049, 128, 100, 62 * 2048),         # ... and exactly at the end of a pair's first / second column
+    (2049, 128, 100, 63 * 2048),
+    (3001, 64, 99, 10 ** 12),            # padded lanes and a partial last pass (3001 = 46 * 64 + 57)
+    (4095, 64, 64, 10 ** 12),            # whole columns per wavefront: 2 each, n not a multiple of 64
+    (4096, 32, 67, 10 ** 12),
+])
+def test_scan_two_column_walk(ctx, n, R, n_cols, window, want_scores):
+    # nq_scan_column_pair_regs (2048 < n <= 4096): two whole list columns per pass wherever a wavefront's share and the
+    # window hold both; everything else goes through the one-column walk.  Duplicated columns, queens sharing rows.
+    ctx.set_algo("scan")
+    rng = np.random.default_rng(n * 7 + R + (window % 1000))
+    rows = np.stack([_board(rng, n, "uniform" if r % 3 else "perm") for r in range(R)])
+    cols = np.stack([rng.integers(0, n, size=n_cols) for _ in range(R)])
+    for r in range(0, R, 5):
+        cols[r, 1::7] = cols[r, 0:-1:7][: len(cols[r, 1::7])]     # neighbours in the list that are the SAME column
+    cur = [int(orc.nq_col_scores_table(rows[r]).sum()) for r in range(R)]
+    nc = np.full(R, n_cols)
+    nc[3] = 1
+    nc[4] = 2
+    nc[5] = 0
+    out, scores = ctx.nqueens_eval_batch(rows, cur, cols, nc, window, want_scores=want_scores)
+    for r in range(R):
+        exp = orc.nq_neighbourhood(rows[r], cols[r, :nc[r]], window, "table", want_scores=want_scores)
+        got = out[r]
+        assert (got["n_scored"], got["best_index"]) == (exp["n_scored"], exp["best_index"]), (r, got, exp)
+        if exp["best_index"] >= 0:
+            assert got["best_score"] == exp["best_score"], (r, got, exp)
+        if want_scores:
+            k = nc[r] * n
+            assert np.array_equal(scores[r, :k], exp["scores"]), r
+            assert (scores[r, k:] == orc.SKIPPED).all()
+
+
 @pytest.mark.parametrize("n,n_cols", [(8, 2), (33, 4), (200, 6), (1000, 9)])
 def test_general_tabu_set_exclusion_list(ctx, n, n_cols):
     # History configurations whose tabu set holds more than the current board (all_solution_iteration_expiry == 0,
