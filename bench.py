@@ -387,11 +387,14 @@ def build_report(args, world, R, n, info, value, elapsed, avg_launch_s, neighbou
     traffic = counters.get("hbm_traffic", {}).get(f"nq_{args.algo}_n{n}_r{R}", {}).get("bytes_per_launch")
     kernel = ("nq_scan_regs_kernel<BoardF32<64>, false>" if (args.algo == "scan" and 2048 < n <= 4096)
               else ("nq_table_quads_kernel" if args.algo == "table" else "nq_scan_*"))
-    # VALU-issue roofline of the scan kernel: per neighbour every lane runs 4 full-rate fp32
-    # instructions (sub, sub, mul+clamp, add) for each of its ceil64(n)/64 columns; achieved counts ONLY those
-    # algorithmic instructions (measured SQ_INSTS_VALU per neighbour is in counters.*), peak is the spec issue rate.
+    # VALU-issue roofline of the scan kernel: per neighbour every lane runs full-rate fp32 instructions
+    # for each of its ceil64(n)/64 columns -- 4 (sub, sub, mul+clamp, add) in the one-column walk; 3.5 in the two-column
+    # walk of 2048 < n <= 4096, where two list columns share the first sub (whole columns only: this workload's case).
+    # achieved counts ONLY those algorithmic instructions (measured SQ_INSTS_VALU per neighbour is in counters.*), peak
+    # is the spec issue rate.
     simds = 4 * info["n_cus"]
-    algo_wave_instr = 4 * ((n + 63) // 64)
+    two_column_walk = args.algo == "scan" and 2048 < n <= 4096
+    algo_wave_instr = (3.5 if two_column_walk else 4.0) * ((n + 63) // 64)
     peak_wi = valu_issue_peak_wave_instr_per_s(info["n_cus"])
     ach_wi = neighbours_per_step * algo_wave_instr / avg_launch_s
     roof = {
@@ -407,7 +410,7 @@ def build_report(args, world, R, n, info, value, elapsed, avg_launch_s, neighbou
         "peak_source": "MI355X_MICROARCH.md: wave64 VALU instruction = 2 cycles per SIMD-32, 4 SIMDs x n_cus, 2.4 GHz max clock; "
                        "1 fp32 operation per lane per instruction (sub / mul / add, no fused pairs), i.e. half the 157.3 TFLOP/s FMA peak",
         "note": "no MFMA and not HBM-bound: the 16 KiB state of a restart is read once per wavefront and held in registers; "
-                "every candidate then costs 4 fp32 instructions per column (exact integer-valued arithmetic), so the limiter is VALU issue",
+                "every candidate then costs 3.5 (two list columns per pass sharing rows[j] - v; 4 in the one-column walk) fp32 instructions per column (exact integer-valued arithmetic), so the limiter is VALU issue",
         # SURVEY 8(d)'s fixed byte accounting, kept as a labelled secondary: NOT a usable roofline fraction (> 1), because
         # those bytes are served from registers, not from HBM; measured HBM traffic is `traffic` (rocprofv3 counters)
         "hbm_effective_secondary": {
