@@ -83,6 +83,35 @@ def nq_case(ctx):
         stats["nq_steps"] = stats.get("nq_steps", 0) + 2 * R
 
 
+def nq_two_column_case(ctx):
+    """Batches whose wavefront shares hold several whole columns (2048 < n <= 4096): the scan kernel's two-column walk,
+    its hand-over to the one-column walk at cut columns, odd leftovers and the window's end."""
+    n = int(rng.integers(2049, 4097))
+    R = int(rng.choice([32, 64, 128, 256]))
+    n_cols = int(rng.integers(2, 16)) * (512 // R) + int(rng.integers(0, 5))
+    rows = np.stack([rng.integers(0, n, size=n) if rng.integers(0, 3) else rng.permutation(n) for _ in range(R)])
+    cols = rng.integers(0, n, size=(R, n_cols))
+    dup = rng.integers(0, 2, size=(R, n_cols - 1)).astype(bool) & (rng.integers(0, 8, size=(R, n_cols - 1)) == 0)
+    cols[:, 1:][dup] = cols[:, :-1][dup]                              # list neighbours that are the same column
+    nc = rng.integers(0, n_cols + 1, size=R)
+    nc[rng.integers(0, R, size=R // 2)] = n_cols
+    k = int(rng.integers(0, n_cols + 1))
+    window = int(rng.choice([10 ** 12, k * (n - 1), k * (n - 1) + int(rng.integers(1, n - 1)), max(1, k * (n - 1) - 1)]))
+    want = bool(rng.integers(0, 2)) and R * n_cols * n * 8 < (1 << 30)
+    cur = [int(orc.nq_col_scores_table(rows[r]).sum()) for r in range(R)]
+    ctx.set_algo("scan")
+    out, scores = ctx.nqueens_eval_batch(rows, cur, cols, nc, window, want_scores=want)
+    for r in range(R):
+        e = orc.nq_neighbourhood(rows[r], cols[r, :nc[r]], window, "table", want_scores=want)
+        if (out[r]["n_scored"], out[r]["best_index"]) != (e["n_scored"], e["best_index"]) or \
+                (e["best_index"] >= 0 and out[r]["best_score"] != e["best_score"]) or \
+                (want and not np.array_equal(scores[r, :nc[r] * n], e["scores"])):
+            fail("nqueens scan, several columns per wavefront", n=n, R=R, r=r, rows=rows[r], cols=cols[r, :nc[r]], window=window,
+                 got=out[r], exp={kk: e[kk] for kk in ("n_scored", "best_index", "best_score")})
+        stats["nq_candidates"] += e["n_scored"]
+    stats["nq_two_column_batches"] = stats.get("nq_two_column_batches", 0) + 1
+
+
 def sched_case(ctx):
     D = int(rng.choice([rng.integers(1, 32), 31, rng.integers(32, 65)], p=[0.4, 0.3, 0.3]))
     S = int(min(64, D + rng.integers(0, 2)))
@@ -211,6 +240,8 @@ with ls_amd.Context(0) as ctx:
         server_walk(ctx)
         if turn % 8 == 0:
             multi_sched_case(ctx)
+        if turn % 8 == 4:
+            nq_two_column_case(ctx)
         turn += 1
         if time.time() - last > 30:
             print("progress", stats, flush=True)
