@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CHECK(x)                                                                          \
@@ -45,6 +46,9 @@
 #define OP_MIN3U32(d) "v_min3_u32 " d ", " d ", %16, %17\n\t"
 #define OP_ANDOR(d) "v_and_or_b32 " d ", " d ", %16, %17\n\t"
 #define OP_XAD(d) "v_xad_u32 " d ", " d ", %16, %17\n\t"
+#define OP_ADD3(d) "v_add3_u32 " d ", " d ", %16, %17\n\t"
+#define OP_LSHLADD(d) "v_lshl_add_u32 " d ", %16, 1, " d "\n\t"
+#define OP_FMACLAMP(d) "v_fma_f32 " d ", |" d "|, |%16|, %17 clamp\n\t"
 
 #define KERNEL(NAME, OPM, ...)                                                           \
     __global__ __launch_bounds__(256) void NAME(unsigned long long *out, float *sink, int iters)  \
@@ -92,6 +96,9 @@ KERNEL(k_dot2f16, OP_DOT2F16, "memory")
 KERNEL(k_min3u32, OP_MIN3U32, "memory")
 KERNEL(k_andor, OP_ANDOR, "memory")
 KERNEL(k_xad, OP_XAD, "memory")
+KERNEL(k_add3, OP_ADD3, "memory")
+KERNEL(k_lshladd, OP_LSHLADD, "memory")
+KERNEL(k_fmaclamp, OP_FMACLAMP, "memory")
 
 // packed f32 needs 64-bit register pairs
 __global__ __launch_bounds__(256) void k_pkaddf32(unsigned long long *out, float *sink, int iters)
@@ -183,6 +190,20 @@ MIX_KERNEL(k_mix_long1024, MIX64, 16)
 #define E64 E16 E16 E16 E16
 MIX_KERNEL(k_e32_long1024, E64, 16)
 
+// the two-column walk's mix with the two board columns' flags added by ONE v_add3_u32 per candidate (24 instructions per
+// 8 (candidate, column) pairs: 4 sub e32, 8 sub e64, 8 mul e64, 4 add3) against the same with v_add_f32 (28)
+#define ADD3_HALF(acc0, acc1, acc2, acc3)                                                                                       \
+    "v_sub_f32_e32 %4, %16, %12\n\tv_sub_f32_e32 %5, %16, %13\n\tv_sub_f32_e32 %6, %16, %14\n\tv_sub_f32_e32 %7, %16, %15\n\t" \
+    "v_sub_f32_e64 %8, |%4|, %17\n\tv_sub_f32_e64 %9, |%5|, %17\n\tv_sub_f32_e64 %10, |%6|, %17\n\tv_sub_f32_e64 %11, |%7|, %17\n\t" \
+    "v_mul_f32_e64 %8, |%4|, |%8| clamp\n\tv_mul_f32_e64 %9, |%5|, |%9| clamp\n\tv_mul_f32_e64 %10, |%6|, |%10| clamp\n\tv_mul_f32_e64 %11, |%7|, |%11| clamp\n\t" \
+    "v_sub_f32_e64 %4, |%4|, %16\n\tv_sub_f32_e64 %5, |%5|, %16\n\tv_sub_f32_e64 %6, |%6|, %16\n\tv_sub_f32_e64 %7, |%7|, %16\n\t" \
+    "v_mul_f32_e64 %4, |%12|, |%4| clamp\n\tv_mul_f32_e64 %5, |%13|, |%5| clamp\n\tv_mul_f32_e64 %6, |%14|, |%6| clamp\n\tv_mul_f32_e64 %7, |%15|, |%7| clamp\n\t" \
+    "v_add3_u32 " acc0 ", " acc0 ", %8, %4\n\tv_add3_u32 " acc1 ", " acc1 ", %9, %5\n\tv_add3_u32 " acc2 ", " acc2 ", %10, %6\n\tv_add3_u32 " acc3 ", " acc3 ", %11, %7\n\t"
+#define ADD3_COL ADD3_HALF("%0", "%1", "%2", "%3")
+#define A4 ADD3_COL ADD3_COL ADD3_COL ADD3_COL
+#define A16 A4 A4 A4 A4
+MIX_KERNEL(k_add3_mix_1536, A16 A16 A16 A16, 24)
+
 typedef void (*kern_t)(unsigned long long *, float *, int);
 
 struct Entry { const char *name; kern_t fn; };
@@ -202,7 +223,10 @@ int main(int argc, char **argv)
         {"v_min3_u32", k_min3u32}, {"v_and_or_b32", k_andor}, {"v_xad_u32", k_xad},
         {"v_pk_min_u16", k_pkminu16}, {"v_pk_add_u16", k_pkaddu16}, {"v_pk_max_i16", k_pkmaxi16},
         {"v_sad_u32", k_sadu32}, {"v_mad_u32_u24", k_madu24}, {"v_cmp_eq_u32_e64(sdst)", k_cmpeq},
+        {"v_add3_u32", k_add3}, {"v_lshl_add_u32", k_lshladd}, {"v_fma_f32|abs|clamp", k_fmaclamp},
+        {"add3 mix (20 f32 + 4 add3), 1536 straight", k_add3_mix_1536},
     };
+    const char *only = argc > 2 ? argv[2] : nullptr; // substring filter on the names
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -217,6 +241,7 @@ int main(int argc, char **argv)
     CHECK(hipEventCreate(&e1));
     printf("%-28s %5s %12s %12s %10s\n", "instruction", "w/SIMD", "cyc/instr/SIMD", "ns/instr/SIMD", "clock GHz");
     for (const Entry &en : tab) {
+        if (only && !strstr(en.name, only)) continue;
         for (int wps : {1, 2, 3, 4}) {
             const int blocks = cus * wps; // 256-thread blocks: one wave per SIMD each
             hipLaunchKernelGGL(en.fn, dim3(blocks), dim3(256), 0, 0, out, sink, iters / 10); // warm-up
