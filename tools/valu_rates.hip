@@ -204,6 +204,22 @@ MIX_KERNEL(k_e32_long1024, E64, 16)
 #define A16 A4 A4 A4 A4
 MIX_KERNEL(k_add3_mix_1536, A16 A16 A16 A16, 24)
 
+// the 8 x 8 tile's mix: sub e64 |abs||abs|, mul e64 |abs||abs| clamp, add e32 (two thirds of the instructions are 8-byte encodings:
+// 6.67 bytes per instruction against 6.0 for the scan mix) -- and the same with the add as an 8-byte encoding too (8.0)
+#define T8_GRP(ADD)                                                                                      \
+    "v_sub_f32_e64 %8, |%4|, |%16|\n\tv_sub_f32_e64 %9, |%5|, |%16|\n\tv_sub_f32_e64 %10, |%6|, |%16|\n\tv_sub_f32_e64 %11, |%7|, |%16|\n\t" \
+    "v_mul_f32_e64 %8, |%4|, |%8| clamp\n\tv_mul_f32_e64 %9, |%5|, |%9| clamp\n\tv_mul_f32_e64 %10, |%6|, |%10| clamp\n\tv_mul_f32_e64 %11, |%7|, |%11| clamp\n\t" \
+    ADD " %0, %0, %8\n\t" ADD " %1, %1, %9\n\t" ADD " %2, %2, %10\n\t" ADD " %3, %3, %11\n\t" \
+    "v_sub_f32_e64 %8, |%12|, |%17|\n\tv_sub_f32_e64 %9, |%13|, |%17|\n\tv_sub_f32_e64 %10, |%14|, |%17|\n\tv_sub_f32_e64 %11, |%15|, |%17|\n\t" \
+    "v_mul_f32_e64 %8, |%12|, |%8| clamp\n\tv_mul_f32_e64 %9, |%13|, |%9| clamp\n\tv_mul_f32_e64 %10, |%14|, |%10| clamp\n\tv_mul_f32_e64 %11, |%15|, |%11| clamp\n\t" \
+    ADD " %0, %0, %8\n\t" ADD " %1, %1, %9\n\t" ADD " %2, %2, %10\n\t" ADD " %3, %3, %11\n\t"
+#define T8A T8_GRP("v_add_f32_e32")
+#define T8B T8_GRP("v_add_f32_e64")
+#define T8A8 T8A T8A T8A T8A T8A T8A T8A T8A
+#define T8B8 T8B T8B T8B T8B T8B T8B T8B T8B
+MIX_KERNEL(k_t8_mix, T8A8 T8A8 T8A8 T8A8, 12)
+MIX_KERNEL(k_t8_mix_e64, T8B8 T8B8 T8B8 T8B8, 12)
+
 typedef void (*kern_t)(unsigned long long *, float *, int);
 
 struct Entry { const char *name; kern_t fn; };
@@ -225,6 +241,7 @@ int main(int argc, char **argv)
         {"v_sad_u32", k_sadu32}, {"v_mad_u32_u24", k_madu24}, {"v_cmp_eq_u32_e64(sdst)", k_cmpeq},
         {"v_add3_u32", k_add3}, {"v_lshl_add_u32", k_lshladd}, {"v_fma_f32|abs|clamp", k_fmaclamp},
         {"add3 mix (20 f32 + 4 add3), 1536 straight", k_add3_mix_1536},
+        {"tile8 mix (6.67 B/instr), 768 straight", k_t8_mix}, {"tile8 mix, add e64 (8 B/instr), 768 straight", k_t8_mix_e64},
     };
     const char *only = argc > 2 ? argv[2] : nullptr; // substring filter on the names
     hipDeviceProp_t prop;
