@@ -28,6 +28,8 @@
 //         for every candidate; per-lane counts are combined through a wave-private LDS tile
 //         (register path: lane q then owns candidate q) or DPP adds (LDS path); wavefronts
 //         keep running key minima, blocks combine through LDS, one 64-bit atomicMin per block.
+//         2048 < n <= 4096: two list columns share a pass wherever both are whole (rows[j] - v is
+//         common to them): 3.5 instead of 4 instructions per (candidate, board column).
 //   TABLE occupancy histograms (rows / two diagonals) built once per board;
 //         a candidate is three table reads.  One lane per candidate.
 #include <atomic>
