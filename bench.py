@@ -389,11 +389,11 @@ def build_report(args, world, R, n, info, value, elapsed, avg_launch_s, neighbou
               else ("nq_table_quads_kernel" if args.algo == "table" else "nq_scan_*"))
     # VALU-issue roofline of the scan kernel: per neighbour every lane runs full-rate fp32 instructions
     # for each of its ceil64(n)/64 columns -- 4 (sub, sub, mul+clamp, add) in the one-column walk; 3.5 in the two-column
-    # walk of 2048 < n <= 4096, where two list columns share the first sub (whole columns only: this workload's case).
+    # walk of 512 < n <= 4096, where two list columns share the first sub (whole columns only: this workload's case).
     # achieved counts ONLY those algorithmic instructions (measured SQ_INSTS_VALU per neighbour is in counters.*), peak
     # is the spec issue rate.
     simds = 4 * info["n_cus"]
-    two_column_walk = args.algo == "scan" and 2048 < n <= 4096
+    two_column_walk = args.algo == "scan" and 512 < n <= 4096
     algo_wave_instr = (3.5 if two_column_walk else 4.0) * ((n + 63) // 64)
     peak_wi = valu_issue_peak_wave_instr_per_s(info["n_cus"])
     ach_wi = neighbours_per_step * algo_wave_instr / avg_launch_s

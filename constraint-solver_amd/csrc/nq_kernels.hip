@@ -28,7 +28,7 @@
 //         for every candidate; per-lane counts are combined through a wave-private LDS tile
 //         (register path: lane q then owns candidate q) or DPP adds (LDS path); wavefronts
 //         keep running key minima, blocks combine through LDS, one 64-bit atomicMin per block.
-//         2048 < n <= 4096: two list columns share a pass wherever both are whole (rows[j] - v is
+//         512 < n <= 4096: two list columns share a pass wherever both are whole (rows[j] - v is
 //         common to them): 3.5 instead of 4 instructions per (candidate, board column).
 //   TABLE occupancy histograms (rows / two diagonals) built once per board;
 //         a candidate is three table reads.  One lane per candidate.
@@ -185,10 +185,12 @@ template <int NR>
 struct BoardF32 {
     static constexpr int CAP = 64 * NR;
     static constexpr int SELF = 1;
-    // NR == 64 (2048 < n <= 4096): TWO list columns per pass (lanes4x2).  d = rows[j] - v does not depend on the
+    // NR >= 16 (512 < n <= 4096): TWO list columns per pass (lanes4x2).  d = rows[j] - v does not depend on the
     // candidate's column, so two columns that walk the same values share it: 3.5 instructions per (candidate, column)
-    // instead of 4.  A third register array holds the second column's |j - c|; 2 waves per SIMD either way.
-    static constexpr bool PAIR = NR == 64;
+    // instead of 4.  A third register array holds the second column's |j - c|: NR = 64 and 16 keep their 2 and 4 waves per
+    // SIMD, NR = 32 goes from 4 to 2 (the same ns per instruction, nq_waves_for); below, the second tile would cost
+    // residency for launches that rarely hold two whole columns per wavefront.
+    static constexpr bool PAIR = NR >= 16;
     static constexpr int TILES = PAIR ? 2 : 1;
     static constexpr int WAVES = nq_waves_for((PAIR ? 3 : 2) * NR + 40);
     float R[NR], E[NR], E2[PAIR ? NR : 1];

@@ -564,9 +564,13 @@ def test_scan_production_path_own_square_at_share_boundaries(ctx, algo):
     (3001, 64, 99, 10 ** 12),            # padded lanes and a partial last pass (3001 = 46 * 64 + 57)
     (4095, 64, 64, 10 ** 12),            # whole columns per wavefront: 2 each, n not a multiple of 64
     (4096, 32, 67, 10 ** 12),
+    (2048, 64, 40, 10 ** 12),            # the 32-register tier (1024 < n <= 2048)
+    (1500, 128, 37, 30 * 1499 + 700),
+    (1024, 128, 66, 10 ** 12),           # the 16-register tier (512 < n <= 1024)
+    (700, 256, 50, 41 * 699),
 ])
 def test_scan_two_column_walk(ctx, n, R, n_cols, window, want_scores):
-    # nq_scan_column_pair_regs (2048 < n <= 4096): two whole list columns per pass wherever a wavefront's share and the
+    # nq_scan_column_pair_regs (512 < n <= 4096): two whole list columns per pass wherever a wavefront's share and the
     # window hold both; everything else goes through the one-column walk.  Duplicated columns, queens sharing rows.
     ctx.set_algo("scan")
     rng = np.random.default_rng(n * 7 + R + (window % 1000))
