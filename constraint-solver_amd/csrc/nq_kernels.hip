@@ -28,8 +28,9 @@
 //         for every candidate; per-lane counts are combined through a wave-private LDS tile
 //         (register path: lane q then owns candidate q) or DPP adds (LDS path); wavefronts
 //         keep running key minima, blocks combine through LDS, one 64-bit atomicMin per block.
-//         512 < n <= 4096: two list columns share a pass wherever both are whole (rows[j] - v is
-//         common to them): 3.5 instead of 4 instructions per (candidate, board column).
+//         n > 512: two list columns share a pass wherever both are whole (rows[j] - v is common
+//         to them): 3.5 instead of 4 instructions per (candidate, board column) in the register
+//         kernel, 3.75 instead of 4.5 in the LDS kernel.
 //   TABLE occupancy histograms (rows / two diagonals) built once per board;
 //         a candidate is three table reads.  One lane per candidate.
 #include <atomic>
@@ -570,6 +571,83 @@ __device__ __forceinline__ void nq_count4_lds(const float *sR, int n_pad, int la
     cnt[2] = (int)(t23 & 0xffffu); cnt[3] = (int)(t23 >> 16);
 }
 
+// The same for TWO list columns ca, cb over the same four values (their rows[j] - v are shared): 28 instructions per board
+// column for 8 candidates instead of 2 x 16.
+#define LS_F32_LDS_HALF(JC, A0, A1, A2, A3)                                                          \
+    "v_sub_f32_e64 %12, |%8|, |" JC "|\n\tv_sub_f32_e64 %13, |%9|, |" JC "|\n\t"                      \
+    "v_sub_f32_e64 %14, |%10|, |" JC "|\n\tv_sub_f32_e64 %15, |%11|, |" JC "|\n\t"                    \
+    "v_mul_f32_e64 %12, |%8|, |%12| clamp\n\tv_mul_f32_e64 %13, |%9|, |%13| clamp\n\t"                \
+    "v_mul_f32_e64 %14, |%10|, |%14| clamp\n\tv_mul_f32_e64 %15, |%11|, |%15| clamp\n\t"              \
+    "v_add_f32_e32 " A0 ", " A0 ", %12\n\tv_add_f32_e32 " A1 ", " A1 ", %13\n\t"                      \
+    "v_add_f32_e32 " A2 ", " A2 ", %14\n\tv_add_f32_e32 " A3 ", " A3 ", %15\n\t"
+#define LS_F32_LDS_STEP2                                                                             \
+    "v_sub_f32_e32 %8, %16, %19\n\tv_sub_f32_e32 %9, %16, %20\n\t"                                   \
+    "v_sub_f32_e32 %10, %16, %21\n\tv_sub_f32_e32 %11, %16, %22\n\t"                                 \
+    LS_F32_LDS_HALF("%17", "%0", "%1", "%2", "%3") LS_F32_LDS_HALF("%18", "%4", "%5", "%6", "%7")
+
+__device__ __forceinline__ void nq_count4x2_lds(const float *sR, int n_pad, int lane, int v, int ca, int cb, int (&cnt_a)[4],
+                                                int (&cnt_b)[4])
+{
+    const float f0 = (float)v, f1 = (float)(v + 1), f2 = (float)(v + 2), f3 = (float)(v + 3);
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    float ja0 = (float)(4 * lane - ca), ja1 = ja0 + 1.0f, ja2 = ja0 + 2.0f, ja3 = ja0 + 3.0f; // j - ca per owned column
+    float jb0 = (float)(4 * lane - cb), jb1 = jb0 + 1.0f, jb2 = jb0 + 2.0f, jb3 = jb0 + 3.0f; // j - cb
+    const float4 *p4 = reinterpret_cast<const float4 *>(sR) + lane;
+    const int visits8 = n_pad >> 9;
+    for (int i = 0; i < visits8; i++) {
+        const float4 r = p4[128 * i], t = p4[128 * i + 64];
+        float d0, d1, d2, d3, u0, u1, u2, u3;
+#define LS_LDS_COL2(R, JA, JB)                                                                                        \
+        asm(LS_F32_LDS_STEP2                                                                                          \
+            : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "=&v"(d0), "=&v"(d1),      \
+              "=&v"(d2), "=&v"(d3), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)                                          \
+            : "v"(R), "v"(JA), "v"(JB), "v"(f0), "v"(f1), "v"(f2), "v"(f3));
+        LS_LDS_COL2(r.x, ja0, jb0) LS_LDS_COL2(r.y, ja1, jb1) LS_LDS_COL2(r.z, ja2, jb2) LS_LDS_COL2(r.w, ja3, jb3)
+        ja0 += 256.0f; ja1 += 256.0f; ja2 += 256.0f; ja3 += 256.0f;
+        jb0 += 256.0f; jb1 += 256.0f; jb2 += 256.0f; jb3 += 256.0f;
+        LS_LDS_COL2(t.x, ja0, jb0) LS_LDS_COL2(t.y, ja1, jb1) LS_LDS_COL2(t.z, ja2, jb2) LS_LDS_COL2(t.w, ja3, jb3)
+        ja0 += 256.0f; ja1 += 256.0f; ja2 += 256.0f; ja3 += 256.0f;
+        jb0 += 256.0f; jb1 += 256.0f; jb2 += 256.0f; jb3 += 256.0f;
+#undef LS_LDS_COL2
+    }
+    const int visits = n_pad >> 6;
+    const unsigned a01 = (unsigned)wave_sum_i32((visits - (int)m0) | ((visits - (int)m1) << 16));
+    const unsigned a23 = (unsigned)wave_sum_i32((visits - (int)m2) | ((visits - (int)m3) << 16));
+    const unsigned b01 = (unsigned)wave_sum_i32((visits - (int)p0) | ((visits - (int)p1) << 16));
+    const unsigned b23 = (unsigned)wave_sum_i32((visits - (int)p2) | ((visits - (int)p3) << 16));
+    cnt_a[0] = (int)(a01 & 0xffffu); cnt_a[1] = (int)(a01 >> 16); cnt_a[2] = (int)(a23 & 0xffffu); cnt_a[3] = (int)(a23 >> 16);
+    cnt_b[0] = (int)(b01 & 0xffffu); cnt_b[1] = (int)(b01 >> 16); cnt_b[2] = (int)(b23 & 0xffffu); cnt_b[3] = (int)(b23 >> 16);
+}
+#undef LS_F32_LDS_STEP2
+#undef LS_F32_LDS_HALF
+
+// two WHOLE list columns (slots `slot`, `slot + 1`), every value 0 .. n-1 except the own squares ra, rb
+__device__ __forceinline__ void nq_scan_pair_lds(const float *sR, int n_pad, int n, int ca, int cb, int ra, int rb, int conf_a,
+                                                 int conf_b, int slot, unsigned long long &best, long long *srow_a,
+                                                 long long *srow_b, long long cur, int lane)
+{
+    const unsigned long long hda = nq_key_hi(0, ca, n, slot), hua = nq_key_hi(1, ca, n, slot);
+    const unsigned long long hdb = nq_key_hi(0, cb, n, slot + 1), hub = nq_key_hi(1, cb, n, slot + 1);
+    for (int v = 0; v < n; v += 4) {
+        int cnt_a[4], cnt_b[4];
+        nq_count4x2_lds(sR, n_pad, lane, v, ca, cb, cnt_a, cnt_b);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int w = v + u;
+            if (w < n && w != ra) {
+                const int delta = cnt_a[u] - conf_a;
+                best = u64min(best, nq_key(delta, w > ra ? hua : hda, w));
+                if (srow_a != nullptr && lane == 0) srow_a[w] = cur + 2ll * delta;
+            }
+            if (w < n && w != rb) {
+                const int delta = cnt_b[u] - conf_b;
+                best = u64min(best, nq_key(delta, w > rb ? hub : hdb, w));
+                if (srow_b != nullptr && lane == 0) srow_b[w] = cur + 2ll * delta;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void nq_scan_range_lds(const float *sR, int n_pad, int vbeg, int vend, int c,
                                                   int conf_old, unsigned long long khi,
                                                   unsigned long long &best, long long *scores_row,
@@ -624,6 +702,22 @@ __global__ __launch_bounds__(NQ_LDS_BLOCK) void nq_scan_lds_kernel(NqArgs a)
             const int ve = (left < (long long)(n - v0)) ? (int)(v0 + left) : n;
             const int c = cols[slot];
             const int rc = (unsigned)c < (unsigned)n ? rows[c] : -1;
+            // this column and the next one whole, both inside the share and the window: one two-column walk
+            if (v0 == 0 && left >= 2ll * n && (unsigned)rc < (unsigned)n && a.window - (long long)slot * (n - 1) >= 2ll * (n - 1)) {
+                const int c2 = cols[slot + 1];
+                const int rc2 = (unsigned)c2 < (unsigned)n ? rows[c2] : -1;
+                if ((unsigned)rc2 < (unsigned)n) {
+                    int cnt[4], cnt2[4];
+                    nq_count4_lds(sR, n_pad, lane, rc, c, cnt);
+                    nq_count4_lds(sR, n_pad, lane, rc2, c2, cnt2);
+                    long long *srow = a.scores_out ? a.scores_out + ((long long)restart * a.max_cols + slot) * n : nullptr;
+                    nq_scan_pair_lds(sR, n_pad, n, c, c2, rc, rc2, cnt[0] - 1, cnt2[0] - 1, slot, best, srow,
+                                     srow ? srow + n : nullptr, cur, lane);
+                    k += 2ll * n;
+                    slot += 2;
+                    continue;
+                }
+            }
             if ((unsigned)rc < (unsigned)n) {
                 const long long base = (long long)slot * (n - 1);
                 const NqRanges rg = nq_ranges(v0, ve, rc, base, a.window);

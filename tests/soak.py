@@ -84,11 +84,13 @@ def nq_case(ctx):
 
 
 def nq_two_column_case(ctx):
-    """Batches whose wavefront shares hold several whole columns (512 < n <= 4096): the scan kernel's two-column walk,
+    """Batches whose wavefront shares hold several whole columns (n > 512; beyond 4096 the LDS kernel): the scan kernel's two-column walk,
     its hand-over to the one-column walk at cut columns, odd leftovers and the window's end."""
-    n = int(rng.integers(513, 4097))
-    R = int(rng.choice([32, 64, 128, 256]))
+    n = int(rng.integers(513, 4097)) if rng.integers(0, 6) else int(rng.integers(4097, 9001))   # the LDS kernel now and then
+    R = int(rng.choice([32, 64, 128, 256])) if n <= 4096 else 256
     n_cols = int(rng.integers(2, 16)) * ((512 if n > 2048 else 1024) // R) + int(rng.integers(0, 5))
+    if n > 4096:
+        n_cols = int(rng.integers(2, 4)) * 32 + int(rng.integers(0, 20))     # 8192 / R = 32 wavefronts per restart
     rows = np.stack([rng.integers(0, n, size=n) if rng.integers(0, 3) else rng.permutation(n) for _ in range(R)])
     cols = rng.integers(0, n, size=(R, n_cols))
     dup = rng.integers(0, 2, size=(R, n_cols - 1)).astype(bool) & (rng.integers(0, 8, size=(R, n_cols - 1)) == 0)

@@ -568,9 +568,12 @@ def test_scan_production_path_own_square_at_share_boundaries(ctx, algo):
     (1500, 128, 37, 30 * 1499 + 700),
     (1024, 128, 66, 10 ** 12),           # the 16-register tier (512 < n <= 1024)
     (700, 256, 50, 41 * 699),
+    (5000, 256, 80, 10 ** 12),           # the LDS kernel (n > 4096): 32 wavefronts per restart, 2.5 columns each
+    (4097, 256, 77, 70 * 4096 + 9),
+    (8192, 256, 70, 10 ** 12),
 ])
 def test_scan_two_column_walk(ctx, n, R, n_cols, window, want_scores):
-    # nq_scan_column_pair_regs (512 < n <= 4096): two whole list columns per pass wherever a wavefront's share and the
+    # nq_scan_column_pair_regs (512 < n <= 4096) / nq_scan_pair_lds (n > 4096): two whole list columns per pass wherever a wavefront's share and the
     # window hold both; everything else goes through the one-column walk.  Duplicated columns, queens sharing rows.
     ctx.set_algo("scan")
     rng = np.random.default_rng(n * 7 + R + (window % 1000))
