@@ -313,6 +313,10 @@ def run_rank(args, rank, world, device, sync, launcher):
                     "table_frac": (tb.get("roofline") or {}).get("frac"), "table_per_s": tb.get("neighbours_per_s"),
                     "table_r64_frac": (tb64.get("roofline") or {}).get("frac"), "table_r64_per_s": tb64.get("neighbours_per_s"),
                     "int_formulation_per_s": (ex.get("scan_int_formulation_packed_u16") or {}).get("neighbours_per_s"),
+                    "scan_n1024_x32_per_s": (ex.get("scan_full_neighbourhood_n1024_x32") or {}).get("neighbours_per_s"),
+                    "scan_n8192_x32_per_s": (ex.get("scan_full_neighbourhood_n8192_x32") or {}).get("neighbours_per_s"),
+                    "scan_other_sizes_verified": bool((ex.get("scan_full_neighbourhood_n1024_x32") or {}).get("verified_restart_0")
+                                                      and (ex.get("scan_full_neighbourhood_n8192_x32") or {}).get("verified_restart_0")),
                     "hbm_measured_bytes": hs.get("measured_hbm_bytes_per_launch"), "hbm_effective_over_peak": hs.get("effective_over_hbm_peak"),
                     "ls_step_us": st1.get("us_per_call_bare_c_entry") or st1.get("us_per_call"),
                     "c4_e2e_s": e2e.get("seconds"), "c4_e2e_per_s": e2e.get("neighbours_per_s"), "c4_e2e_equal": eq,
@@ -680,6 +684,33 @@ def extra_measurements(ctx, torch, dev, n, R, boards, cur_np, info, e2e=True, sc
         del rows64, cur64_d, cols64, nc64, res64
     except Exception as e:  # noqa: BLE001 - a secondary line must not take the bench down
         out["table_full_neighbourhood_64_restarts"] = {"error": repr(e)}
+    # the scan kernel's other tiers on full neighbourhoods: n = 1024 (16-register tier, config 2's size) and n = 8192 (the LDS
+    # kernel, 2048 of its columns); restart 0's record of each timed launch is re-checked against the oracle afterwards
+    if n == 4096:
+        for n2, R2, mc2 in ((1024, 32, 1024), (8192, 32, 2048)):
+            key = f"scan_full_neighbourhood_n{n2}_x{R2}"
+            try:
+                b2 = make_boards(n2, range(R2))
+                _, cur2 = ctx.nqueens_col_scores(b2)
+                rows2, cur2_d = torch.from_numpy(b2).to(dev), torch.from_numpy(cur2).to(dev)
+                cols2 = torch.arange(mc2, dtype=torch.int32, device=dev).repeat(R2, 1).contiguous()
+                nc2 = torch.full((R2,), mc2, dtype=torch.int32, device=dev)
+                res2 = torch.zeros((R2, 4), dtype=torch.int64, device=dev)
+                ctx.set_algo("scan")
+                s = timed(lambda: ctx.nqueens_eval_batch_dev(R2, n2, rows2.data_ptr(), cur2_d.data_ptr(), cols2.data_ptr(), nc2.data_ptr(),
+                                                             mc2, mc2 * (n2 - 1), res2.data_ptr()), 3)
+                torch.cuda.synchronize()
+                got = res2.cpu().numpy()[0]
+                if os.path.join(ROOT, "oracle") not in sys.path:
+                    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle as orc                                   # the checker, after the timed region
+                exp = orc.nq_neighbourhood(b2[0], np.arange(mc2), mc2 * (n2 - 1), "table", want_scores=False)
+                ok = (int(got[0]), int(got[1]), int(got[2])) == (exp["n_scored"], exp["best_index"], exp["best_score"])
+                out[key] = {"neighbours_per_s": R2 * mc2 * (n2 - 1) / s, "ms_per_launch": s * 1e3,
+                            "pair_checks_per_s": R2 * mc2 * (n2 - 1) / s * (n2 - 1), "columns": mc2, "verified_restart_0": bool(ok)}
+                del rows2, cur2_d, cols2, nc2, res2
+            except Exception as e:  # noqa: BLE001 - a secondary line must not take the bench down
+                out[key] = {"error": repr(e)}
     # the all-integer formulation of the scan kernel (BoardPk16: packed u16 xor / min / add, LS_NQ_SCAN_VARIANT=1) on the same
     # launch: the same results (parity-tested), half-rate instructions -- the fp32 product test is a speed choice, not a precision one
     try:
